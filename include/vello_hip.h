@@ -1,0 +1,172 @@
+/*
+ * vello_hip.h -- C ABI of the MI355X (gfx950) engine that replaces vello's wgpu compute path.
+ *
+ * Drop-in boundary: everything above this file stays the reference's host code
+ * (vello::Scene -> vello_encoding::Encoding -> Resolver::resolve -> packed scene bytes + Layout);
+ * everything below it (vello/src/wgpu_engine.rs WgpuEngine::run_recording, the Recording built by
+ * vello/src/render.rs:135-629, and the 22 WGSL entry points of vello_shaders/shader/) is replaced
+ * by this library.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Reference interface replaced by each entry point:
+ *   vello_hip_create           vello::Renderer::new                      vello/src/lib.rs:432-459
+ *                              (+ shaders::full_shaders                  vello/src/shaders.rs:48-274)
+ *   vello_hip_destroy          Drop for Renderer / WgpuEngine
+ *   vello_hip_render           Renderer::render_to_texture               vello/src/lib.rs:474-515
+ *                              = render_full + WgpuEngine::run_recording vello/src/render.rs:84-112,
+ *                                                                        vello/src/wgpu_engine.rs:380-777
+ *   vello_hip_upload_scene     Command::Upload("vello.scene") +          vello/src/render.rs:229-232,
+ *                              Command::UploadUniform("vello.config")    vello/src/recording.rs:124-140
+ *   vello_hip_render_resident  the Dispatch/DispatchIndirect chain       vello/src/render.rs:250-502, :560-629
+ *   vello_hip_sync             queue.submit + device.poll                vello/src/wgpu_engine.rs:757
+ *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
+ *   vello_hip_run_stages /     CpuShaderType::Present per-stage seam     vello/src/wgpu_engine.rs:57-61, :541-553,
+ *   vello_hip_{read,write}_buffer  (CpuBinding byte buffers)             vello_shaders/src/cpu.rs:58-62
+ *   vello_hip_set_profiling /  wgpu-profiler per-dispatch GPU timestamps vello/src/wgpu_engine.rs:570-588
+ *   vello_hip_get_stage_ms
+ */
+#ifndef VELLO_HIP_H
+#define VELLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vello_hip_ctx vello_hip_ctx;
+
+/* vello_encoding::Layout, vello_encoding/src/resolve.rs:18-39 (10 x u32, offsets in u32 words) */
+typedef struct vello_hip_layout {
+    uint32_t n_draw_objects, n_paths, n_clips, bin_data_start;
+    uint32_t path_tag_base, path_data_base, draw_tag_base, draw_data_base;
+    uint32_t transform_base, style_base;
+} vello_hip_layout;
+
+/* vello::AaConfig, vello/src/lib.rs:175-193 */
+enum { VELLO_HIP_AA_AREA = 0, VELLO_HIP_AA_MSAA8 = 1, VELLO_HIP_AA_MSAA16 = 2 };
+/* vello::AaSupport bits for vello_hip_create(aa_mask) */
+enum { VELLO_HIP_AA_MASK_AREA = 1, VELLO_HIP_AA_MASK_MSAA8 = 2, VELLO_HIP_AA_MASK_MSAA16 = 4, VELLO_HIP_AA_MASK_ALL = 7 };
+
+/* vello::RenderParams, vello/src/lib.rs:357-369.  base_color is premultiplied RGBA8 packed with
+ * R in the low byte (vello_encoding/src/config.rs:183). */
+typedef struct vello_hip_render_params {
+    uint32_t width, height;
+    uint32_t base_color;
+    uint32_t aa; /* VELLO_HIP_AA_* */
+} vello_hip_render_params;
+
+/* vello_encoding::BumpAllocators, vello_encoding/src/config.rs:24-37 */
+typedef struct vello_hip_bump {
+    uint32_t failed, binning, ptcl, tile, seg_counts, segments, blend, lines;
+} vello_hip_bump;
+
+/* Capacities of the bump-allocated pools in elements.  Zero fields take the reference's
+ * hand-picked sizes (vello_encoding/src/config.rs:398-408). */
+typedef struct vello_hip_capacities {
+    uint32_t lines, bin_data, tiles, seg_counts, segments, blend_spill, ptcl;
+} vello_hip_capacities;
+
+/* Error codes (0 = ok).  Capacity overflow mirrors the reference protocol: the target is left
+ * untouched (fine.wgsl:1070-1074) and additionally VELLO_HIP_E_CAPACITY is returned by
+ * vello_hip_sync / vello_hip_render with the counters available through vello_hip_get_bump. */
+enum {
+    VELLO_HIP_OK = 0,
+    VELLO_HIP_E_INVALID = -1,   /* bad argument / AA mode not enabled at create (render.rs:566-598 panics) */
+    VELLO_HIP_E_HIP = -2,       /* HIP runtime error; see vello_hip_last_error */
+    VELLO_HIP_E_NO_DEVICE = -3, /* no gfx950 device / kernels missing: never falls back to a CPU path */
+    VELLO_HIP_E_CAPACITY = -4   /* bump.failed != 0 */
+};
+
+/* Stage ids (launch order; render.rs:250-502, :560-629).  Several reference dispatches are fused:
+ * PATHTAG_SCAN = pathtag_reduce(+2)/scan(1)/scan + bbox_clear, DRAW_SCAN = draw_reduce + draw_leaf,
+ * CLIP = clip_reduce + clip_leaf, PATH_COUNT/PATH_TILING include their *_setup dispatch. */
+enum {
+    VELLO_HIP_STAGE_PATHTAG_SCAN = 0,
+    VELLO_HIP_STAGE_FLATTEN,
+    VELLO_HIP_STAGE_DRAW_SCAN,
+    VELLO_HIP_STAGE_CLIP,
+    VELLO_HIP_STAGE_BINNING,
+    VELLO_HIP_STAGE_TILE_ALLOC,
+    VELLO_HIP_STAGE_PATH_COUNT,
+    VELLO_HIP_STAGE_BACKDROP,
+    VELLO_HIP_STAGE_COARSE,
+    VELLO_HIP_STAGE_PATH_TILING,
+    VELLO_HIP_STAGE_FINE,
+    VELLO_HIP_STAGE_COUNT
+};
+
+/* Buffer ids for the differential-test seam (byte layouts = the reference's). */
+enum {
+    VELLO_HIP_BUF_SCENE = 0,
+    VELLO_HIP_BUF_CONFIG,        /* ConfigUniform, 88 B */
+    VELLO_HIP_BUF_TAG_MONOIDS,   /* PathMonoid[Tw], 20 B */
+    VELLO_HIP_BUF_PATH_BBOXES,   /* PathBbox[P], 24 B */
+    VELLO_HIP_BUF_BUMP,          /* BumpAllocators, 32 B */
+    VELLO_HIP_BUF_LINES,         /* LineSoup[], 24 B */
+    VELLO_HIP_BUF_DRAW_MONOIDS,  /* DrawMonoid[D], 16 B */
+    VELLO_HIP_BUF_INFO_BIN_DATA, /* u32[] */
+    VELLO_HIP_BUF_CLIP_INP,      /* Clip[K], 8 B */
+    VELLO_HIP_BUF_CLIP_BBOXES,   /* f32x4[K] */
+    VELLO_HIP_BUF_DRAW_BBOXES,   /* f32x4[D] */
+    VELLO_HIP_BUF_BIN_HEADERS,   /* BinHeader[], 8 B */
+    VELLO_HIP_BUF_PATHS,         /* Path[], 32 B */
+    VELLO_HIP_BUF_TILES,         /* Tile[], 8 B */
+    VELLO_HIP_BUF_SEG_COUNTS,    /* SegmentCount[], 8 B */
+    VELLO_HIP_BUF_SEGMENTS,      /* PathSegment[], 24 B */
+    VELLO_HIP_BUF_PTCL,          /* u32[] */
+    VELLO_HIP_BUF_BLEND_SPILL,   /* u32[] */
+    VELLO_HIP_BUF_OUTPUT,        /* internal RGBA8 target, width*height*4 */
+    VELLO_HIP_BUF_COUNT
+};
+
+/* Creates an engine bound to HIP device `device`.  Fails with VELLO_HIP_E_NO_DEVICE when no GPU is
+ * present; there is no CPU fallback. */
+int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *caps /* nullable */, vello_hip_ctx **out);
+void vello_hip_destroy(vello_hip_ctx *ctx);
+
+/* One frame, host buffers in, blocking: upload + render + (optional) copy out.
+ * `out_rgba8` receives un-premultiplied RGBA8 rows of `out_stride` bytes (fine.wgsl:1386-1397);
+ * it is a device pointer when out_is_device != 0, else host memory.  `ramps` is the gradient
+ * ramp texture (512 RGBA8 texels per ramp, vello_encoding/src/ramp_cache.rs:12) or NULL.
+ * `bump_out` (nullable) receives the bump counters. */
+int vello_hip_render(vello_hip_ctx *ctx, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                     const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_rgba8,
+                     size_t out_stride, int out_is_device, vello_hip_bump *bump_out);
+
+/* Split form used for steady-state measurement: the packed scene is made resident once ... */
+int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                           const uint32_t *ramps, uint32_t n_ramps);
+/* ... then each call enqueues one full frame (all stages) on the context's stream and returns
+ * without waiting.  `out_device` may be NULL (render into the internal target only). */
+int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
+/* Waits for everything enqueued; returns VELLO_HIP_E_CAPACITY if the last frame overflowed. */
+int vello_hip_sync(vello_hip_ctx *ctx);
+int vello_hip_get_bump(vello_hip_ctx *ctx, vello_hip_bump *out);
+/* The hipStream_t the context launches on (for callers that record their own events). */
+void *vello_hip_get_stream(vello_hip_ctx *ctx);
+
+/* Differential-test seam: run stages [first, last] of the resident scene; read/write any buffer. */
+int vello_hip_run_stages(vello_hip_ctx *ctx, const vello_hip_render_params *params, int first_stage, int last_stage);
+int vello_hip_read_buffer(vello_hip_ctx *ctx, int buf_id, void *dst, size_t offset, size_t size);
+int vello_hip_write_buffer(vello_hip_ctx *ctx, int buf_id, const void *src, size_t offset, size_t size);
+size_t vello_hip_buffer_size(vello_hip_ctx *ctx, int buf_id);
+
+/* Per-stage GPU timing with hipEvents on the launch stream.  stage_mask bit i enables events
+ * around stage i; times accumulate until read.  vello_hip_get_stage_ms syncs, writes the summed
+ * milliseconds and launch counts per stage, and resets the accumulators. */
+int vello_hip_set_profiling(vello_hip_ctx *ctx, uint32_t stage_mask);
+int vello_hip_get_stage_ms(vello_hip_ctx *ctx, float ms_out[VELLO_HIP_STAGE_COUNT], uint32_t count_out[VELLO_HIP_STAGE_COUNT]);
+
+const char *vello_hip_stage_name(int stage);
+const char *vello_hip_last_error(vello_hip_ctx *ctx /* nullable: last create() error */);
+
+/* vello_encoding::make_mask_lut / make_mask_lut_16 (vello_encoding/src/mask.rs:36-98); exported so
+ * the host can check the persistent LUT the engine keeps on the device. */
+void vello_hip_make_mask_lut(uint8_t out[1024]);
+void vello_hip_make_mask_lut_16(uint8_t out[8192]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

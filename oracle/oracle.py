@@ -1,0 +1,118 @@
+"""ctypes wrapper of the CPU oracle (oracle/libvello_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg, never by vello_amd.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+STAGES = ["pathtag_scan", "flatten", "draw_scan", "clip", "binning", "tile_alloc", "path_count", "backdrop", "coarse",
+          "path_tiling", "fine"]
+BUFFERS = ["tag_monoids", "path_bboxes", "bump", "lines", "draw_monoids", "info_bin_data", "clip_inp", "clip_bboxes",
+           "draw_bboxes", "bin_headers", "paths", "tiles", "seg_counts", "segments", "ptcl", "blend_spill", "output"]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libvello_oracle.so")
+        if not os.path.exists(path):
+            build()
+        lib = ctypes.CDLL(path)
+        vp, u32, i32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_size_t
+        lib.vo_create.restype = vp
+        lib.vo_create.argtypes = [u32]
+        lib.vo_destroy.argtypes = [vp]
+        lib.vo_set_scene.restype = i32
+        lib.vo_set_scene.argtypes = [vp, vp, sz, vp, u32, u32, u32, i32]
+        lib.vo_set_ramps.argtypes = [vp, vp, u32]
+        lib.vo_get_config.restype = vp
+        lib.vo_get_config.argtypes = [vp]
+        lib.vo_run.restype = i32
+        lib.vo_run.argtypes = [vp, i32, i32]
+        lib.vo_render.restype = i32
+        lib.vo_render.argtypes = [vp, vp]
+        lib.vo_buffer.restype = vp
+        lib.vo_buffer.argtypes = [vp, i32, ctypes.POINTER(sz)]
+        lib.vo_make_mask_lut.argtypes = [vp]
+        lib.vo_make_mask_lut_16.argtypes = [vp]
+        lib.vo_set_threads.argtypes = [vp, i32]
+        _LIB = lib
+    return _LIB
+
+
+def make_mask_lut():
+    out = np.zeros(1024, dtype=np.uint8)
+    _lib().vo_make_mask_lut(out.ctypes.data)
+    return out
+
+
+def make_mask_lut_16():
+    out = np.zeros(8192, dtype=np.uint8)
+    _lib().vo_make_mask_lut_16(out.ctypes.data)
+    return out
+
+
+class Oracle:
+    def __init__(self, capacity_scale=1):
+        self._lib = _lib()
+        self._h = self._lib.vo_create(capacity_scale)
+        self.width = self.height = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.vo_destroy(self._h)
+        except Exception:
+            pass
+        self._h = None
+
+    def set_threads(self, n):
+        self._lib.vo_set_threads(self._h, n)
+
+    def set_scene(self, packed, layout, width, height, base_color_rgba8, aa):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        lay = (ctypes.c_uint32 * 10)(*layout)
+        r = self._lib.vo_set_scene(self._h, packed.ctypes.data, packed.nbytes, lay, width, height, int(base_color_rgba8), int(aa))
+        if r != 0:
+            raise RuntimeError("vo_set_scene failed")
+        self.width, self.height = width, height
+
+    def config(self):
+        p = self._lib.vo_get_config(self._h)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint32)), shape=(22,)).copy()
+
+    def run(self, first, last):
+        first = STAGES.index(first) if isinstance(first, str) else first
+        last = STAGES.index(last) if isinstance(last, str) else last
+        if self._lib.vo_run(self._h, first, last) != 0:
+            raise RuntimeError("vo_run failed")
+
+    def render(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        r = self._lib.vo_render(self._h, out.ctypes.data)
+        if r < 0:
+            raise RuntimeError("vo_render failed")
+        return out
+
+    def buffer(self, name, dtype=np.uint8):
+        """Live view of an intermediate buffer (valid until the next set_scene)."""
+        size = ctypes.c_size_t()
+        p = self._lib.vo_buffer(self._h, BUFFERS.index(name), ctypes.byref(size))
+        a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(size.value,))
+        n = size.value - size.value % np.dtype(dtype).itemsize
+        return a[:n].view(dtype)
+
+    def bump(self):
+        b = self.buffer("bump", np.uint32)[:8]
+        return dict(zip(["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"], [int(v) for v in b]))

@@ -1,0 +1,161 @@
+// Shared definitions for the gfx950 kernels: reference byte layouts,
+// numeric rules, and wave64 / workgroup primitives.
+//
+// Numeric rules (DESIGN.md "numerics"):
+//  * compiled with -ffp-contract=off -fno-fast-math: the tile/pixel DDA in path_count, path_tiling
+//    and fine recomputes floor(a*i+b) three times and must agree bit for bit;
+//  * fma only where flatten.wgsl:668-672 spells fma();
+//  * f32 transcendentals = fp64 ocml value rounded once to f32 (MI355X runs fp64 at half the fp32
+//    vector rate), which equals the correctly rounded result up to ~2^-29 per call and is what the
+//    CPU oracle computes with libm;
+//  * WGSL u32(f32)/i32(f32) are saturating, round() is ties-to-even.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vk {
+
+// ---------------- layouts ----------------
+struct Layout {
+    uint32_t n_draw_objects, n_paths, n_clips, bin_data_start;
+    uint32_t path_tag_base, path_data_base, draw_tag_base, draw_data_base, transform_base, style_base;
+};
+struct Config {  // vello_encoding/src/config.rs:124-154
+    uint32_t width_in_tiles, height_in_tiles, target_width, target_height, base_color;
+    Layout layout;
+    uint32_t lines_size, binning_size, tiles_size, seg_counts_size, segments_size, blend_size, ptcl_size;
+};
+struct Bump {  // config.rs:24-37
+    uint32_t failed, binning, ptcl, tile, seg_counts, segments, blend, lines;
+};
+struct TagMonoid { uint32_t trans_ix, pathseg_ix, pathseg_offset, style_ix, path_ix; };
+struct PathBbox { int32_t x0, y0, x1, y1; uint32_t draw_flags, trans_ix; };
+struct LineSoup { uint32_t path_ix, pad; float p0x, p0y, p1x, p1y; };
+struct SegmentCount { uint32_t line_ix, counts; };
+struct Segment { float p0x, p0y, p1x, p1y, y_edge; uint32_t pad; };
+struct Path { uint32_t bbox[4]; uint32_t tiles; uint32_t pad[3]; };
+struct Tile { int32_t backdrop; uint32_t segment_count_or_ix; };
+struct DrawMonoid { uint32_t path_ix, clip_ix, scene_offset, info_offset; };
+struct Clip { uint32_t ix; int32_t path_ix; };
+struct BinHeader { uint32_t element_count, chunk_offset; };
+struct Bbox4 { float x0, y0, x1, y1; };
+
+static_assert(sizeof(Config) == 88, "ConfigUniform");
+static_assert(sizeof(Bump) == 32, "BumpAllocators");
+static_assert(sizeof(TagMonoid) == 20, "PathMonoid");
+static_assert(sizeof(PathBbox) == 24, "PathBbox");
+static_assert(sizeof(LineSoup) == 24, "LineSoup");
+static_assert(sizeof(Segment) == 24, "PathSegment");
+static_assert(sizeof(Path) == 32, "Path");
+static_assert(sizeof(Tile) == 8, "Tile");
+static_assert(sizeof(DrawMonoid) == 16, "DrawMonoid");
+
+// ---------------- constants ----------------
+constexpr uint32_t TILE_WIDTH = 16, TILE_HEIGHT = 16, N_TILE_X = 16, N_TILE_Y = 16, N_TILE = 256;
+constexpr uint32_t PATH_TAG_SEG_TYPE = 3, PATH_TAG_LINETO = 1, PATH_TAG_QUADTO = 2, PATH_TAG_CUBICTO = 3;
+constexpr uint32_t PATH_TAG_F32 = 8, PATH_TAG_TRANSFORM = 0x20, PATH_TAG_PATH = 0x10, PATH_TAG_STYLE = 0x40;
+constexpr uint32_t PATH_TAG_SUBPATH_END = 4, STYLE_SIZE_IN_WORDS = 2;
+constexpr uint32_t STYLE_FLAGS_STYLE = 0x80000000u, STYLE_FLAGS_FILL = 0x40000000u, STYLE_MITER_LIMIT_MASK = 0xFFFFu;
+constexpr uint32_t STYLE_FLAGS_START_CAP_MASK = 0x0C000000u, STYLE_FLAGS_END_CAP_MASK = 0x03000000u;
+constexpr uint32_t STYLE_FLAGS_CAP_SQUARE = 0x01000000u, STYLE_FLAGS_CAP_ROUND = 0x02000000u;
+constexpr uint32_t STYLE_FLAGS_JOIN_MASK = 0x30000000u, STYLE_FLAGS_JOIN_BEVEL = 0u;
+constexpr uint32_t STYLE_FLAGS_JOIN_MITER = 0x10000000u, STYLE_FLAGS_JOIN_ROUND = 0x20000000u;
+constexpr uint32_t DRAWTAG_NOP = 0, DRAWTAG_FILL_COLOR = 0x44, DRAWTAG_FILL_LIN_GRADIENT = 0x114;
+constexpr uint32_t DRAWTAG_FILL_RAD_GRADIENT = 0x29c, DRAWTAG_FILL_SWEEP_GRADIENT = 0x254, DRAWTAG_FILL_IMAGE = 0x28C;
+constexpr uint32_t DRAWTAG_BLURRED_ROUNDED_RECT = 0x2d4, DRAWTAG_BEGIN_CLIP = 0x49, DRAWTAG_END_CLIP = 0x21;
+constexpr uint32_t DRAW_INFO_FLAGS_FILL_RULE_BIT = 1;
+constexpr uint32_t STAGE_BINNING = 0x1, STAGE_TILE_ALLOC = 0x2, STAGE_FLATTEN = 0x4, STAGE_PATH_COUNT = 0x8, STAGE_COARSE = 0x10;
+constexpr uint32_t PTCL_INITIAL_ALLOC = 64, PTCL_INCREMENT = 256, PTCL_HEADROOM = 2;
+constexpr uint32_t CMD_END = 0, CMD_FILL = 1, CMD_SOLID = 3, CMD_COLOR = 5, CMD_LIN_GRAD = 6, CMD_RAD_GRAD = 7;
+constexpr uint32_t CMD_SWEEP_GRAD = 8, CMD_IMAGE = 9, CMD_BEGIN_CLIP = 10, CMD_END_CLIP = 11, CMD_JUMP = 12, CMD_BLUR_RECT = 13;
+constexpr uint32_t BLEND_STACK_SPLIT = 4;
+constexpr uint32_t RAD_GRAD_KIND_CIRCULAR = 1, RAD_GRAD_KIND_STRIP = 2, RAD_GRAD_KIND_FOCAL_ON_CIRCLE = 3, RAD_GRAD_KIND_CONE = 4;
+constexpr uint32_t RAD_GRAD_SWAPPED = 1;
+constexpr float ONE_MINUS_ULP = 0.99999994f;
+constexpr float ROBUST_EPSILON = 2e-7f;
+
+// ---------------- scalar helpers ----------------
+__device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float cos_cr(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float atan2_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+__device__ __forceinline__ float asin_cr(float x) { return (float)asin((double)x); }
+__device__ __forceinline__ float acos_cr(float x) { return (float)acos((double)x); }
+__device__ __forceinline__ float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+
+__device__ __forceinline__ uint32_t f2u(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+__device__ __forceinline__ int32_t f2i(float f) {
+    if (f != f) return 0;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    if (f >= 2147483648.0f) return 0x7fffffff;
+    return (int32_t)f;
+}
+__device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ float minf(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float maxf(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }
+__device__ __forceinline__ float roundf_te(float x) { return rintf(x); }
+__device__ __forceinline__ int32_t mini(int32_t a, int32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int32_t maxi(int32_t a, int32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ int32_t clampi(int32_t x, int32_t lo, int32_t hi) { return mini(maxi(x, lo), hi); }
+__device__ __forceinline__ uint32_t minu(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t maxu(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t span(float a, float b) {
+    return f2u(maxf(ceilf(maxf(a, b)) - floorf(minf(a, b)), 1.0f));
+}
+
+struct vec2 {
+    float x, y;
+};
+__device__ __forceinline__ vec2 v2(float x, float y) { return vec2{x, y}; }
+__device__ __forceinline__ vec2 operator+(vec2 a, vec2 b) { return vec2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ vec2 operator-(vec2 a, vec2 b) { return vec2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ vec2 operator*(vec2 a, float s) { return vec2{a.x * s, a.y * s}; }
+__device__ __forceinline__ vec2 operator-(vec2 a) { return vec2{-a.x, -a.y}; }
+__device__ __forceinline__ float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ float length(vec2 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ vec2 normalize(vec2 a) {
+    float l = length(a);
+    return vec2{a.x / l, a.y / l};
+}
+
+struct Xform {
+    float m0, m1, m2, m3, t0, t1;
+};
+__device__ __forceinline__ Xform read_transform(const uint32_t *scene, uint32_t base, uint32_t ix) {
+    const uint32_t *p = scene + base + ix * 6u;
+    return Xform{__uint_as_float(p[0]), __uint_as_float(p[1]), __uint_as_float(p[2]),
+                 __uint_as_float(p[3]), __uint_as_float(p[4]), __uint_as_float(p[5])};
+}
+
+// ---------------- wave64 / workgroup primitives ----------------
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// Inclusive scan over a 256-thread workgroup (4 waves): wave shuffles + one LDS hop.
+// `sh` needs 4 entries.  Returns the inclusive prefix; *total receives the workgroup sum.
+__device__ __forceinline__ uint32_t block256_incl_scan_u32(uint32_t v, uint32_t *sh, uint32_t *total) {
+    int tid = threadIdx.x;
+    int lane = tid & 63, w = tid >> 6;
+    uint32_t s = wave_incl_scan_u32(v, lane);
+    __syncthreads();  // protect sh from a previous use
+    if (lane == 63) sh[w] = s;
+    __syncthreads();
+    uint32_t s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+    uint32_t add = (w > 0 ? s0 : 0u) + (w > 1 ? s1 : 0u) + (w > 2 ? s2 : 0u);
+    *total = s0 + s1 + s2 + s3;
+    return s + add;
+}
+
+}  // namespace vk

@@ -1,0 +1,80 @@
+// Engine-internal interface between the host driver (engine.hip) and the kernel translation units.
+#pragma once
+#include "common.h"
+
+namespace vk {
+
+// Single-pass decoupled look-back state: per partition, NF granules for the workgroup aggregate
+// followed by NF granules for the inclusive prefix.  A granule is one naturally aligned 8-byte
+// {status:32, value:32} word written exactly once per frame by ONE relaxed agent-scope store
+// (write-through), so it is never torn and needs no separate flag or fence
+// (cdna_hip_programming.md guideline 16, form R2).
+constexpr uint32_t SCAN_STATUS_AGG = 1, SCAN_STATUS_PREFIX = 2;
+constexpr uint32_t PATHTAG_PART_WORDS = 1024;  // 256 threads x 4 tag words (= 4096 tags)
+constexpr uint32_t DRAW_PART = 256;            // draw objects per partition
+constexpr uint32_t FLATTEN_TAGS_PER_THREAD = 4;
+constexpr uint32_t FLATTEN_BLOCK_TAGS = 256 * FLATTEN_TAGS_PER_THREAD;
+constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = 8;
+constexpr uint32_t PATH_COUNT_CHUNK = 256 * PATH_COUNT_LINES_PER_THREAD;
+// Spin bound for look-back waits: a predecessor always holds a smaller ticket, so it is resident
+// or finished; the bound only turns a driver-level hang into a reported failure.
+constexpr uint32_t SPIN_LIMIT = 1u << 24;
+constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a spin bound trips
+
+// Words of the per-frame control block (zeroed by ONE hipMemsetAsync per frame, together with
+// the bump allocators and both look-back state arrays which follow it in the same allocation).
+struct Control {
+    Bump bump;              // must be first: VELLO_HIP_BUF_BUMP aliases it
+    uint32_t ticket_pathtag;
+    uint32_t ticket_draw;
+    uint32_t pad[6];
+};
+static_assert(sizeof(Control) == 64, "Control");
+
+struct Frame {
+    Config cfg;  // host copy; kernels receive it by value
+    uint32_t n_tag_words;
+    uint32_t aa;
+    // device pointers
+    const uint32_t *scene;
+    Control *control;
+    unsigned long long *pathtag_state;  // [n_pathtag_parts][2][5]
+    unsigned long long *draw_state;     // [n_draw_parts][2][4]
+    TagMonoid *tag_monoids;
+    PathBbox *path_bboxes;
+    LineSoup *lines;
+    DrawMonoid *draw_monoids;
+    uint32_t *info_bin_data;
+    Clip *clip_inp;
+    Bbox4 *clip_bboxes;
+    Bbox4 *draw_bboxes;
+    BinHeader *bin_headers;
+    Path *paths;
+    Tile *tiles;
+    SegmentCount *seg_counts;
+    Segment *segments;
+    uint32_t *ptcl;
+    uint32_t *blend_spill;
+    uint32_t *clip_stack;  // spill area for clip stacks deeper than the LDS window
+    uint8_t *output;
+    size_t out_stride;
+    const uint32_t *ramps;
+    uint32_t n_ramps;
+    const uint32_t *mask_lut8;
+    const uint32_t *mask_lut16;
+    Bump *bump() const { return &control->bump; }
+};
+
+void launch_pathtag_scan(const Frame &f, hipStream_t s);
+void launch_flatten(const Frame &f, hipStream_t s);
+void launch_draw_scan(const Frame &f, hipStream_t s);
+void launch_clip(const Frame &f, hipStream_t s);
+void launch_binning(const Frame &f, hipStream_t s);
+void launch_tile_alloc(const Frame &f, hipStream_t s);
+void launch_path_count(const Frame &f, hipStream_t s);
+void launch_backdrop(const Frame &f, hipStream_t s);
+void launch_coarse(const Frame &f, hipStream_t s);
+void launch_path_tiling(const Frame &f, hipStream_t s);
+void launch_fine(const Frame &f, hipStream_t s);
+
+}  // namespace vk

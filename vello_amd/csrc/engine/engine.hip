@@ -1,0 +1,532 @@
+// Host driver of the gfx950 engine and the C ABI of include/vello_hip.h.
+// Replaces WgpuEngine::run_recording (vello/src/wgpu_engine.rs:380-777) and the Recording built by
+// Render::render_encoding_coarse / record_fine (vello/src/render.rs:135-629): the recording is a
+// fixed launch sequence here, the ResourcePool (wgpu_engine.rs:972-1000) becomes a set of device
+// buffers owned by the context and reused across frames.
+#include "../../../include/vello_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace vk;
+
+namespace {
+
+std::string g_create_error;
+
+const char *kStageNames[VELLO_HIP_STAGE_COUNT] = {"pathtag_scan", "flatten",  "draw_scan", "clip",        "binning", "tile_alloc",
+                                                  "path_count",   "backdrop", "coarse",    "path_tiling", "fine"};
+
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t size = 0;
+};
+
+uint32_t align_up(uint32_t len, uint32_t alignment) { return len + ((0u - len) & (alignment - 1u)); }
+
+}  // namespace
+
+struct vello_hip_ctx {
+    int device = 0;
+    uint32_t aa_mask = 0;
+    hipStream_t stream = nullptr;
+    vello_hip_capacities caps{};
+    DevBuf buf[VELLO_HIP_BUF_COUNT];
+    DevBuf zero_region;  // Control + look-back states (BUF_BUMP aliases its head)
+    DevBuf clip_stack, ramps, mask8, mask16;
+    uint32_t n_ramps = 0;
+    bool scene_resident = false;
+    vello_hip_layout layout{};
+    size_t scene_len = 0;
+    uint32_t n_tag_words = 0, n_pathtag_parts = 0, n_draw_parts = 0;
+    size_t zero_bytes = 0;
+    // last frame
+    Config cfg{};
+    bool have_cfg = false;
+    // profiling
+    uint32_t prof_mask = 0;
+    struct EvPair {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> events;
+    std::vector<hipEvent_t> event_pool;
+    float stage_ms[VELLO_HIP_STAGE_COUNT] = {};
+    uint32_t stage_count[VELLO_HIP_STAGE_COUNT] = {};
+    std::string last_error;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                             \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return VELLO_HIP_E_HIP;                                                                    \
+        }                                                                                              \
+    } while (0)
+
+int ensure(vello_hip_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 256;
+    if (b.size >= bytes) return 0;
+    if (b.ptr) HIP_TRY(c, hipFree(b.ptr));
+    b.ptr = nullptr;
+    b.size = 0;
+    HIP_TRY(c, hipMalloc(&b.ptr, bytes + 256));
+    b.size = bytes;
+    return 0;
+}
+
+hipEvent_t get_event(vello_hip_ctx *c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// RenderConfig::new + BufferSizes::new, vello_encoding/src/config.rs:168-196, :363-435
+int configure(vello_hip_ctx *c, const vello_hip_render_params *p, Config &cfg) {
+    if (!p || p->width == 0 || p->height == 0 || p->aa > VELLO_HIP_AA_MSAA16) {
+        c->last_error = "invalid render params";
+        return VELLO_HIP_E_INVALID;
+    }
+    if (((c->aa_mask >> p->aa) & 1u) == 0u) {
+        // render.rs:566-568, :593-598: "shaders not configured to support AA mode"
+        c->last_error = "AA mode was not enabled in vello_hip_create(aa_mask)";
+        return VELLO_HIP_E_INVALID;
+    }
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.width_in_tiles = align_up(p->width, TILE_WIDTH) / TILE_WIDTH;
+    cfg.height_in_tiles = align_up(p->height, TILE_HEIGHT) / TILE_HEIGHT;
+    cfg.target_width = p->width;
+    cfg.target_height = p->height;
+    cfg.base_color = p->base_color;
+    std::memcpy(&cfg.layout, &c->layout, sizeof(Layout));
+    uint32_t bin_data = c->caps.bin_data;
+    if (bin_data <= c->layout.bin_data_start) {
+        c->last_error = "bin_data capacity smaller than the scene's info words";
+        return VELLO_HIP_E_INVALID;
+    }
+    cfg.lines_size = c->caps.lines;
+    cfg.binning_size = bin_data - c->layout.bin_data_start;
+    cfg.tiles_size = c->caps.tiles;
+    cfg.seg_counts_size = c->caps.seg_counts;
+    cfg.segments_size = c->caps.segments;
+    cfg.blend_size = c->caps.blend_spill;
+    cfg.ptcl_size = c->caps.ptcl;
+    uint64_t initial_ptcl = (uint64_t)cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
+    if (initial_ptcl + PTCL_INCREMENT > cfg.ptcl_size) {
+        c->last_error = "ptcl capacity smaller than the fixed per-tile allocation";
+        return VELLO_HIP_E_INVALID;
+    }
+    return 0;
+}
+
+int prepare_frame(vello_hip_ctx *c, const vello_hip_render_params *p, void *out_device, size_t out_stride, Frame &f, bool upload_cfg) {
+    if (!c->scene_resident) {
+        c->last_error = "no scene uploaded";
+        return VELLO_HIP_E_INVALID;
+    }
+    int r = configure(c, p, f.cfg);
+    if (r) return r;
+    c->cfg = f.cfg;
+    c->have_cfg = true;
+    // size-dependent buffers
+    uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
+    uint32_t aligned_n_bins = align_up(wb * hb, 256u);
+    uint32_t binning_wgs = (c->layout.n_draw_objects + 255u) / 256u;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
+    // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
+    if (upload_cfg) HIP_TRY(c, hipMemcpy(c->buf[VELLO_HIP_BUF_CONFIG].ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
+    f.n_tag_words = c->n_tag_words;
+    f.aa = p->aa;
+    f.scene = (const uint32_t *)c->buf[VELLO_HIP_BUF_SCENE].ptr;
+    f.control = (Control *)c->zero_region.ptr;
+    f.pathtag_state = (unsigned long long *)((char *)c->zero_region.ptr + sizeof(Control));
+    f.draw_state = f.pathtag_state + (size_t)c->n_pathtag_parts * 10u;
+    f.tag_monoids = (TagMonoid *)c->buf[VELLO_HIP_BUF_TAG_MONOIDS].ptr;
+    f.path_bboxes = (PathBbox *)c->buf[VELLO_HIP_BUF_PATH_BBOXES].ptr;
+    f.lines = (LineSoup *)c->buf[VELLO_HIP_BUF_LINES].ptr;
+    f.draw_monoids = (DrawMonoid *)c->buf[VELLO_HIP_BUF_DRAW_MONOIDS].ptr;
+    f.info_bin_data = (uint32_t *)c->buf[VELLO_HIP_BUF_INFO_BIN_DATA].ptr;
+    f.clip_inp = (Clip *)c->buf[VELLO_HIP_BUF_CLIP_INP].ptr;
+    f.clip_bboxes = (Bbox4 *)c->buf[VELLO_HIP_BUF_CLIP_BBOXES].ptr;
+    f.draw_bboxes = (Bbox4 *)c->buf[VELLO_HIP_BUF_DRAW_BBOXES].ptr;
+    f.bin_headers = (BinHeader *)c->buf[VELLO_HIP_BUF_BIN_HEADERS].ptr;
+    f.paths = (Path *)c->buf[VELLO_HIP_BUF_PATHS].ptr;
+    f.tiles = (Tile *)c->buf[VELLO_HIP_BUF_TILES].ptr;
+    f.seg_counts = (SegmentCount *)c->buf[VELLO_HIP_BUF_SEG_COUNTS].ptr;
+    f.segments = (Segment *)c->buf[VELLO_HIP_BUF_SEGMENTS].ptr;
+    f.ptcl = (uint32_t *)c->buf[VELLO_HIP_BUF_PTCL].ptr;
+    f.blend_spill = (uint32_t *)c->buf[VELLO_HIP_BUF_BLEND_SPILL].ptr;
+    f.clip_stack = (uint32_t *)c->clip_stack.ptr;
+    if (out_device) {
+        f.output = (uint8_t *)out_device;
+        f.out_stride = out_stride ? out_stride : (size_t)p->width * 4u;
+    } else {
+        f.output = (uint8_t *)c->buf[VELLO_HIP_BUF_OUTPUT].ptr;
+        f.out_stride = (size_t)p->width * 4u;
+    }
+    f.ramps = c->n_ramps ? (const uint32_t *)c->ramps.ptr : nullptr;
+    f.n_ramps = c->n_ramps;
+    f.mask_lut8 = (const uint32_t *)c->mask8.ptr;
+    f.mask_lut16 = (const uint32_t *)c->mask16.ptr;
+    return 0;
+}
+
+int run_stage_range(vello_hip_ctx *c, const Frame &f, int first, int last) {
+    for (int s = first; s <= last; s++) {
+        bool prof = ((c->prof_mask >> s) & 1u) != 0u;
+        vello_hip_ctx::EvPair ev{s, nullptr, nullptr};
+        if (prof) {
+            ev.a = get_event(c);
+            ev.b = get_event(c);
+            HIP_TRY(c, hipEventRecord(ev.a, c->stream));
+        }
+        switch (s) {
+        case VELLO_HIP_STAGE_PATHTAG_SCAN:
+            // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
+            HIP_TRY(c, hipMemsetAsync(c->zero_region.ptr, 0, c->zero_bytes, c->stream));
+            launch_pathtag_scan(f, c->stream);
+            break;
+        case VELLO_HIP_STAGE_FLATTEN: launch_flatten(f, c->stream); break;
+        case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, c->stream); break;
+        case VELLO_HIP_STAGE_CLIP: launch_clip(f, c->stream); break;
+        case VELLO_HIP_STAGE_BINNING: launch_binning(f, c->stream); break;
+        case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, c->stream); break;
+        case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, c->stream); break;
+        case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, c->stream); break;
+        case VELLO_HIP_STAGE_COARSE: launch_coarse(f, c->stream); break;
+        case VELLO_HIP_STAGE_PATH_TILING: launch_path_tiling(f, c->stream); break;
+        case VELLO_HIP_STAGE_FINE: launch_fine(f, c->stream); break;
+        default: return VELLO_HIP_E_INVALID;
+        }
+        HIP_TRY(c, hipGetLastError());
+        if (prof) {
+            HIP_TRY(c, hipEventRecord(ev.b, c->stream));
+            c->events.push_back(ev);
+        }
+    }
+    return 0;
+}
+
+int drain_events(vello_hip_ctx *c) {
+    for (auto &ev : c->events) {
+        float ms = 0.f;
+        HIP_TRY(c, hipEventSynchronize(ev.b));
+        HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+        c->stage_ms[ev.stage] += ms;
+        c->stage_count[ev.stage] += 1;
+        c->event_pool.push_back(ev.a);
+        c->event_pool.push_back(ev.b);
+    }
+    c->events.clear();
+    return 0;
+}
+
+// vello_encoding/src/mask.rs:11-98
+const uint8_t PATTERN8[8] = {0, 5, 3, 7, 1, 4, 6, 2};
+const uint8_t PATTERN16[16] = {1, 8, 4, 11, 15, 7, 3, 12, 0, 9, 5, 13, 2, 10, 6, 14};
+uint32_t one_mask_n(double slope, double translation, bool is_pos, const uint8_t *pat, int n) {
+    if (is_pos) translation = 1. - translation;
+    uint32_t result = 0;
+    double inv = 1.0 / (double)n;
+    for (int i = 0; i < n; i++) {
+        double y = ((double)i + 0.5) * inv;
+        double x = ((double)pat[i] + 0.5) * inv;
+        if (!is_pos) y = 1. - y;
+        if ((x - (1.0 - translation)) * (1. - slope) - (y - translation) * slope >= 0.) result |= 1u << i;
+    }
+    return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vello_hip_make_mask_lut(uint8_t out[1024]) {
+    const int W = 32, H = 32, HALF = 16;
+    for (int i = 0; i < W * H; i++) {
+        int u = i % W, v = i / W;
+        double y = ((double)(v % HALF) + 0.5) * (1.0 / (double)HALF);
+        double x = ((double)u + 0.5) * (1.0 / (double)W);
+        out[i] = (uint8_t)one_mask_n(y, x, v >= HALF, PATTERN8, 8);
+    }
+}
+
+void vello_hip_make_mask_lut_16(uint8_t out[8192]) {
+    const int W = 64, H = 64, HALF = 32;
+    for (int i = 0; i < W * H; i++) {
+        int u = i % W, v = i / W;
+        double y = ((double)(v % HALF) + 0.5) * (1.0 / (double)HALF);
+        double x = ((double)u + 0.5) * (1.0 / (double)W);
+        uint32_t m = one_mask_n(y, x, v >= HALF, PATTERN16, 16);
+        out[2 * i] = (uint8_t)(m & 0xff);
+        out[2 * i + 1] = (uint8_t)(m >> 8);
+    }
+}
+
+const char *vello_hip_stage_name(int stage) {
+    if (stage < 0 || stage >= VELLO_HIP_STAGE_COUNT) return "?";
+    return kStageNames[stage];
+}
+
+const char *vello_hip_last_error(vello_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *caps, vello_hip_ctx **out) {
+    if (!out) return VELLO_HIP_E_INVALID;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+        g_create_error = std::string("no usable HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count=0") +
+                         "); the engine has no CPU fallback";
+        return VELLO_HIP_E_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        g_create_error = "hipSetDevice failed";
+        return VELLO_HIP_E_NO_DEVICE;
+    }
+    vello_hip_ctx *c = new vello_hip_ctx();
+    c->device = device;
+    c->aa_mask = aa_mask ? (aa_mask & VELLO_HIP_AA_MASK_ALL) : VELLO_HIP_AA_MASK_ALL;
+    // reference pool sizes, vello_encoding/src/config.rs:398-408
+    vello_hip_capacities d{1u << 21, 1u << 18, 1u << 21, 1u << 21, 1u << 21, 1u << 20, 1u << 23};
+    if (caps) {
+        if (caps->lines) d.lines = caps->lines;
+        if (caps->bin_data) d.bin_data = caps->bin_data;
+        if (caps->tiles) d.tiles = caps->tiles;
+        if (caps->seg_counts) d.seg_counts = caps->seg_counts;
+        if (caps->segments) d.segments = caps->segments;
+        if (caps->blend_spill) d.blend_spill = caps->blend_spill;
+        if (caps->ptcl) d.ptcl = caps->ptcl;
+    }
+    // path_tiling writes segments[] unguarded by a failure bit only when both pools match (coarse.wgsl:166)
+    if (d.segments < d.seg_counts) d.segments = d.seg_counts;
+    c->caps = d;
+    auto fail = [&](const char *what) {
+        g_create_error = std::string(what) + ": " + c->last_error;
+        vello_hip_destroy(c);
+        return VELLO_HIP_E_HIP;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_CONFIG], sizeof(Config))) return fail("config");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup))) return fail("lines");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u)) return fail("bin_data");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile))) return fail("tiles");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_SEG_COUNTS], (size_t)d.seg_counts * sizeof(SegmentCount))) return fail("seg_counts");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_SEGMENTS], (size_t)d.segments * sizeof(Segment))) return fail("segments");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u)) return fail("blend_spill");
+    if (ensure(c, c->buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u)) return fail("ptcl");
+    if (ensure(c, c->mask8, 1024) || ensure(c, c->mask16, 8192)) return fail("mask lut");
+    {
+        std::vector<uint8_t> l8(1024), l16(8192);
+        vello_hip_make_mask_lut(l8.data());
+        vello_hip_make_mask_lut_16(l16.data());
+        if (hipMemcpy(c->mask8.ptr, l8.data(), 1024, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->mask16.ptr, l16.data(), 8192, hipMemcpyHostToDevice) != hipSuccess)
+            return fail("mask lut upload");
+    }
+    *out = c;
+    return VELLO_HIP_OK;
+}
+
+void vello_hip_destroy(vello_hip_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &ev : c->events) {
+        (void)hipEventDestroy(ev.a);
+        (void)hipEventDestroy(ev.b);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto &b : c->buf)
+        if (b.ptr && &b != &c->buf[VELLO_HIP_BUF_BUMP]) (void)hipFree(b.ptr);
+    for (DevBuf *b : {&c->zero_region, &c->clip_stack, &c->ramps, &c->mask8, &c->mask16})
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                           const uint32_t *ramps, uint32_t n_ramps) {
+    if (!c || !scene || !layout || (scene_len & 3u) || scene_len == 0) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const vello_hip_layout &L = *layout;
+    size_t words = scene_len / 4u;
+    if (L.path_tag_base > L.path_data_base || L.path_data_base > L.draw_tag_base || L.draw_tag_base > L.draw_data_base ||
+        L.draw_data_base > L.transform_base || L.transform_base > L.style_base || L.style_base > words ||
+        (size_t)L.draw_tag_base + L.n_draw_objects > words) {
+        c->last_error = "layout does not describe the scene buffer";
+        return VELLO_HIP_E_INVALID;
+    }
+    if ((((size_t)L.path_data_base - L.path_tag_base) * 4u) % 1024u != 0u) {
+        c->last_error = "path tag stream is not padded to 4*256 tags (resolve.rs:622-639)";
+        return VELLO_HIP_E_INVALID;
+    }
+    int r;
+    // 64 B of slack: flatten reads tag ix+1 and the (wrapped) style word of pre-style tags speculatively
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_SCENE], scene_len + 64))) return r;
+    c->layout = L;
+    c->scene_len = scene_len;
+    uint32_t n_path_tags = (L.path_data_base - L.path_tag_base) * 4u;
+    c->n_tag_words = align_up(n_path_tags, 1024u) / 4u;
+    c->n_pathtag_parts = (c->n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
+    if (c->n_pathtag_parts == 0) c->n_pathtag_parts = 1;
+    c->n_draw_parts = (L.n_draw_objects + DRAW_PART - 1u) / DRAW_PART;
+    c->zero_bytes = sizeof(Control) + ((size_t)c->n_pathtag_parts * 10u + (size_t)c->n_draw_parts * 8u) * 8u;
+    if ((r = ensure(c, c->zero_region, c->zero_bytes))) return r;
+    c->buf[VELLO_HIP_BUF_BUMP].ptr = c->zero_region.ptr;
+    c->buf[VELLO_HIP_BUF_BUMP].size = sizeof(Bump);
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(c->n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_PATH_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(PathBbox)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_DRAW_MONOIDS], (size_t)(L.n_draw_objects + 1u) * sizeof(DrawMonoid)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_CLIP_INP], (size_t)(L.n_clips + 1u) * sizeof(Clip)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_CLIP_BBOXES], (size_t)(L.n_clips + 1u) * sizeof(Bbox4)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
+    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
+    if ((r = ensure(c, c->clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
+    HIP_TRY(c, hipMemcpyAsync(c->buf[VELLO_HIP_BUF_SCENE].ptr, scene, scene_len, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync((char *)c->buf[VELLO_HIP_BUF_SCENE].ptr + scene_len, 0, 64, c->stream));
+    c->n_ramps = 0;
+    if (ramps && n_ramps) {
+        if ((r = ensure(c, c->ramps, (size_t)n_ramps * 512u * 4u))) return r;
+        HIP_TRY(c, hipMemcpyAsync(c->ramps.ptr, ramps, (size_t)n_ramps * 512u * 4u, hipMemcpyHostToDevice, c->stream));
+        c->n_ramps = n_ramps;
+    }
+    // the source buffers are caller-owned only for the duration of the call (recording.rs:124-129)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->scene_resident = true;
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_render_resident(vello_hip_ctx *c, const vello_hip_render_params *params, void *out_device, size_t out_stride) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Frame f;
+    int r = prepare_frame(c, params, out_device, out_stride, f, false);
+    if (r) return r;
+    return run_stage_range(c, f, 0, VELLO_HIP_STAGE_FINE);
+}
+
+int vello_hip_run_stages(vello_hip_ctx *c, const vello_hip_render_params *params, int first, int last) {
+    if (!c || first < 0 || last >= VELLO_HIP_STAGE_COUNT || first > last) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    Frame f;
+    int r = prepare_frame(c, params, nullptr, 0, f, true);
+    if (r) return r;
+    if ((r = run_stage_range(c, f, first, last))) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_get_bump(vello_hip_ctx *c, vello_hip_bump *out) {
+    if (!c || !out || !c->zero_region.ptr) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->zero_region.ptr, sizeof(vello_hip_bump), hipMemcpyDeviceToHost));
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_sync(vello_hip_ctx *c) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->zero_region.ptr && c->have_cfg) {
+        vello_hip_bump b;
+        HIP_TRY(c, hipMemcpy(&b, c->zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
+        if (b.failed != 0u) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,
+                          b.lines, b.binning, b.tile, b.seg_counts, b.segments, b.ptcl);
+            c->last_error = msg;
+            return VELLO_HIP_E_CAPACITY;
+        }
+    }
+    return VELLO_HIP_OK;
+}
+
+void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                     const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_rgba8, size_t out_stride,
+                     int out_is_device, vello_hip_bump *bump_out) {
+    if (!c || !params) return VELLO_HIP_E_INVALID;
+    int r = vello_hip_upload_scene(c, scene, scene_len, layout, ramps, n_ramps);
+    if (r) return r;
+    r = vello_hip_render_resident(c, params, out_is_device ? out_rgba8 : nullptr, out_stride);
+    if (r) return r;
+    int sync_r = vello_hip_sync(c);
+    if (bump_out) {
+        int br = vello_hip_get_bump(c, bump_out);
+        if (br) return br;
+    }
+    if (sync_r) return sync_r;
+    if (out_rgba8 && !out_is_device) {
+        size_t row = (size_t)params->width * 4u;
+        size_t stride = out_stride ? out_stride : row;
+        HIP_TRY(c, hipMemcpy2D(out_rgba8, stride, c->buf[VELLO_HIP_BUF_OUTPUT].ptr, row, row, params->height, hipMemcpyDeviceToHost));
+    }
+    return VELLO_HIP_OK;
+}
+
+size_t vello_hip_buffer_size(vello_hip_ctx *c, int id) {
+    if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT) return 0;
+    return c->buf[id].size;
+}
+
+int vello_hip_read_buffer(vello_hip_ctx *c, int id, void *dst, size_t offset, size_t size) {
+    if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT || !dst) return VELLO_HIP_E_INVALID;
+    if (!c->buf[id].ptr || offset + size > c->buf[id].size) {
+        c->last_error = "read_buffer out of range";
+        return VELLO_HIP_E_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(dst, (const char *)c->buf[id].ptr + offset, size, hipMemcpyDeviceToHost));
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_write_buffer(vello_hip_ctx *c, int id, const void *src, size_t offset, size_t size) {
+    if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT || !src) return VELLO_HIP_E_INVALID;
+    if (!c->buf[id].ptr || offset + size > c->buf[id].size) {
+        c->last_error = "write_buffer out of range";
+        return VELLO_HIP_E_INVALID;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy((char *)c->buf[id].ptr + offset, src, size, hipMemcpyHostToDevice));
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_set_profiling(vello_hip_ctx *c, uint32_t stage_mask) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    c->prof_mask = stage_mask;
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_get_stage_ms(vello_hip_ctx *c, float ms_out[VELLO_HIP_STAGE_COUNT], uint32_t count_out[VELLO_HIP_STAGE_COUNT]) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = drain_events(c);
+    if (r) return r;
+    for (int i = 0; i < VELLO_HIP_STAGE_COUNT; i++) {
+        if (ms_out) ms_out[i] = c->stage_ms[i];
+        if (count_out) count_out[i] = c->stage_count[i];
+        c->stage_ms[i] = 0.f;
+        c->stage_count[i] = 0;
+    }
+    return VELLO_HIP_OK;
+}
+
+}  // extern "C"

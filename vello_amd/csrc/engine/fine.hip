@@ -1,0 +1,697 @@
+// fine: per-tile rasterization + compositing -> RGBA8.
+// Reference: vello_shaders/shader/fine.wgsl (area AA :1005-1059, MSAA :146-709, command
+// interpreter :1064-1398), shared/blend.wgsl:147-319 (vello/src/render.rs:560-629).
+//
+// gfx950 design: the reference workgroup is 4x16 = 64 invocations, i.e. exactly one wave64, so one
+// wave owns one 16x16 tile and every cross-lane step of the reference becomes a wave operation:
+//  * the per-batch Hillis-Steele scan of pixel counts is a 6-step shuffle scan;
+//  * each batch of 64 segments is staged into LDS once with coalesced 24-B loads and all later
+//    passes (area loop / pixel walk) read it from LDS (the reference re-reads global memory per
+//    lane: fine.wgsl:1018, :226);
+//  * the winding accumulators (sh_samples etc.) are LDS atomics on the packed 8-bit counters of
+//    the reference, kept bit-identical so the MSAA coverage is integer-exact;
+//  * the half-plane mask LUT is a persistent device buffer (the reference re-uploads it every
+//    frame: render.rs:583-591), read through L1/L2;
+//  * each lane owns 4 horizontally adjacent pixels and stores them as one 16-byte write.
+#include "engine.h"
+
+namespace vk {
+
+namespace {
+
+constexpr uint32_t PIXELS_PER_THREAD = 4;
+constexpr int GRADIENT_WIDTH = 512;
+constexpr uint32_t LUMINANCE_MASK_LAYER = 0x10000u;
+
+struct vec4 {
+    float x, y, z, w;
+};
+__device__ __forceinline__ vec4 operator*(vec4 a, float s) { return vec4{a.x * s, a.y * s, a.z * s, a.w * s}; }
+__device__ __forceinline__ vec4 operator+(vec4 a, vec4 b) { return vec4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
+
+__device__ __forceinline__ vec4 unpack4x8unorm(uint32_t u) {
+    return vec4{(float)(u & 0xffu) / 255.0f, (float)((u >> 8) & 0xffu) / 255.0f, (float)((u >> 16) & 0xffu) / 255.0f,
+                (float)((u >> 24) & 0xffu) / 255.0f};
+}
+__device__ __forceinline__ uint32_t unorm8(float e) { return (uint32_t)floorf(0.5f + 255.0f * clampf(e, 0.0f, 1.0f)); }
+__device__ __forceinline__ uint32_t pack4x8unorm(vec4 c) {
+    return unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+}
+
+struct CmdFill {
+    uint32_t size_and_rule, seg_data;
+    int32_t backdrop;
+};
+
+struct FineShared {
+    Segment seg[64];
+    uint32_t count[64];
+    uint32_t winding_y[4];
+    uint32_t winding_y_prefix[4];
+    uint32_t winding[64];
+};
+
+// ---------------- area AA (fine.wgsl:1005-1059) ----------------
+__device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t lane, float (&area)[4]) {
+    const uint32_t n_segs = fill.size_and_rule >> 1;
+    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
+    const float xy_x = (float)((lane & 3u) * PIXELS_PER_THREAD);
+    const float xy_y = (float)(lane >> 2);
+    const float backdrop_f = (float)fill.backdrop;
+#pragma unroll
+    for (int k = 0; k < 4; k++) area[k] = backdrop_f;
+    for (uint32_t base = 0; base < n_segs; base += 64u) {
+        uint32_t slice = minu(n_segs - base, 64u);
+        __syncthreads();
+        if (lane < slice) sh.seg[lane] = segments[fill.seg_data + base + lane];
+        __syncthreads();
+        for (uint32_t i = 0; i < slice; i++) {
+            Segment sg = sh.seg[i];
+            float y = sg.p0y - xy_y;
+            float delta_x = sg.p1x - sg.p0x;
+            float delta_y = sg.p1y - sg.p0y;
+            float y0 = clampf(y, 0.0f, 1.0f);
+            float y1 = clampf(y + delta_y, 0.0f, 1.0f);
+            float dy = y0 - y1;
+            if (dy != 0.0f) {
+                float vec_y_recip = 1.0f / delta_y;
+                float t0 = (y0 - y) * vec_y_recip;
+                float t1 = (y1 - y) * vec_y_recip;
+                float startx = sg.p0x - xy_x;
+                float x0 = startx + t0 * delta_x;
+                float x1 = startx + t1 * delta_x;
+                float xmin0 = minf(x0, x1);
+                float xmax0 = maxf(x0, x1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float i_f = (float)k;
+                    float xmin = minf(xmin0 - i_f, 1.0f) - 1.0e-6f;
+                    float xmax = xmax0 - i_f;
+                    float b = minf(xmax, 1.0f);
+                    float c = maxf(b, 0.0f);
+                    float d = maxf(xmin, 0.0f);
+                    float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                    area[k] += a * dy;
+                }
+            }
+            float y_edge = signf(delta_x) * clampf(xy_y - sg.y_edge + 1.0f, 0.0f, 1.0f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) area[k] += y_edge;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float a = area[k];
+        if (even_odd) a = fabsf(a - 2.0f * roundf_te(0.5f * a));
+        else a = minf(fabsf(a), 1.0f);
+        area[k] = a;
+    }
+}
+
+// ---------------- MSAA (fine.wgsl:146-709) ----------------
+template <int AA>
+__device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
+                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4]) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
+    const uint32_t n_segs = fill.size_and_rule >> 1;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    __syncthreads();
+    if (!even_odd) {
+        if (lane < 4u) sh.winding_y[lane] = 0x80808080u;
+        sh.winding[lane] = 0x80808080u;
+#pragma unroll
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD * SWPP; i++) sh_samples[i * 64u + lane] = 0x80808080u;
+    } else {
+        if (lane == 0u) sh.winding_y[0] = 0u;
+        if (lane < 16u) sh.winding[lane] = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) sh_samples[i * 64u + lane] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n_batch = (n_segs + 63u) / 64u;
+    for (uint32_t batch = 0; batch < n_batch; batch++) {
+        const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
+        uint32_t count = 0u;
+        if (lane < slice_size) {
+            Segment sg = segments[fill.seg_data + batch * 64u + lane];
+            sh.seg[lane] = sg;
+            float y_edge_f = (float)TILE_HEIGHT;
+            uint32_t delta = (sg.p1x <= sg.p0x) ? 1u : 0xffffffffu;
+            if (sg.p0x == 0.0f) y_edge_f = sg.p0y;
+            else if (sg.p1x == 0.0f) y_edge_f = sg.p1y;
+            if (!(sg.p0y == sg.p1y && sg.p0y == floorf(sg.p0y))) count = span(sg.p0x, sg.p1x) + span(sg.p0y, sg.p1y) - 1u;
+            uint32_t y_edge = f2u(ceilf(y_edge_f));
+            if (y_edge < TILE_HEIGHT) {
+                if (!even_odd) atomicAdd(&sh.winding_y[y_edge >> 2], delta << ((y_edge & 3u) << 3));
+                else atomicXor(&sh.winding_y[0], 1u << y_edge);
+            }
+        }
+        uint32_t incl = wave_incl_scan_u32(count, (int)lane);
+        sh.count[lane] = incl;
+        uint32_t total = __shfl(incl, 63);
+        __syncthreads();
+        for (uint32_t i = lane; i < total; i += 64u) {
+            uint32_t lo = 0u, hi = slice_size;
+            while (hi > lo + 1u) {
+                uint32_t mid = (lo + hi) >> 1;
+                if (i >= sh.count[mid - 1u]) lo = mid; else hi = mid;
+            }
+            const uint32_t el_ix = lo;
+            const bool last_pixel = i + 1u == sh.count[el_ix];
+            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+            Segment sg = sh.seg[el_ix];
+            // line setup, fine.wgsl:236-261
+            const bool is_down = sg.p1y >= sg.p0y;
+            const vec2 xy0 = is_down ? v2(sg.p0x, sg.p0y) : v2(sg.p1x, sg.p1y);
+            const vec2 xy1 = is_down ? v2(sg.p1x, sg.p1y) : v2(sg.p0x, sg.p0y);
+            const float dx = fabsf(xy1.x - xy0.x);
+            const float dy = xy1.y - xy0.y;
+            const float idxdy = 1.0f / (dx + dy);
+            float a = dx * idxdy;
+            const bool is_positive_slope = xy1.x >= xy0.x;
+            const float x_sign = is_positive_slope ? 1.0f : -1.0f;
+            const float xt0 = floorf(xy0.x * x_sign);
+            const float c = xy0.x * x_sign - xt0;
+            const float y0i = floorf(xy0.y);
+            const float ytop = y0i + 1.0f;
+            const float b = minf((dy * c + dx * (ytop - xy0.y)) * idxdy, ONE_MINUS_ULP);
+            const uint32_t count_x = span(xy0.x, xy1.x) - 1u;
+            const uint32_t cnt = count_x + span(xy0.y, xy1.y);
+            const float robust_err = floorf(a * ((float)cnt - 1.0f) + b) - (float)count_x;
+            if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
+            const int32_t x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+            const float zf = a * (float)sub_ix + b;
+            const float z = floorf(zf);
+            const int32_t x = x0i + f2i(x_sign * z);
+            const int32_t y = f2i(y0i) + (int32_t)sub_ix - f2i(z);
+            bool is_delta, is_bump;
+            const float zp = floorf(a * (float)(sub_ix - 1u) + b);
+            if (sub_ix == 0u) {
+                is_delta = y0i == xy0.y;
+                is_bump = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
+            } else {
+                is_delta = z == zp;
+                is_bump = is_positive_slope && !is_delta;
+            }
+            const uint32_t pix_ix = (uint32_t)y * TILE_WIDTH + (uint32_t)x;
+            if ((uint32_t)x < TILE_WIDTH - 1u && (uint32_t)y < TILE_HEIGHT && is_delta) {
+                if (!even_odd) {
+                    uint32_t delta_pix = pix_ix + 1u;
+                    uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
+                    atomicAdd(&sh.winding[delta_pix >> 2], d);
+                } else {
+                    atomicXor(&sh.winding[y], 2u << (uint32_t)x);
+                }
+            }
+            const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
+            const float half_height = (float)(MASK_HEIGHT / 2u);
+            const float mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
+            const float mask_col = floorf((zf - z) * (float)MASK_WIDTH);
+            const uint32_t mask_ix = mask_block + f2u(mask_row + mask_col);
+            uint32_t mask;
+            if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
+            else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
+            if (sub_ix == 0u && !is_bump) {
+                uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy0.y - (float)y)));
+                mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
+            }
+            if (last_pixel && xy1.x != 0.0f) {
+                uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy1.y - (float)y)));
+                mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
+            }
+            if (pix_ix >= 256u) continue;  // memory safety only; tile-clipped segments never get here
+            // sample words are stored transposed ([word][pixel-of-lane group]) so that the 4 words of
+            // a pixel land in different banks: index = word * 64 + (pix >> 2) ... see sample_index()
+            if (even_odd) {
+                if (is_bump) mask ^= FULL;
+                atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
+                continue;
+            }
+            const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
+            constexpr uint32_t NH = MSAA16 ? 2u : 1u;
+#pragma unroll
+            for (uint32_t h = 0; h < NH; h++) {
+                uint32_t m8 = (mask >> (8u * h)) & 0xffu;
+                uint32_t m_a = m8 ^ (m8 << 7);
+                uint32_t m_b = m_a ^ (m_a << 14);
+                uint32_t e0 = m_b & 0x1010101u;
+                uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
+                uint32_t e1 = (m_b >> 4) & 0x1010101u;
+                uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
+                if (is_bump) {
+                    s0 += bump_delta;
+                    s1 += bump_delta;
+                }
+                // logical word w of pixel p lives at ((p & 3) * SWPP + w) * 64 + (p >> 2)
+                atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
+                atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
+            }
+        }
+        __syncthreads();
+    }
+    // resolve
+    if (even_odd) {
+        uint32_t scan_x = sh.winding[ly];
+        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
+        uint32_t scan_y = sh.winding_y[0];
+        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
+        uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)fill.backdrop;
+#pragma unroll
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
+            uint32_t pix_ix = lane * PIXELS_PER_THREAD + i;
+            uint32_t samples = sh_samples[i * 64u + lane];
+            uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % TILE_WIDTH));
+            uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
+            area[i] = (float)__popc((samples ^ pix_mask) & FULL) * (MSAA16 ? 0.0625f : 0.125f);
+        }
+        return;
+    }
+    uint32_t packed_w = sh.winding[lane];
+    packed_w += (packed_w - 0x808080u) << 8;
+    packed_w += (packed_w - 0x8080u) << 16;
+    uint32_t packed_y = sh.winding_y[ly >> 2];
+    packed_y += (packed_y - 0x808080u) << 8;
+    packed_y += (packed_y - 0x8080u) << 16;
+    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
+    if ((ly & 3u) == 3u && lx == 0u) sh.winding_y_prefix[ly >> 2] = wind_y;
+    const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
+    sh.winding[lane] = prefix_x;
+    __syncthreads();
+    for (uint32_t i = (lane & ~3u); i < lane; i++) packed_w += sh.winding[i];
+    for (uint32_t i = 0; i < (ly >> 2); i++) wind_y += sh.winding_y_prefix[i];
+#pragma unroll
+    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
+        uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)fill.backdrop;
+        if (expected_zero >= 256u) {
+            area[i] = 1.0f;
+        } else if (!MSAA16) {
+            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
+            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
+            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+            uint32_t xored0_2 = xored0 | (xored0 * 2u);
+            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+            uint32_t xored1_2 = xored1 | (xored1 >> 1);
+            uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            uint32_t xored4 = xored2 | (xored2 * 4u);
+            uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__popc(xored8 & 0xC0C0C0C0u) * 0.125f;
+        } else {
+            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
+            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
+            uint32_t samples2 = sh_samples[(i * SWPP + 2u) * 64u + lane];
+            uint32_t samples3 = sh_samples[(i * SWPP + 3u) * 64u + lane];
+            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+            uint32_t xored0_2 = xored0 | (xored0 * 2u);
+            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+            uint32_t xored1_2 = xored1 | (xored1 >> 1);
+            uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            uint32_t xored01_4 = xored01 | (xored01 * 4u);
+            uint32_t xored2 = (expected_zero * 0x1010101u) ^ samples2;
+            uint32_t xored2_2 = xored2 | (xored2 * 2u);
+            uint32_t xored3 = (expected_zero * 0x1010101u) ^ samples3;
+            uint32_t xored3_2 = xored3 | (xored3 >> 1);
+            uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
+            uint32_t xored23_4 = xored23 | (xored23 >> 2);
+            uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
+            uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
+        }
+    }
+}
+
+// ---------------- blend (shared/blend.wgsl) ----------------
+struct vec3 {
+    float x, y, z;
+};
+__device__ __forceinline__ vec3 v3(float x, float y, float z) { return vec3{x, y, z}; }
+__device__ __forceinline__ float min3(vec3 c) { return minf(c.x, minf(c.y, c.z)); }
+__device__ __forceinline__ float max3(vec3 c) { return maxf(c.x, maxf(c.y, c.z)); }
+__device__ __forceinline__ float lum(vec3 c) { return c.x * 0.3f + c.y * 0.59f + c.z * 0.11f; }
+__device__ __forceinline__ float svg_lum(vec3 c) { return c.x * 0.2125f + c.y * 0.7154f + c.z * 0.0721f; }
+__device__ __forceinline__ float sat(vec3 c) { return max3(c) - min3(c); }
+__device__ __forceinline__ float screen1(float cb, float cs) { return cb + cs - (cb * cs); }
+__device__ float color_dodge(float cb, float cs) {
+    if (cb == 0.0f) return 0.0f;
+    else if (cs == 1.0f) return 1.0f;
+    else return minf(1.0f, cb / (1.0f - cs));
+}
+__device__ float color_burn(float cb, float cs) {
+    if (cb == 1.0f) return 1.0f;
+    else if (cs == 0.0f) return 0.0f;
+    else return 1.0f - minf(1.0f, (1.0f - cb) / cs);
+}
+__device__ __forceinline__ float hard_light1(float cb, float cs) { return cs <= 0.5f ? cb * 2.0f * cs : screen1(cb, 2.0f * cs - 1.0f); }
+__device__ __forceinline__ float soft_light1(float cb, float cs) {
+    float d = cb <= 0.25f ? ((16.0f * cb - 12.0f) * cb + 4.0f) * cb : sqrtf(cb);
+    return cs <= 0.5f ? cb - (1.0f - 2.0f * cs) * cb * (1.0f - cb) : cb + (2.0f * cs - 1.0f) * (d - cb);
+}
+__device__ vec3 clip_color(vec3 c) {
+    float l = lum(c);
+    float n = min3(c);
+    float x = max3(c);
+    if (n < 0.0f) c = v3(l + (((c.x - l) * l) / (l - n)), l + (((c.y - l) * l) / (l - n)), l + (((c.z - l) * l) / (l - n)));
+    if (x > 1.0f)
+        c = v3(l + (((c.x - l) * (1.0f - l)) / (x - l)), l + (((c.y - l) * (1.0f - l)) / (x - l)), l + (((c.z - l) * (1.0f - l)) / (x - l)));
+    return c;
+}
+__device__ vec3 set_lum(vec3 c, float l) {
+    float d = l - lum(c);
+    return clip_color(v3(c.x + d, c.y + d, c.z + d));
+}
+__device__ __forceinline__ void set_sat_inner(float &cmin, float &cmid, float &cmax, float s) {
+    if (cmax > cmin) {
+        cmid = ((cmid - cmin) * s) / (cmax - cmin);
+        cmax = s;
+    } else {
+        cmid = 0.0f;
+        cmax = 0.0f;
+    }
+    cmin = 0.0f;
+}
+__device__ vec3 set_sat(vec3 c, float s) {
+    float r = c.x, g = c.y, b = c.z;
+    if (r <= g) {
+        if (g <= b) set_sat_inner(r, g, b, s);
+        else if (r <= b) set_sat_inner(r, b, g, s);
+        else set_sat_inner(b, r, g, s);
+    } else {
+        if (r <= b) set_sat_inner(g, r, b, s);
+        else if (g <= b) set_sat_inner(g, b, r, s);
+        else set_sat_inner(b, g, r, s);
+    }
+    return v3(r, g, b);
+}
+__device__ vec3 blend_mix(vec3 cb, vec3 cs, uint32_t mode) {
+    switch (mode) {
+    case 1: return v3(cb.x * cs.x, cb.y * cs.y, cb.z * cs.z);
+    case 2: return v3(screen1(cb.x, cs.x), screen1(cb.y, cs.y), screen1(cb.z, cs.z));
+    case 3: return v3(hard_light1(cs.x, cb.x), hard_light1(cs.y, cb.y), hard_light1(cs.z, cb.z));
+    case 4: return v3(minf(cb.x, cs.x), minf(cb.y, cs.y), minf(cb.z, cs.z));
+    case 5: return v3(maxf(cb.x, cs.x), maxf(cb.y, cs.y), maxf(cb.z, cs.z));
+    case 6: return v3(color_dodge(cb.x, cs.x), color_dodge(cb.y, cs.y), color_dodge(cb.z, cs.z));
+    case 7: return v3(color_burn(cb.x, cs.x), color_burn(cb.y, cs.y), color_burn(cb.z, cs.z));
+    case 8: return v3(hard_light1(cb.x, cs.x), hard_light1(cb.y, cs.y), hard_light1(cb.z, cs.z));
+    case 9: return v3(soft_light1(cb.x, cs.x), soft_light1(cb.y, cs.y), soft_light1(cb.z, cs.z));
+    case 10: return v3(fabsf(cb.x - cs.x), fabsf(cb.y - cs.y), fabsf(cb.z - cs.z));
+    case 11: return v3(cb.x + cs.x - 2.0f * cb.x * cs.x, cb.y + cs.y - 2.0f * cb.y * cs.y, cb.z + cs.z - 2.0f * cb.z * cs.z);
+    case 12: return set_lum(set_sat(cs, sat(cb)), lum(cb));
+    case 13: return set_lum(set_sat(cb, sat(cs)), lum(cb));
+    case 14: return set_lum(cs, lum(cb));
+    case 15: return set_lum(cb, lum(cs));
+    default: return cs;
+    }
+}
+__device__ vec4 blend_compose(vec3 cb, vec3 cs, float ab, float as_, uint32_t mode) {
+    float fa = 0.0f, fb = 0.0f;
+    switch (mode) {
+    case 1: fa = 1.0f; fb = 0.0f; break;
+    case 2: fa = 0.0f; fb = 1.0f; break;
+    case 3: fa = 1.0f; fb = 1.0f - as_; break;
+    case 4: fa = 1.0f - ab; fb = 1.0f; break;
+    case 5: fa = ab; fb = 0.0f; break;
+    case 6: fa = 0.0f; fb = as_; break;
+    case 7: fa = 1.0f - ab; fb = 0.0f; break;
+    case 8: fa = 0.0f; fb = 1.0f - as_; break;
+    case 9: fa = ab; fb = 1.0f - as_; break;
+    case 10: fa = 1.0f - ab; fb = as_; break;
+    case 11: fa = 1.0f - ab; fb = 1.0f - as_; break;
+    case 12: fa = 1.0f; fb = 1.0f; break;
+    case 13:
+        return vec4{minf(1.0f, as_ * cs.x + ab * cb.x), minf(1.0f, as_ * cs.y + ab * cb.y), minf(1.0f, as_ * cs.z + ab * cb.z),
+                    minf(1.0f, as_ + ab)};
+    default: break;
+    }
+    float as_fa = as_ * fa, ab_fb = ab * fb;
+    return vec4{as_fa * cs.x + ab_fb * cb.x, as_fa * cs.y + ab_fb * cb.y, as_fa * cs.z + ab_fb * cb.z, minf(as_fa + ab_fb, 1.0f)};
+}
+__device__ __forceinline__ vec3 unpremultiply(vec4 c) {
+    float inv_alpha = 1.0f / maxf(c.w, 1e-15f);
+    return v3(c.x * inv_alpha, c.y * inv_alpha, c.z * inv_alpha);
+}
+__device__ __forceinline__ float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+__device__ vec4 blend_mix_compose(vec4 backdrop, vec4 src, uint32_t mode) {
+    const uint32_t BLEND_DEFAULT = (0u << 8) | 3u;
+    if ((mode & 0x7fffu) == BLEND_DEFAULT) return backdrop * (1.0f - src.w) + src;
+    vec3 cs = unpremultiply(src);
+    vec3 cb = unpremultiply(backdrop);
+    uint32_t mix_mode = mode >> 8;
+    vec3 mixed = blend_mix(cb, cs, mix_mode);
+    cs = v3(mixf(cs.x, mixed.x, backdrop.w), mixf(cs.y, mixed.y, backdrop.w), mixf(cs.z, mixed.z, backdrop.w));
+    uint32_t compose_mode = mode & 0xffu;
+    if (compose_mode == 3u) {
+        return vec4{mixf(backdrop.x, cs.x, src.w), mixf(backdrop.y, cs.y, src.w), mixf(backdrop.z, cs.z, src.w),
+                    src.w + backdrop.w * (1.0f - src.w)};
+    }
+    return blend_compose(cb, cs, backdrop.w, src.w, compose_mode);
+}
+
+__device__ __forceinline__ float extend_mode_normalized(float t, uint32_t mode) {  // fine.wgsl:863-875
+    switch (mode) {
+    case 0: return clampf(t, 0.0f, 1.0f);
+    case 1: return t - floorf(t);
+    default: return fabsf(t - 2.0f * roundf_te(0.5f * t));
+    }
+}
+__device__ __forceinline__ vec4 ramp_load(const uint32_t *__restrict__ ramps, uint32_t n_ramps, int32_t x, uint32_t index) {
+    if (!ramps || index >= n_ramps || x < 0 || x >= GRADIENT_WIDTH) return vec4{0.0f, 0.0f, 0.0f, 0.0f};
+    return unpack4x8unorm(ramps[index * GRADIENT_WIDTH + (uint32_t)x]);
+}
+__device__ __forceinline__ void src_over(vec4 &rgba, vec4 fg, float area) {
+    vec4 fg_i = fg * area;
+    rgba = rgba * (1.0f - fg_i.w) + fg_i;
+}
+
+}  // namespace
+
+template <int AA>
+__global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+                                             const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
+                                             uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
+                                             const uint32_t *__restrict__ mask_lut) {
+    __shared__ FineShared sh;
+    __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
+    if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
+    const uint32_t lane = threadIdx.x;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
+    const uint32_t tile_ix = tile_y * cfg.width_in_tiles + tile_x;
+    const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
+    const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
+    vec4 rgba[4];
+    const vec4 base_color = unpack4x8unorm(cfg.base_color);
+#pragma unroll
+    for (int i = 0; i < 4; i++) rgba[i] = base_color;
+    uint32_t blend_stack[BLEND_STACK_SPLIT][4];
+    uint32_t clip_depth = 0u;
+    float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
+    const uint32_t blend_offset = ptcl[cmd_ix];
+    cmd_ix += 1u;
+    for (;;) {
+        const uint32_t tag = ptcl[cmd_ix];
+        if (tag == CMD_END) break;
+        if (tag == CMD_FILL) {
+            CmdFill fill;
+            fill.size_and_rule = ptcl[cmd_ix + 1u];
+            fill.seg_data = ptcl[cmd_ix + 2u];
+            fill.backdrop = (int32_t)ptcl[cmd_ix + 3u];
+            if constexpr (AA == 0) fill_path_area(sh, segments, fill, lane, area);
+            else fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area);
+            cmd_ix += 4u;
+        } else if (tag == CMD_SOLID) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) area[i] = 1.0f;
+            cmd_ix += 1u;
+        } else if (tag == CMD_COLOR) {
+            const vec4 fg = unpack4x8unorm(ptcl[cmd_ix + 1u]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+            cmd_ix += 2u;
+        } else if (tag == CMD_BEGIN_CLIP) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t packed = pack4x8unorm(rgba[i]);
+                if (clip_depth < BLEND_STACK_SPLIT) {
+#pragma unroll
+                    for (uint32_t d = 0; d < BLEND_STACK_SPLIT; d++)
+                        if (clip_depth == d) blend_stack[d][i] = packed;
+                } else {
+                    uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
+                    if (ix < cfg.blend_size) blend_spill[ix] = packed;
+                }
+                rgba[i] = vec4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            clip_depth += 1u;
+            cmd_ix += 1u;
+        } else if (tag == CMD_END_CLIP) {
+            const uint32_t blend = ptcl[cmd_ix + 1u];
+            const float alpha = __uint_as_float(ptcl[cmd_ix + 2u]);
+            clip_depth -= 1u;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t bg_rgba = 0u;
+                if (clip_depth < BLEND_STACK_SPLIT) {
+#pragma unroll
+                    for (uint32_t d = 0; d < BLEND_STACK_SPLIT; d++)
+                        if (clip_depth == d) bg_rgba = blend_stack[d][i];
+                } else {
+                    uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
+                    bg_rgba = ix < cfg.blend_size ? blend_spill[ix] : 0u;
+                }
+                const vec4 bg = unpack4x8unorm(bg_rgba);
+                const vec4 fg = (rgba[i] * area[i]) * alpha;
+                if (blend == LUMINANCE_MASK_LAYER) {
+                    if (area[i] == 0.0f) {
+                        rgba[i] = bg;
+                    } else {
+                        float luminance = clampf(svg_lum(unpremultiply(fg)) * fg.w, 0.0f, 1.0f);
+                        rgba[i] = bg * luminance;
+                    }
+                } else {
+                    rgba[i] = blend_mix_compose(bg, fg, blend);
+                }
+            }
+            cmd_ix += 3u;
+        } else if (tag == CMD_JUMP) {
+            cmd_ix = ptcl[cmd_ix + 1u];
+        } else if (tag == CMD_LIN_GRAD) {
+            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+            const uint32_t io = ptcl[cmd_ix + 2u];
+            const float line_x = __uint_as_float(info[io]), line_y = __uint_as_float(info[io + 1u]), line_c = __uint_as_float(info[io + 2u]);
+            const float d = line_x * xy_x + line_y * xy_y + line_c;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float my_d = d + line_x * (float)i;
+                int32_t x = f2i(roundf_te(extend_mode_normalized(my_d, extend) * (float)(GRADIENT_WIDTH - 1)));
+                src_over(rgba[i], ramp_load(ramps, n_ramps, x, index), area[i]);
+            }
+            cmd_ix += 3u;
+        } else if (tag == CMD_RAD_GRAD) {
+            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+            const uint32_t io = ptcl[cmd_ix + 2u];
+            const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                        m3 = __uint_as_float(info[io + 3u]);
+            const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+            const float focal_x = __uint_as_float(info[io + 6u]), radius = __uint_as_float(info[io + 7u]);
+            const uint32_t flags_kind = info[io + 8u];
+            const uint32_t flags = flags_kind >> 3, kind = flags_kind & 7u;
+            const bool is_strip = kind == RAD_GRAD_KIND_STRIP, is_circular = kind == RAD_GRAD_KIND_CIRCULAR;
+            const bool is_focal_on_circle = kind == RAD_GRAD_KIND_FOCAL_ON_CIRCLE;
+            const bool is_swapped = (flags & RAD_GRAD_SWAPPED) != 0u;
+            const float r1_recip = is_circular ? 0.0f : 1.0f / radius;
+            const float less_scale = (is_swapped || (1.0f - focal_x) < 0.0f) ? -1.0f : 1.0f;
+            const float t_sign = signf(1.0f - focal_x);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float mx = xy_x + (float)i, my = xy_y;
+                float x = m0 * mx + m2 * my + xl0;
+                float y = m1 * mx + m3 * my + xl1;
+                float xx = x * x, yy = y * y;
+                float t = 0.0f;
+                bool is_valid = true;
+                if (is_strip) {
+                    float a = radius - yy;
+                    t = sqrtf(a) + x;
+                    is_valid = a >= 0.0f;
+                } else if (is_focal_on_circle) {
+                    t = (xx + yy) / x;
+                    is_valid = t >= 0.0f && x != 0.0f;
+                } else if (radius > 1.0f) {
+                    t = sqrtf(xx + yy) - x * r1_recip;
+                } else {
+                    float a = xx - yy;
+                    t = less_scale * sqrtf(a) - x * r1_recip;
+                    is_valid = a >= 0.0f && t >= 0.0f;
+                }
+                if (is_valid) {
+                    t = extend_mode_normalized(focal_x + t_sign * t, extend);
+                    if (is_swapped) t = 1.0f - t;
+                    int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
+                    src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
+                }
+            }
+            cmd_ix += 3u;
+        } else if (tag == CMD_SWEEP_GRAD) {
+            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+            const uint32_t io = ptcl[cmd_ix + 2u];
+            const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                        m3 = __uint_as_float(info[io + 3u]);
+            const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+            const float t0 = __uint_as_float(info[io + 6u]), t1 = __uint_as_float(info[io + 7u]);
+            const float scale = 1.0f / (t1 - t0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float mx = xy_x + (float)i, my = xy_y;
+                float x = m0 * mx + m2 * my + xl0;
+                float y = m1 * mx + m3 * my + xl1;
+                float xabs = fabsf(x), yabs = fabsf(y);
+                float slope = minf(xabs, yabs) / maxf(xabs, yabs);
+                float s = slope * slope;
+                float phi = slope * (0.15912117063999176025390625f +
+                                     s * (-5.185396969318389892578125e-2f +
+                                          s * (2.476101927459239959716796875e-2f + s * (-7.0547382347285747528076171875e-3f))));
+                if (xabs < yabs) phi = 1.0f / 4.0f - phi;
+                if (x < 0.0f) phi = 1.0f / 2.0f - phi;
+                if (y < 0.0f) phi = 1.0f - phi;
+                if (phi != phi) phi = 0.0f;
+                phi = (phi - t0) * scale;
+                float t = extend_mode_normalized(phi, extend);
+                int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
+                src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
+            }
+            cmd_ix += 3u;
+        } else if (tag == CMD_IMAGE) {
+            cmd_ix += 2u;  // images: SURVEY.md 8f f3 (next)
+        } else if (tag == CMD_BLUR_RECT) {
+            cmd_ix += 3u;  // blurred rounded rect: SURVEY.md 8f f3 (next)
+        } else {
+            cmd_ix += 1u;
+        }
+    }
+    // fine.wgsl:1386-1397: un-premultiplied RGBA8
+    const uint32_t px0 = tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD;
+    const uint32_t py = tile_y * TILE_HEIGHT + ly;
+    if (py < cfg.target_height && px0 < cfg.target_width) {
+        uint32_t packed[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            vec4 fg = rgba[i];
+            float a_inv = 1.0f / maxf(fg.w, 1e-6f);
+            packed[i] = pack4x8unorm(vec4{fg.x * a_inv, fg.y * a_inv, fg.z * a_inv, fg.w});
+        }
+        uint8_t *row = output + (size_t)py * out_stride + (size_t)px0 * 4u;
+        if (px0 + 4u <= cfg.target_width && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0u)) {
+            *reinterpret_cast<uint4 *>(row) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++)
+                if (px0 + i < cfg.target_width) reinterpret_cast<uint32_t *>(row)[i] = packed[i];
+        }
+    }
+}
+
+void launch_fine(const Frame &f, hipStream_t s) {
+    dim3 grid(f.cfg.width_in_tiles, f.cfg.height_in_tiles);
+    if (grid.x * grid.y == 0) return;
+    const Segment *seg = f.segments;
+    uint32_t stride = (uint32_t)f.out_stride;
+    if (f.aa == 0)
+        hipLaunchKernelGGL(k_fine<0>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
+                           f.n_ramps, f.mask_lut8);
+    else if (f.aa == 1)
+        hipLaunchKernelGGL(k_fine<1>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
+                           f.n_ramps, f.mask_lut8);
+    else
+        hipLaunchKernelGGL(k_fine<2>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
+                           f.n_ramps, f.mask_lut16);
+}
+
+}  // namespace vk

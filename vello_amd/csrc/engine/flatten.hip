@@ -1,0 +1,717 @@
+// flatten: path segments -> LineSoup (+ per-path integer bboxes).
+// Reference: vello_shaders/shader/flatten.wgsl:328-923 (Euler-spiral flattening of fills, GPU
+// stroker with joins/caps); CPU twin vello_shaders/src/cpu/{flatten,euler}.rs.
+//
+// gfx950 design.  The reference bumps `bump.lines` with one global atomic per emitted line; on
+// MI355X same-address device-scope atomics retire at ~12 ns each (MI355X_MICROARCH.md "dequeue"
+// row), i.e. ~18 ms for a paris-class frame.  Here each workgroup (256 threads x 4 tags) runs the
+// flattener twice over its 1024 tags: a COUNT pass (no stores, no position math), a wave64 shuffle
+// scan of the per-thread counts, ONE atomicAdd for the whole workgroup, then the EMIT pass writes
+// every thread's lines into its own contiguous slice.  Line order is therefore deterministic
+// inside a workgroup; across workgroups it follows atomic order exactly as in the reference
+// (the line soup is an unordered set, flatten.wgsl:775-798).
+#include "engine.h"
+
+namespace vk {
+
+namespace {
+
+constexpr float DERIV_THRESH = 1e-6f;
+constexpr float DERIV_THRESH_SQUARED = DERIV_THRESH * DERIV_THRESH;
+constexpr float DERIV_EPS = 1e-6f;
+constexpr float SUBDIV_LIMIT = 1.0f / 65536.0f;
+constexpr float K1_THRESH = 1e-3f;
+constexpr float DIST_THRESH = 1e-3f;
+constexpr float TANGENT_THRESH = 1e-6f;
+
+struct CubicParams { float th0, th1, chord_len, err; };
+struct EulerParams { float th0, k0, k1, ch; };
+struct CubicPoints { vec2 p0, p1, p2, p3; };
+struct PointDeriv { vec2 point, deriv; };
+
+// flatten.wgsl:668-672
+__device__ __forceinline__ vec2 xf_apply(const Xform &t, vec2 p) {
+    float px = fmaf(t.m0, p.x, fmaf(t.m2, p.y, t.t0));
+    float py = fmaf(t.m1, p.x, fmaf(t.m3, p.y, t.t1));
+    return v2(px, py);
+}
+
+template <bool EMIT>
+struct Emitter {
+    uint32_t next;      // next line index of this thread's slice (EMIT) / running count (COUNT)
+    float bx0, by0, bx1, by1;
+    LineSoup *lines;
+    uint32_t lines_size;
+
+    __device__ __forceinline__ uint32_t alloc(uint32_t n) {
+        uint32_t r = next;
+        next += n;
+        return r;
+    }
+    // flatten.wgsl:766-773
+    __device__ __forceinline__ void write(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1) {
+        if constexpr (EMIT) {
+            bx0 = minf(bx0, minf(p0.x, p1.x));
+            by0 = minf(by0, minf(p0.y, p1.y));
+            bx1 = maxf(bx1, maxf(p0.x, p1.x));
+            by1 = maxf(by1, maxf(p0.y, p1.y));
+            if (ix < lines_size) {
+                LineSoup l;
+                l.path_ix = path_ix; l.pad = 0u;
+                l.p0x = p0.x; l.p0y = p0.y; l.p1x = p1.x; l.p1y = p1.y;
+                lines[ix] = l;
+            }
+        }
+    }
+    __device__ __forceinline__ void write_xf(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1, const Xform &t) {
+        if constexpr (EMIT) write(ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
+    }
+};
+
+// flatten.wgsl:94-133
+__device__ CubicParams cubic_from_points_derivs(vec2 p0, vec2 p1, vec2 q0, vec2 q1, float dt) {
+    CubicParams r;
+    vec2 chord = p1 - p0;
+    float chord_squared = dot(chord, chord);
+    float chord_len = sqrtf(chord_squared);
+    if (chord_squared < DERIV_THRESH_SQUARED) {
+        float chord_err = sqrtf((9.0f / 32.0f) * (dot(q0, q0) + dot(q1, q1))) * dt;
+        r.th0 = 0.0f; r.th1 = 0.0f; r.chord_len = DERIV_THRESH; r.err = chord_err;
+        return r;
+    }
+    float scale = dt / chord_squared;
+    vec2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
+    float th0 = atan2_cr(h0.y, h0.x);
+    float d0 = length(h0) * scale;
+    vec2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
+    float th1 = atan2_cr(h1.y, h1.x);
+    float d1 = length(h1) * scale;
+    float cth0 = cos_cr(th0);
+    float cth1 = cos_cr(th1);
+    float err = 2.0f;
+    if (cth0 * cth1 >= 0.0f) {
+        float e0 = (2.0f / 3.0f) / maxf(1.0f + cth0, 1e-9f);
+        float e1 = (2.0f / 3.0f) / maxf(1.0f + cth1, 1e-9f);
+        float s0 = sin_cr(th0);
+        float s1 = sin_cr(th1);
+        float s01 = cth0 * s1 + cth1 * s0;
+        float amin = 0.15f * (2.0f * e0 * s0 + 2.0f * e1 * s1 - e0 * e1 * s01);
+        float a = 0.15f * (2.0f * d0 * s0 + 2.0f * d1 * s1 - d0 * d1 * s01);
+        float aerr = fabsf(a - amin);
+        float symm = fabsf(th0 + th1);
+        float asymm = fabsf(th0 - th1);
+        float dist = length(v2(d0 - e0, d1 - e1));
+        float symm2 = symm * symm;
+        float ctr = (4.625e-6f * symm * symm2 + 7.5e-3f * asymm) * symm2;
+        float halo = (5e-3f * symm + 7e-2f * asymm) * dist;
+        err = ctr + 1.55f * aerr + halo;
+    }
+    err *= chord_len;
+    r.th0 = th0; r.th1 = th1; r.chord_len = chord_len; r.err = err;
+    return r;
+}
+
+// flatten.wgsl:135-158
+__device__ EulerParams es_params_from_angles(float th0, float th1) {
+    EulerParams r;
+    float k0 = th0 + th1;
+    float dth = th1 - th0;
+    float d2 = dth * dth;
+    float k2 = k0 * k0;
+    float a = 6.0f;
+    a -= d2 * (1.0f / 70.0f);
+    a -= (d2 * d2) * (1.0f / 10780.0f);
+    a += (d2 * d2 * d2) * 2.769178184818219e-07f;
+    float b = -0.1f + d2 * (1.0f / 4200.0f) + d2 * d2 * 1.6959677820260655e-05f;
+    float cc = -1.0f / 1400.0f + d2 * 6.84915970574303e-05f - k2 * 7.936475029053326e-06f;
+    a += (b + cc * k2) * k2;
+    float k1 = dth * a;
+    float ch = 1.0f;
+    ch -= d2 * (1.0f / 40.0f);
+    ch += (d2 * d2) * 0.00034226190482569864f;
+    ch -= (d2 * d2 * d2) * 1.9349474568904524e-06f;
+    float b_ = -1.0f / 24.0f + d2 * 0.0024702380951963226f - d2 * d2 * 3.7297408997537985e-05f;
+    float c_ = 1.0f / 1920.0f - d2 * 4.87350869747975e-05f - k2 * 3.1001936068463107e-06f;
+    ch += (b_ + c_ * k2) * k2;
+    r.th0 = th0; r.k0 = k0; r.k1 = k1; r.ch = ch;
+    return r;
+}
+
+__device__ __forceinline__ float es_params_eval_th(const EulerParams &p, float t) {
+    return (p.k0 + 0.5f * p.k1 * (t - 1.0f)) * t - p.th0;
+}
+
+// flatten.wgsl:165-196
+__device__ vec2 integ_euler_10(float k0, float k1) {
+    float t1_1 = k0;
+    float t1_2 = 0.5f * k1;
+    float t2_2 = t1_1 * t1_1;
+    float t2_3 = 2.0f * (t1_1 * t1_2);
+    float t2_4 = t1_2 * t1_2;
+    float t3_4 = t2_2 * t1_2 + t2_3 * t1_1;
+    float t3_6 = t2_4 * t1_2;
+    float t4_4 = t2_2 * t2_2;
+    float t4_5 = 2.0f * (t2_2 * t2_3);
+    float t4_6 = 2.0f * (t2_2 * t2_4) + t2_3 * t2_3;
+    float t4_7 = 2.0f * (t2_3 * t2_4);
+    float t4_8 = t2_4 * t2_4;
+    float t5_6 = t4_4 * t1_2 + t4_5 * t1_1;
+    float t5_8 = t4_6 * t1_2 + t4_7 * t1_1;
+    float t6_6 = t4_4 * t2_2;
+    float t6_7 = t4_4 * t2_3 + t4_5 * t2_2;
+    float t6_8 = t4_4 * t2_4 + t4_5 * t2_3 + t4_6 * t2_2;
+    float t7_8 = t6_6 * t1_2 + t6_7 * t1_1;
+    float t8_8 = t6_6 * t2_2;
+    float u = 1.0f;
+    u -= (1.0f / 24.0f) * t2_2 + (1.0f / 160.0f) * t2_4;
+    u += (1.0f / 1920.0f) * t4_4 + (1.0f / 10752.0f) * t4_6 + (1.0f / 55296.0f) * t4_8;
+    u -= (1.0f / 322560.0f) * t6_6 + (1.0f / 1658880.0f) * t6_8;
+    u += (1.0f / 92897280.0f) * t8_8;
+    float v = (1.0f / 12.0f) * t1_2;
+    v -= (1.0f / 480.0f) * t3_4 + (1.0f / 2688.0f) * t3_6;
+    v += (1.0f / 53760.0f) * t5_6 + (1.0f / 276480.0f) * t5_8;
+    v -= (1.0f / 11612160.0f) * t7_8;
+    return v2(u, v);
+}
+
+// flatten.wgsl:198-227
+__device__ vec2 es_seg_eval_with_offset(vec2 p0, vec2 p1, const EulerParams &p, float t, float normalized_offset) {
+    float thm = es_params_eval_th(p, t * 0.5f);
+    float k0 = p.k0, k1 = p.k1;
+    vec2 uv = integ_euler_10((k0 + k1 * (0.5f * t - 0.5f)) * t, k1 * t * t);
+    float scale = t / p.ch;
+    float s = scale * sin_cr(thm);
+    float cs = scale * cos_cr(thm);
+    float ex = uv.x * cs - uv.y * s;
+    float ey = -uv.y * cs - uv.x * s;
+    float th = es_params_eval_th(p, t);
+    vec2 xy = v2(ex + normalized_offset * sin_cr(th), ey + normalized_offset * cos_cr(th));
+    vec2 chord = p1 - p0;
+    return v2(p0.x + (chord.x * xy.x - chord.y * xy.y), p0.y + (chord.x * xy.y + chord.y * xy.x));
+}
+
+__device__ __forceinline__ float pow_1_5_signed(float x) { return x * sqrtf(fabsf(x)); }
+
+constexpr float BREAK1 = 0.8f, BREAK2 = 1.25f, BREAK3 = 2.1f;
+constexpr float SIN_SCALE = 1.0976991822760038f;
+constexpr float QUAD_A1 = 0.6406f, QUAD_B1 = -0.81f, QUAD_C1 = 0.9148117935952064f;
+constexpr float QUAD_A2 = 0.5f, QUAD_B2 = -0.156f, QUAD_C2 = 0.16145779359520596f;
+constexpr float QUAD_W1 = 0.5f * QUAD_B1 / QUAD_A1, QUAD_V1 = 1.0f / QUAD_A1, QUAD_U1 = QUAD_W1 * QUAD_W1 - QUAD_C1 / QUAD_A1;
+constexpr float QUAD_W2 = 0.5f * QUAD_B2 / QUAD_A2, QUAD_V2 = 1.0f / QUAD_A2, QUAD_U2 = QUAD_W2 * QUAD_W2 - QUAD_C2 / QUAD_A2;
+constexpr float FRAC_PI_4 = 0.7853981633974483f;
+constexpr float CBRT_9_8 = 1.040041911525952f;
+constexpr float SQRT8_OVER_3 = 0.9428090415820634f;
+
+// flatten.wgsl:254-266
+__device__ float espc_int_approx(float x) {
+    float y = fabsf(x);
+    float a;
+    if (y < BREAK1) {
+        a = sin_cr(SIN_SCALE * y) * (1.0f / SIN_SCALE);
+    } else if (y < BREAK2) {
+        a = SQRT8_OVER_3 * pow_1_5_signed(y - 1.0f) + FRAC_PI_4;
+    } else {
+        float qa = y < BREAK3 ? QUAD_A1 : QUAD_A2;
+        float qb = y < BREAK3 ? QUAD_B1 : QUAD_B2;
+        float qc = y < BREAK3 ? QUAD_C1 : QUAD_C2;
+        a = (qa * y + qb) * y + qc;
+    }
+    return a * signf(x);
+}
+
+// flatten.wgsl:268-282
+__device__ float espc_int_inv_approx(float x) {
+    float y = fabsf(x);
+    float a;
+    if (y < 0.7010707591262915f) {
+        a = asin_cr(y * SIN_SCALE) * (1.0f / SIN_SCALE);
+    } else if (y < 0.903249293595206f) {
+        float b = y - FRAC_PI_4;
+        float u = pow_cr(fabsf(b), 2.0f / 3.0f) * signf(b);
+        a = u * CBRT_9_8 + 1.0f;
+    } else {
+        bool lo = y < 2.038857793595206f;
+        float u = lo ? QUAD_U1 : QUAD_U2;
+        float v = lo ? QUAD_V1 : QUAD_V2;
+        float w = lo ? QUAD_W1 : QUAD_W2;
+        a = sqrtf(u + v * y) - w;
+    }
+    return a * signf(x);
+}
+
+// flatten.wgsl:289-297
+__device__ PointDeriv eval_cubic_and_deriv(vec2 p0, vec2 p1, vec2 p2, vec2 p3, float t) {
+    PointDeriv r;
+    float m = 1.0f - t;
+    float mm = m * m;
+    float mt = m * t;
+    float tt = t * t;
+    vec2 inner = (p1 * (3.0f * mm) + p2 * (3.0f * mt)) + p3 * tt;
+    r.point = p0 * (mm * m) + inner * t;
+    r.deriv = ((p1 - p0) * mm + (p2 - p1) * (2.0f * mt)) + (p3 - p2) * tt;
+    return r;
+}
+
+// flatten.wgsl:299-313
+__device__ vec2 cubic_start_tangent(vec2 p0, vec2 p1, vec2 p2, vec2 p3) {
+    const float EPS = 1e-12f;
+    vec2 d01 = p1 - p0, d02 = p2 - p0, d03 = p3 - p0;
+    if (dot(d01, d01) > EPS) return d01;
+    if (dot(d02, d02) > EPS) return d02;
+    return d03;
+}
+__device__ vec2 cubic_end_tangent(vec2 p0, vec2 p1, vec2 p2, vec2 p3) {
+    const float EPS = 1e-12f;
+    vec2 d23 = p3 - p2, d13 = p3 - p1, d03 = p3 - p0;
+    if (dot(d23, d23) > EPS) return d23;
+    if (dot(d13, d13) > EPS) return d13;
+    return d03;
+}
+
+enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 };
+
+// flatten.wgsl:328-481
+template <bool EMIT>
+__device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
+                              float offset, vec2 start_p, vec2 end_p) {
+    vec2 p0, p1, p2, p3;
+    float scale;
+    Xform transform;
+    vec2 t_start = start_p, t_end = end_p;
+    if (offset == 0.0f) {
+        p0 = xf_apply(local_to_device, cubic.p0);
+        p1 = xf_apply(local_to_device, cubic.p1);
+        p2 = xf_apply(local_to_device, cubic.p2);
+        p3 = xf_apply(local_to_device, cubic.p3);
+        scale = 1.0f;
+        transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+        t_start = p0;
+        t_end = p3;
+    } else {
+        p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
+        transform = local_to_device;
+        scale = 0.5f * (length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
+                        length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
+    }
+    if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return;
+    const float tol = 0.25f;
+    uint32_t t0_u = 0u;
+    float dt = 1.0f;
+    vec2 last_p = p0;
+    vec2 last_q = p1 - p0;
+    if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+    float last_t = 0.0f;
+    vec2 lp0 = t_start;
+    for (;;) {
+        float t0 = (float)t0_u * dt;
+        if (t0 == 1.0f) break;
+        float t1 = t0 + dt;
+        vec2 this_p0 = last_p;
+        vec2 this_q0 = last_q;
+        PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+        if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+            PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+            this_pq1.deriv = new_pq1.deriv;
+            if (t1 < 1.0f) {
+                this_pq1.point = new_pq1.point;
+                t1 = t1 - DERIV_EPS;
+            }
+        }
+        float actual_dt = t1 - last_t;
+        CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
+        if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
+            EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
+            float k0 = ep.k0 - 0.5f * ep.k1;
+            float k1 = ep.k1;
+            float normalized_offset = offset / cp.chord_len;
+            float dist_scaled = normalized_offset * ep.ch;
+            float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
+            float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+            int robust = ESPC_ROBUST_NORMAL;
+            if (fabsf(k1) < K1_THRESH) {
+                float k = ep.k0;
+                n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
+                robust = ESPC_ROBUST_LOW_K1;
+            } else if (fabsf(dist_scaled) < DIST_THRESH) {
+                a = k1;
+                b = k0;
+                int0 = pow_1_5_signed(b);
+                float int1 = pow_1_5_signed(a + b);
+                integral = int1 - int0;
+                n_frac = (2.0f / 3.0f) * integral / a;
+                robust = ESPC_ROBUST_LOW_DIST;
+            } else {
+                a = -2.0f * dist_scaled * k1;
+                b = -1.0f - 2.0f * dist_scaled * k0;
+                int0 = espc_int_approx(b);
+                float int1 = espc_int_approx(a + b);
+                integral = int1 - int0;
+                float k_peak = k0 - k1 * b / a;
+                float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
+                n_frac = integral * integrand_peak / a;
+            }
+            float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
+            uint32_t n_u = f2u(n);
+            uint32_t line_ix = em.alloc(n_u);
+            if constexpr (EMIT) {
+                for (uint32_t i = 0; i < n_u; i++) {
+                    vec2 lp1;
+                    if (i + 1u == n_u && t1 == 1.0f) {
+                        lp1 = t_end;
+                    } else {
+                        float t = (float)(i + 1u) / n;
+                        float sv = t;
+                        if (robust != ESPC_ROBUST_LOW_K1) {
+                            float u = integral * t + int0;
+                            float inv;
+                            if (robust == ESPC_ROBUST_LOW_DIST) inv = pow_cr(fabsf(u), 2.0f / 3.0f) * signf(u);
+                            else inv = espc_int_inv_approx(u);
+                            sv = (inv - b) / a;
+                        }
+                        lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, sv, normalized_offset);
+                    }
+                    vec2 l0 = offset >= 0.0f ? lp0 : lp1;
+                    vec2 l1 = offset >= 0.0f ? lp1 : lp0;
+                    em.write_xf(line_ix + i, path_ix, l0, l1, transform);
+                    lp0 = lp1;
+                }
+            }
+            last_p = this_pq1.point;
+            last_q = this_pq1.deriv;
+            last_t = t1;
+            t0_u += 1u;
+            uint32_t shift = (uint32_t)(__ffs((int)t0_u) - 1);
+            t0_u >>= shift;
+            dt *= (float)(1u << shift);
+        } else {
+            t0_u = t0_u * 2u;
+            dt *= 0.5f;
+        }
+    }
+}
+
+// flatten.wgsl:494-521
+template <bool EMIT>
+__device__ void flatten_arc(Emitter<EMIT> &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float angle,
+                            const Xform &transform) {
+    vec2 p0 = xf_apply(transform, begin);
+    vec2 r = begin - center;
+    const float MIN_THETA = 0.0001f;
+    const float tol = 0.25f;
+    float radius = maxf(tol, length(p0 - xf_apply(transform, center)));
+    float theta = maxf(MIN_THETA, 2.0f * acos_cr(1.0f - tol / radius));
+    uint32_t n_lines = maxu(1u, f2u(ceilf(angle / theta)));
+    uint32_t line_ix = em.alloc(n_lines);
+    if constexpr (EMIT) {
+        float cs = cos_cr(theta);
+        float sn = sin_cr(theta);
+        for (uint32_t i = 0; i < n_lines - 1u; i++) {
+            r = v2(cs * r.x + sn * r.y, -sn * r.x + cs * r.y);
+            vec2 p1 = xf_apply(transform, center + r);
+            em.write(line_ix + i, path_ix, p0, p1);
+            p0 = p1;
+        }
+        vec2 p1 = xf_apply(transform, end);
+        em.write(line_ix + n_lines - 1u, path_ix, p0, p1);
+    }
+}
+
+// flatten.wgsl:523-547
+template <bool EMIT>
+__device__ void draw_cap(Emitter<EMIT> &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
+                         vec2 offset_tangent, const Xform &transform) {
+    if (cap_style == STYLE_FLAGS_CAP_ROUND) {
+        flatten_arc<EMIT>(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
+        return;
+    }
+    vec2 start = cap0, end = cap1;
+    bool is_square = cap_style == STYLE_FLAGS_CAP_SQUARE;
+    uint32_t line_ix = em.alloc(is_square ? 3u : 1u);
+    if (is_square) {
+        vec2 v = offset_tangent;
+        vec2 p0 = start + v;
+        vec2 p1 = end + v;
+        em.write_xf(line_ix + 1u, path_ix, start, p0, transform);
+        em.write_xf(line_ix + 2u, path_ix, p1, end, transform);
+        start = p0;
+        end = p1;
+    }
+    em.write_xf(line_ix, path_ix, start, end, transform);
+}
+
+// unpack2x16float()[0]; vello_encoding/src/math.rs:127-150
+__device__ float f16_to_f32(uint32_t bits) {
+    const uint32_t MAGIC = 113u << 23;
+    const uint32_t SHIFTED_EXP = 0x7c00u << 13;
+    uint32_t o = (bits & 0x7fffu) << 13;
+    uint32_t e = SHIFTED_EXP & o;
+    o += (127u - 15u) << 23;
+    if (e == SHIFTED_EXP) {
+        o += (128u - 16u) << 23;
+    } else if (e == 0u) {
+        o += 1u << 23;
+        o = __float_as_uint(__uint_as_float(o) - __uint_as_float(MAGIC));
+    }
+    return __uint_as_float(o | ((bits & 0x8000u) << 16));
+}
+
+// flatten.wgsl:549-631
+template <bool EMIT>
+__device__ void draw_join(Emitter<EMIT> &em, uint32_t path_ix, uint32_t style_flags, vec2 p0, vec2 tan_prev, vec2 tan_next,
+                          vec2 n_prev, vec2 n_next, const Xform &transform) {
+    vec2 front0 = p0 + n_prev;
+    vec2 front1 = p0 + n_next;
+    vec2 back0 = p0 - n_next;
+    vec2 back1 = p0 - n_prev;
+    float cr = tan_prev.x * tan_next.y - tan_prev.y * tan_next.x;
+    float d = dot(tan_prev, tan_next);
+    uint32_t join = style_flags & STYLE_FLAGS_JOIN_MASK;
+    if (join == STYLE_FLAGS_JOIN_BEVEL) {
+        uint32_t ix = em.alloc(2u);
+        em.write_xf(ix, path_ix, front0, front1, transform);
+        em.write_xf(ix + 1u, path_ix, back0, back1, transform);
+    } else if (join == STYLE_FLAGS_JOIN_MITER) {
+        float hyp = length(v2(cr, d));
+        float miter_limit = f16_to_f32(style_flags & STYLE_MITER_LIMIT_MASK);
+        uint32_t line_ix;
+        if (2.0f * hyp < (hyp + d) * miter_limit * miter_limit && fabsf(cr) > TANGENT_THRESH * TANGENT_THRESH) {
+            bool is_backside = cr > 0.0f;
+            vec2 fp_last = is_backside ? back1 : front0;
+            vec2 fp_this = is_backside ? back0 : front1;
+            vec2 p = is_backside ? back0 : front0;
+            vec2 v = fp_this - fp_last;
+            float h = (tan_prev.x * v.y - tan_prev.y * v.x) / cr;
+            vec2 miter_pt = fp_this - tan_next * h;
+            line_ix = em.alloc(3u);
+            em.write_xf(line_ix, path_ix, p, miter_pt, transform);
+            line_ix += 1u;
+            if (is_backside) back0 = miter_pt; else front0 = miter_pt;
+        } else {
+            line_ix = em.alloc(2u);
+        }
+        em.write_xf(line_ix, path_ix, front0, front1, transform);
+        em.write_xf(line_ix + 1u, path_ix, back0, back1, transform);
+    } else if (join == STYLE_FLAGS_JOIN_ROUND) {
+        vec2 arc0, arc1, other0, other1;
+        if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
+        else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
+        flatten_arc<EMIT>(em, path_ix, arc0, arc1, p0, fabsf(atan2_cr(cr, d)), transform);
+        uint32_t ix = em.alloc(1u);
+        em.write_xf(ix, path_ix, other0, other1, transform);
+    }
+}
+
+struct PathTagData {
+    uint32_t tag_byte;
+    TagMonoid monoid;
+};
+
+__device__ __forceinline__ TagMonoid reduce_tag_f(uint32_t tag_word) {
+    TagMonoid c;
+    uint32_t point_count = tag_word & 0x3030303u;
+    c.pathseg_ix = __popc((point_count * 7u) & 0x4040404u);
+    c.trans_ix = __popc(tag_word & (PATH_TAG_TRANSFORM * 0x1010101u));
+    uint32_t n_points = point_count + ((tag_word >> 2) & 0x1010101u);
+    uint32_t a = n_points + (n_points & (((tag_word >> 3) & 0x1010101u) * 15u));
+    a += a >> 8;
+    a += a >> 16;
+    c.pathseg_offset = a & 0xffu;
+    c.path_ix = __popc(tag_word & (PATH_TAG_PATH * 0x1010101u));
+    c.style_ix = __popc(tag_word & (PATH_TAG_STYLE * 0x1010101u)) * STYLE_SIZE_IN_WORDS;
+    return c;
+}
+
+// flatten.wgsl:684-701
+__device__ PathTagData compute_tag_monoid(const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix) {
+    uint32_t tag_word = scene[cfg.layout.path_tag_base + (ix >> 2)];
+    uint32_t shift = (ix & 3u) * 8u;
+    TagMonoid tm = reduce_tag_f(tag_word & ((1u << shift) - 1u));
+    TagMonoid pre = tag_monoids[ix >> 2];
+    PathTagData r;
+    r.tag_byte = (tag_word >> shift) & 0xffu;
+    r.monoid.trans_ix = pre.trans_ix + tm.trans_ix - 1u;
+    r.monoid.pathseg_ix = pre.pathseg_ix + tm.pathseg_ix;
+    r.monoid.pathseg_offset = pre.pathseg_offset + tm.pathseg_offset;
+    r.monoid.style_ix = pre.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS;
+    r.monoid.path_ix = pre.path_ix + tm.path_ix;
+    return r;
+}
+
+__device__ __forceinline__ vec2 read_f32_point(const uint32_t *pd, uint32_t ix) {
+    return v2(__uint_as_float(pd[ix]), __uint_as_float(pd[ix + 1u]));
+}
+__device__ __forceinline__ vec2 read_i16_point(const uint32_t *pd, uint32_t ix) {
+    uint32_t raw = pd[ix];
+    float x = (float)(((int32_t)(raw << 16)) >> 16);
+    float y = (float)(((int32_t)raw) >> 16);
+    return v2(x, y);
+}
+
+// flatten.wgsl:710-764
+__device__ CubicPoints read_path_segment(const uint32_t *pd, const PathTagData &tag, bool is_stroke) {
+    vec2 p0, p1, p2 = v2(0.0f, 0.0f), p3 = v2(0.0f, 0.0f);
+    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
+    uint32_t off = tag.monoid.pathseg_offset;
+    bool is_stroke_cap_marker = is_stroke && (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+    bool is_open = seg_type == PATH_TAG_QUADTO;
+    if ((tag.tag_byte & PATH_TAG_F32) != 0u) {
+        p0 = read_f32_point(pd, off);
+        p1 = read_f32_point(pd, off + 2u);
+        if (seg_type >= PATH_TAG_QUADTO) {
+            p2 = read_f32_point(pd, off + 4u);
+            if (seg_type == PATH_TAG_CUBICTO) p3 = read_f32_point(pd, off + 6u);
+        }
+    } else {
+        p0 = read_i16_point(pd, off);
+        p1 = read_i16_point(pd, off + 1u);
+        if (seg_type >= PATH_TAG_QUADTO) {
+            p2 = read_i16_point(pd, off + 2u);
+            if (seg_type == PATH_TAG_CUBICTO) p3 = read_i16_point(pd, off + 3u);
+        }
+    }
+    if (is_stroke_cap_marker && is_open) {
+        p0 = p1;
+        p1 = p2;
+        seg_type = PATH_TAG_LINETO;
+    }
+    const float third = 1.0f / 3.0f;
+    if (seg_type == PATH_TAG_LINETO) {
+        p3 = p1;
+        p2 = p3 + (p0 - p3) * third;
+        p1 = p0 + (p3 - p0) * third;
+    } else if (seg_type == PATH_TAG_QUADTO) {
+        p3 = p2;
+        p2 = p1 + (p2 - p1) * third;
+        p1 = p1 + (p0 - p1) * third;
+    }
+    return CubicPoints{p0, p1, p2, p3};
+}
+
+// One tag: flatten.wgsl:831-923 (body of main).  COUNT mode touches no memory but the scene.
+template <bool EMIT>
+__device__ void flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+                            PathBbox *path_bboxes, uint32_t ix) {
+    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
+    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
+    bool is_path = (tag.tag_byte & PATH_TAG_PATH) != 0u;
+    if (!is_path && seg_type == 0u) return;
+    uint32_t path_ix = tag.monoid.path_ix;
+    uint32_t style_ix = tag.monoid.style_ix;
+    uint32_t trans_ix = tag.monoid.trans_ix;
+    uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
+    if constexpr (EMIT) {
+        if (is_path) {
+            path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
+            path_bboxes[path_ix].trans_ix = trans_ix;
+        }
+    }
+    if (seg_type == 0u) return;
+    const uint32_t *pd = scene + cfg.layout.path_data_base;
+    bool is_stroke = (style_flags & STYLE_FLAGS_STYLE) != 0u;
+    Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
+    CubicPoints pts = read_path_segment(pd, tag, is_stroke);
+    em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+    if (is_stroke) {
+        float linewidth = __uint_as_float(scene[cfg.layout.style_base + style_ix + 1u]);
+        float offset = 0.5f * linewidth;
+        bool is_open = seg_type != PATH_TAG_LINETO;
+        bool is_stroke_cap_marker = (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+        if (is_stroke_cap_marker) {
+            if (is_open) {
+                vec2 tangent = pts.p3 - pts.p0;
+                vec2 offset_tangent = normalize(tangent) * offset;
+                vec2 n = v2(-offset_tangent.y, offset_tangent.x);
+                draw_cap<EMIT>(em, path_ix, (style_flags & STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
+                               -offset_tangent, transform);
+            }
+        } else {
+            // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
+            PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
+            CubicPoints npts = read_path_segment(pd, ntag, true);
+            bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
+            bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+            bool do_join = !n_is_marker || n_is_closed;
+            vec2 n_tangent = npts.p3 - npts.p0;
+            if (!n_is_marker) n_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
+
+            vec2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+            if (dot(tan_start, tan_start) < TANGENT_THRESH * TANGENT_THRESH) tan_start = v2(TANGENT_THRESH, 0.0f);
+            vec2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+            if (dot(tan_prev, tan_prev) < TANGENT_THRESH * TANGENT_THRESH) tan_prev = v2(TANGENT_THRESH, 0.0f);
+            vec2 tan_next = n_tangent;
+            if (dot(tan_next, tan_next) < TANGENT_THRESH * TANGENT_THRESH) tan_next = v2(TANGENT_THRESH, 0.0f);
+            vec2 n_start = normalize(v2(-tan_start.y, tan_start.x)) * offset;
+            vec2 offset_tangent = normalize(tan_prev) * offset;
+            vec2 n_prev = v2(-offset_tangent.y, offset_tangent.x);
+            vec2 tnn = normalize(tan_next) * offset;
+            vec2 n_next = v2(-tnn.y, tnn.x);
+
+            flatten_euler<EMIT>(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
+            flatten_euler<EMIT>(em, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
+            if (do_join) {
+                draw_join<EMIT>(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+            } else {
+                draw_cap<EMIT>(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
+                               offset_tangent, transform);
+            }
+        }
+    } else {
+        flatten_euler<EMIT>(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
+    }
+    if constexpr (EMIT) {
+        if (em.bx1 > em.bx0 || em.by1 > em.by0) {
+            PathBbox *out = &path_bboxes[path_ix];
+            atomicMin(&out->x0, f2i(floorf(em.bx0)));
+            atomicMin(&out->y0, f2i(floorf(em.by0)));
+            atomicMax(&out->x1, f2i(ceilf(em.bx1)));
+            atomicMax(&out->y1, f2i(ceilf(em.by1)));
+        }
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_flatten(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                 const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes, Bump *bump,
+                                                 LineSoup *lines) {
+    __shared__ uint32_t sh_scan[4];
+    __shared__ uint32_t sh_base;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tag0 = blockIdx.x * FLATTEN_BLOCK_TAGS + tid;
+
+    // COUNT pass
+    Emitter<false> cnt;
+    cnt.next = 0u;
+    cnt.lines = nullptr;
+    cnt.lines_size = 0u;
+#pragma unroll 1
+    for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
+        uint32_t ix = tag0 + j * 256u;
+        if (ix < n_tags) flatten_tag<false>(cnt, cfg, scene, tag_monoids, path_bboxes, ix);
+    }
+    uint32_t total;
+    uint32_t incl = block256_incl_scan_u32(cnt.next, sh_scan, &total);
+    if (tid == 0u) sh_base = total ? atomicAdd(&bump->lines, total) : 0u;
+    __syncthreads();
+
+    // EMIT pass
+    Emitter<true> em;
+    em.next = sh_base + (incl - cnt.next);
+    em.lines = lines;
+    em.lines_size = cfg.lines_size;
+#pragma unroll 1
+    for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
+        uint32_t ix = tag0 + j * 256u;
+        if (ix < n_tags) flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, ix);
+    }
+}
+
+void launch_flatten(const Frame &f, hipStream_t s) {
+    uint32_t n_tags = f.n_tag_words * 4u;
+    uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
+    if (grid == 0) return;
+    hipLaunchKernelGGL(k_flatten, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.bump(),
+                       f.lines);
+}
+
+}  // namespace vk

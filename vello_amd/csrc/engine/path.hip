@@ -1,0 +1,372 @@
+// path_count (+setup), backdrop_dyn, path_tiling (+setup).
+// Reference: vello_shaders/shader/path_count_setup.wgsl:17-27, path_count.wgsl:51-202,
+// backdrop_dyn.wgsl:28-86, path_tiling_setup.wgsl:20-32, path_tiling.wgsl:39-173
+// (vello/src/render.rs:443-502); CPU twins cpu/{path_count,backdrop,path_tiling}.rs.
+//
+// HIP has no indirect dispatch: both line-driven kernels launch a fixed grid and stride over the
+// count the previous stage left in `bump` (the *_setup dispatches disappear).
+#include "engine.h"
+
+namespace vk {
+
+namespace {
+
+// Everything path_count derives from one line before it walks tiles (path_count.wgsl:60-164).
+struct LineWalk {
+    bool valid;
+    bool is_down, is_positive_slope;
+    float a, b, x0, y0, x_sign, s0x, s0y;
+    uint32_t imin, imax;
+    int32_t ymin, ymax;
+    int32_t bbox0, bbox1, bbox2, bbox3, stride;
+    uint32_t tiles_base;
+};
+
+__device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths) {
+    LineWalk w;
+    w.valid = false;
+    w.imin = 0u;
+    w.imax = 0u;
+    const float TILE_SCALE = 0.0625f;
+    bool is_down = line.p1y >= line.p0y;
+    vec2 xy0 = is_down ? v2(line.p0x, line.p0y) : v2(line.p1x, line.p1y);
+    vec2 xy1 = is_down ? v2(line.p1x, line.p1y) : v2(line.p0x, line.p0y);
+    vec2 s0 = xy0 * TILE_SCALE;
+    vec2 s1 = xy1 * TILE_SCALE;
+    uint32_t count_x = span(s0.x, s1.x) - 1u;
+    uint32_t count = count_x + span(s0.y, s1.y);
+    float dx = fabsf(s1.x - s0.x);
+    float dy = s1.y - s0.y;
+    if (dx + dy == 0.0f) return w;
+    if (dy == 0.0f && floorf(s0.y) == s0.y) return w;
+    float idxdy = 1.0f / (dx + dy);
+    float a = dx * idxdy;
+    bool is_positive_slope = s1.x >= s0.x;
+    float x_sign = is_positive_slope ? 1.0f : -1.0f;
+    float xt0 = floorf(s0.x * x_sign);
+    float c = s0.x * x_sign - xt0;
+    float y0 = floorf(s0.y);
+    float ytop = (s0.y == s1.y) ? ceilf(s0.y) : y0 + 1.0f;
+    float b = minf((dy * c + dx * (ytop - s0.y)) * idxdy, ONE_MINUS_ULP);
+    float robust_err = floorf(a * ((float)count - 1.0f) + b) - (float)count_x;
+    if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
+    float x0 = xt0 * x_sign + (is_positive_slope ? 0.0f : -1.0f);
+
+    Path path = paths[line.path_ix];
+    int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2], bbox3 = (int32_t)path.bbox[3];
+    float xmin = minf(s0.x, s1.x);
+    int32_t stride = bbox2 - bbox0;
+    if (s0.y >= (float)bbox3 || s1.y <= (float)bbox1 || xmin >= (float)bbox2 || stride == 0) return w;
+    uint32_t imin = 0u;
+    if (s0.y < (float)bbox1) {
+        float iminf = roundf_te(((float)bbox1 - y0 + b - a) / (1.0f - a)) - 1.0f;
+        if (y0 + iminf - floorf(a * iminf + b) < (float)bbox1) iminf += 1.0f;
+        imin = f2u(iminf);
+    }
+    uint32_t imax = count;
+    if (s1.y > (float)bbox3) {
+        float imaxf = roundf_te(((float)bbox3 - y0 + b - a) / (1.0f - a)) - 1.0f;
+        if (y0 + imaxf - floorf(a * imaxf + b) < (float)bbox3) imaxf += 1.0f;
+        imax = f2u(imaxf);
+    }
+    int32_t ymin = 0, ymax = 0;
+    if (maxf(s0.x, s1.x) <= (float)bbox0) {
+        ymin = f2i(ceilf(s0.y));
+        ymax = f2i(ceilf(s1.y));
+        imax = imin;
+    } else {
+        float fudge = is_positive_slope ? 0.0f : 1.0f;
+        if (xmin < (float)bbox0) {
+            float f = roundf_te((x_sign * ((float)bbox0 - x0) - b + fudge) / a);
+            if ((x0 + x_sign * floorf(a * f + b) < (float)bbox0) == is_positive_slope) f += 1.0f;
+            int32_t ynext = f2i(y0 + f - floorf(a * f + b) + 1.0f);
+            if (is_positive_slope) {
+                if (f2u(f) > imin) {
+                    ymin = f2i(y0 + (y0 == s0.y ? 0.0f : 1.0f));
+                    ymax = ynext;
+                    imin = f2u(f);
+                }
+            } else {
+                if (f2u(f) < imax) {
+                    ymin = ynext;
+                    ymax = f2i(ceilf(s1.y));
+                    imax = f2u(f);
+                }
+            }
+        }
+        if (maxf(s0.x, s1.x) > (float)bbox2) {
+            float f = roundf_te((x_sign * ((float)bbox2 - x0) - b + fudge) / a);
+            if ((x0 + x_sign * floorf(a * f + b) < (float)bbox2) == is_positive_slope) f += 1.0f;
+            if (is_positive_slope) imax = minu(imax, f2u(f));
+            else imin = maxu(imin, f2u(f));
+        }
+    }
+    imax = maxu(imin, imax);
+    w.valid = true;
+    w.is_down = is_down;
+    w.is_positive_slope = is_positive_slope;
+    w.a = a; w.b = b; w.x0 = x0; w.y0 = y0; w.x_sign = x_sign; w.s0x = s0.x; w.s0y = s0.y;
+    w.imin = imin; w.imax = imax;
+    w.ymin = maxi(ymin, bbox1);
+    w.ymax = mini(ymax, bbox3);
+    w.bbox0 = bbox0; w.bbox1 = bbox1; w.bbox2 = bbox2; w.bbox3 = bbox3; w.stride = stride;
+    w.tiles_base = path.tiles;
+    return w;
+}
+
+}  // namespace
+
+// One workgroup handles chunks of 256 x 8 lines.  Pass 1 derives every line's crossing count
+// (imax - imin), a shuffle scan + ONE atomicAdd(bump.seg_counts) reserves the chunk's slice, pass 2
+// re-derives the walk (cheap, line and path hit L2) and writes backdrops, per-tile counts and the
+// SegmentCount records.  The reference issues one bump atomic per line (path_count.wgsl:172).
+__global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
+                                                    const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
+    __shared__ uint32_t sh_scan[4];
+    __shared__ uint32_t sh_base;
+    const uint32_t tid = threadIdx.x;
+    if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
+    const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
+    for (uint32_t chunk = blockIdx.x * PATH_COUNT_CHUNK; chunk < n_lines; chunk += gridDim.x * PATH_COUNT_CHUNK) {
+        uint32_t my_total = 0u;
+#pragma unroll 1
+        for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
+            uint32_t line_ix = chunk + j * 256u + tid;
+            if (line_ix < n_lines) {
+                LineWalk w = setup_line_walk(lines[line_ix], paths);
+                my_total += w.imax - w.imin;
+            }
+        }
+        uint32_t total;
+        uint32_t incl = block256_incl_scan_u32(my_total, sh_scan, &total);
+        if (tid == 0u) sh_base = total ? atomicAdd(&bump->seg_counts, total) : 0u;
+        __syncthreads();
+        uint32_t seg_base = sh_base + (incl - my_total);
+#pragma unroll 1
+        for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
+            uint32_t line_ix = chunk + j * 256u + tid;
+            if (line_ix >= n_lines) continue;
+            LineWalk w = setup_line_walk(lines[line_ix], paths);
+            if (!w.valid) continue;
+            int32_t delta = w.is_down ? -1 : 1;
+            for (int32_t y = w.ymin; y < w.ymax; y++) {
+                int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride;
+                atomicAdd(&tile[base].backdrop, delta);
+            }
+            float last_z = floorf(w.a * ((float)w.imin - 1.0f) + w.b);
+            for (uint32_t i = w.imin; i < w.imax; i++) {
+                float zf = w.a * (float)i + w.b;
+                float z = floorf(zf);
+                int32_t y = f2i(w.y0 + (float)i - z);
+                int32_t x = f2i(w.x0 + w.x_sign * z);
+                int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
+                bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
+                if (top_edge && x + 1 < w.bbox2) {
+                    int32_t x_bump = maxi(x + 1, w.bbox0);
+                    atomicAdd(&tile[base + x_bump].backdrop, delta);
+                }
+                uint32_t seg_within_slice = atomicAdd(&tile[base + x].segment_count_or_ix, 1u);
+                uint32_t seg_ix = seg_base + (i - w.imin);
+                if (seg_ix < cfg.seg_counts_size) {
+                    SegmentCount sc;
+                    sc.line_ix = line_ix;
+                    sc.counts = (seg_within_slice << 16) | i;
+                    seg_counts[seg_ix] = sc;
+                }
+                last_z = z;
+            }
+            seg_base += w.imax - w.imin;
+        }
+        __syncthreads();  // sh_base / sh_scan reuse in the next chunk
+    }
+}
+
+// backdrop_dyn.wgsl:28-86: row-wise inclusive prefix of tile backdrops, rows load-balanced over
+// the workgroup with a scan + binary search.
+__global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__restrict__ bump, const Path *__restrict__ paths, Tile *tiles) {
+    __shared__ uint32_t sh_row_width[256];
+    __shared__ uint32_t sh_row_count[256];
+    __shared__ uint32_t sh_offset[256];
+    __shared__ uint32_t sh_scan[4];
+    const uint32_t tid = threadIdx.x;
+    if (bump->failed != 0u) return;
+    const uint32_t drawobj_ix = blockIdx.x * 256u + tid;
+    uint32_t row_count = 0u;
+    if (drawobj_ix < cfg.layout.n_draw_objects) {
+        Path path = paths[drawobj_ix];
+        sh_row_width[tid] = path.bbox[2] - path.bbox[0];
+        row_count = path.bbox[3] - path.bbox[1];
+        sh_offset[tid] = path.tiles;
+    } else {
+        sh_row_width[tid] = 0u;
+    }
+    uint32_t total_rows;
+    uint32_t incl = block256_incl_scan_u32(row_count, sh_scan, &total_rows);
+    sh_row_count[tid] = incl;
+    __syncthreads();
+    for (uint32_t row = tid; row < total_rows; row += 256u) {
+        uint32_t el_ix = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++) {
+            uint32_t probe = el_ix + (128u >> i);
+            if (row >= sh_row_count[probe - 1u]) el_ix = probe;
+        }
+        uint32_t width = sh_row_width[el_ix];
+        if (width > 0u) {
+            uint32_t seq_ix = row - (el_ix > 0u ? sh_row_count[el_ix - 1u] : 0u);
+            uint32_t tile_ix = sh_offset[el_ix] + seq_ix * width;
+            int32_t sum = tiles[tile_ix].backdrop;
+            for (uint32_t x = 1u; x < width; x++) {
+                tile_ix += 1u;
+                sum += tiles[tile_ix].backdrop;
+                tiles[tile_ix].backdrop = sum;
+            }
+        }
+    }
+}
+
+// path_tiling.wgsl:39-173: one (line, tile) crossing per thread, clipped to its tile.
+__global__ void __launch_bounds__(256) k_path_tiling(Config cfg, Bump *bump, const SegmentCount *__restrict__ seg_counts,
+                                                     const LineSoup *__restrict__ lines, const Path *__restrict__ paths,
+                                                     const Tile *__restrict__ tiles, Segment *__restrict__ segments, uint32_t *ptcl) {
+    if (bump->failed != 0u) {  // path_tiling_setup.wgsl:21-25
+        if (blockIdx.x == 0 && threadIdx.x == 0) ptcl[0] = ~0u;
+        return;
+    }
+    const float TILE_SCALE = 0.0625f;
+    const uint32_t n_segments = minu(bump->seg_counts, cfg.seg_counts_size);
+    for (uint32_t gi = blockIdx.x * 256u + threadIdx.x; gi < n_segments; gi += gridDim.x * 256u) {
+        SegmentCount sc = seg_counts[gi];
+        LineSoup line = lines[sc.line_ix];
+        uint32_t seg_within_slice = sc.counts >> 16;
+        uint32_t seg_within_line = sc.counts & 0xffffu;
+        bool is_down = line.p1y >= line.p0y;
+        vec2 xy0 = is_down ? v2(line.p0x, line.p0y) : v2(line.p1x, line.p1y);
+        vec2 xy1 = is_down ? v2(line.p1x, line.p1y) : v2(line.p0x, line.p0y);
+        vec2 s0 = xy0 * TILE_SCALE;
+        vec2 s1 = xy1 * TILE_SCALE;
+        uint32_t count_x = span(s0.x, s1.x) - 1u;
+        uint32_t count = count_x + span(s0.y, s1.y);
+        float dx = fabsf(s1.x - s0.x);
+        float dy = s1.y - s0.y;
+        float idxdy = 1.0f / (dx + dy);
+        float a = dx * idxdy;
+        bool is_positive_slope = s1.x >= s0.x;
+        float x_sign = is_positive_slope ? 1.0f : -1.0f;
+        float xt0 = floorf(s0.x * x_sign);
+        float c = s0.x * x_sign - xt0;
+        float y0i = floorf(s0.y);
+        float ytop = (s0.y == s1.y) ? ceilf(s0.y) : y0i + 1.0f;
+        float b = minf((dy * c + dx * (ytop - s0.y)) * idxdy, ONE_MINUS_ULP);
+        float robust_err = floorf(a * ((float)count - 1.0f) + b) - (float)count_x;
+        if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
+        int32_t x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+        float z = floorf(a * (float)seg_within_line + b);
+        int32_t x = x0i + f2i(x_sign * z);
+        int32_t y = f2i(y0i + (float)seg_within_line - z);
+
+        Path path = paths[line.path_ix];
+        int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2];
+        int32_t stride = bbox2 - bbox0;
+        int32_t tile_ix = (int32_t)path.tiles + (y - bbox1) * stride + x - bbox0;
+        Tile tile = tiles[tile_ix];
+        uint32_t seg_start = ~tile.segment_count_or_ix;
+        if ((int32_t)seg_start < 0) continue;
+        vec2 tile_xy = v2((float)x * (float)TILE_WIDTH, (float)y * (float)TILE_HEIGHT);
+        vec2 tile_xy1 = v2(tile_xy.x + (float)TILE_WIDTH, tile_xy.y + (float)TILE_HEIGHT);
+        if (seg_within_line > 0u) {
+            float z_prev = floorf(a * ((float)seg_within_line - 1.0f) + b);
+            if (z == z_prev) {
+                float xt = xy0.x + (xy1.x - xy0.x) * (tile_xy.y - xy0.y) / (xy1.y - xy0.y);
+                xt = clampf(xt, tile_xy.x + 1e-3f, tile_xy1.x);
+                xy0 = v2(xt, tile_xy.y);
+            } else {
+                float x_clip = is_positive_slope ? tile_xy.x : tile_xy1.x;
+                float yt = xy0.y + (xy1.y - xy0.y) * (x_clip - xy0.x) / (xy1.x - xy0.x);
+                yt = clampf(yt, tile_xy.y + 1e-3f, tile_xy1.y);
+                xy0 = v2(x_clip, yt);
+            }
+        }
+        if (seg_within_line < count - 1u) {
+            float z_next = floorf(a * ((float)seg_within_line + 1.0f) + b);
+            if (z == z_next) {
+                float xt = xy0.x + (xy1.x - xy0.x) * (tile_xy1.y - xy0.y) / (xy1.y - xy0.y);
+                xt = clampf(xt, tile_xy.x + 1e-3f, tile_xy1.x);
+                xy1 = v2(xt, tile_xy1.y);
+            } else {
+                float x_clip = is_positive_slope ? tile_xy1.x : tile_xy.x;
+                float yt = xy0.y + (xy1.y - xy0.y) * (x_clip - xy0.x) / (xy1.x - xy0.x);
+                yt = clampf(yt, tile_xy.y + 1e-3f, tile_xy1.y);
+                xy1 = v2(x_clip, yt);
+            }
+        }
+        float y_edge = 1e9f;
+        vec2 p0 = xy0 - tile_xy;
+        vec2 p1 = xy1 - tile_xy;
+        const float EPSILON = 1e-6f;
+        if (p0.x == 0.0f) {
+            if (p1.x == 0.0f) {
+                p0.x = EPSILON;
+                if (p0.y == 0.0f) {
+                    p1.x = EPSILON;
+                    p1.y = (float)TILE_HEIGHT;
+                } else {
+                    p1.x = 2.0f * EPSILON;
+                    p1.y = p0.y;
+                }
+            } else if (p0.y == 0.0f) {
+                p0.x = EPSILON;
+            } else {
+                y_edge = p0.y;
+            }
+        } else if (p1.x == 0.0f) {
+            if (p1.y == 0.0f) {
+                p1.x = EPSILON;
+            } else {
+                y_edge = p1.y;
+            }
+        }
+        if (p0.x == floorf(p0.x) && p0.x != 0.0f) p0.x -= EPSILON;
+        if (p1.x == floorf(p1.x) && p1.x != 0.0f) p1.x -= EPSILON;
+        if (!is_down) {
+            vec2 tmp = p0;
+            p0 = p1;
+            p1 = tmp;
+        }
+        uint32_t out_ix = seg_start + seg_within_slice;
+        if (out_ix < cfg.segments_size) {
+            Segment sg;
+            sg.p0x = p0.x; sg.p0y = p0.y; sg.p1x = p1.x; sg.p1y = p1.y;
+            sg.y_edge = y_edge;
+            sg.pad = 0u;
+            segments[out_ix] = sg;
+        }
+    }
+}
+
+static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max_blocks) {
+    uint64_t g = (work_items + per_block - 1u) / per_block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (uint32_t)g;
+}
+
+void launch_path_count(const Frame &f, hipStream_t s) {
+    // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
+    uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 1024u);
+    hipLaunchKernelGGL(k_path_count, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+}
+
+void launch_backdrop(const Frame &f, hipStream_t s) {
+    uint32_t n_wg = (f.cfg.layout.n_paths + 255u) / 256u;
+    if (n_wg == 0) return;
+    hipLaunchKernelGGL(k_backdrop, dim3(n_wg), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
+}
+
+void launch_path_tiling(const Frame &f, hipStream_t s) {
+    uint32_t grid = clamp_grid(f.cfg.seg_counts_size, 256u, 2048u);
+    hipLaunchKernelGGL(k_path_tiling, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.seg_counts, f.lines, f.paths, f.tiles,
+                       f.segments, f.ptcl);
+}
+
+}  // namespace vk

@@ -1,0 +1,48 @@
+// Mirror of vello::Scene (vello/src/scene.rs:45-470): the API surface a vello user drives.
+// Only what produces the packed stream for the hot path is restated (fills, GPU strokes,
+// clip/blend layers, append); glyphs, images and gradients stay out of scope.
+#pragma once
+#include <optional>
+
+#include "encoding.hpp"
+
+namespace vello {
+
+using kurbo::Affine;
+using vello_encoding::Color;
+using vello_encoding::Encoding;
+using vello_encoding::Fill;
+
+// peniko::BlendMode { mix, compose }
+struct BlendMode {
+    uint32_t mix = 0;      // Mix::Normal
+    uint32_t compose = 3;  // Compose::SrcOver
+};
+
+class Scene {
+  public:
+    void reset() { encoding_.reset(); }
+    const Encoding &encoding() const { return encoding_; }
+    Encoding &encoding_mut() { return encoding_; }
+
+    // scene.rs:316-340
+    void fill(Fill style, const Affine &transform, const Color &brush, const kurbo::BezPath &shape);
+    // scene.rs:347-440 (GPU_STROKES = true; dashing is expanded on the CPU by kurbo::dash upstream
+    // and is not restated here: a non-empty dash_pattern is rejected)
+    bool stroke(const kurbo::Stroke &style, const Affine &transform, const Color &brush, const kurbo::BezPath &shape);
+    // scene.rs:105-253
+    void push_layer(Fill clip_style, BlendMode blend, float alpha, const Affine &transform, const kurbo::BezPath &clip);
+    void push_luminance_mask_layer(Fill clip_style, float alpha, const Affine &transform, const kurbo::BezPath &clip);
+    void push_clip_layer(Fill clip_style, const Affine &transform, const kurbo::BezPath &clip);
+    void pop_layer() { encoding_.encode_end_clip(); }
+    // scene.rs:463-469
+    void append(const Scene &other, const std::optional<Affine> &transform);
+
+  private:
+    void push_layer_inner(const vello_encoding::DrawBeginClip &params, Fill clip_style, const Affine &transform,
+                          const kurbo::BezPath &clip);
+    bool stroke_gpu_inner(const kurbo::Stroke &style, const Affine &transform, const kurbo::BezPath &shape);
+    Encoding encoding_;
+};
+
+}  // namespace vello

@@ -1,0 +1,184 @@
+"""vello::Renderer / RenderParams / AaConfig (vello/src/lib.rs:175-193, :357-369, :432-515) and a
+direct binding of the engine C ABI (include/vello_hip.h) for measurement and differential tests."""
+import collections
+import ctypes
+import enum
+
+import numpy as np
+
+from ._lib import load_library, VelloHipError, Capacities, Bump, LayoutStruct, RenderParamsStruct
+from .scene import Color
+
+
+class AaConfig(enum.IntEnum):
+    Area = 0
+    Msaa8 = 1
+    Msaa16 = 2
+
+
+Layout = collections.namedtuple("Layout", [
+    "n_draw_objects", "n_paths", "n_clips", "bin_data_start", "path_tag_base", "path_data_base", "draw_tag_base",
+    "draw_data_base", "transform_base", "style_base"])
+
+STAGES = ["pathtag_scan", "flatten", "draw_scan", "clip", "binning", "tile_alloc", "path_count", "backdrop", "coarse",
+          "path_tiling", "fine"]
+BUFFERS = ["scene", "config", "tag_monoids", "path_bboxes", "bump", "lines", "draw_monoids", "info_bin_data", "clip_inp",
+           "clip_bboxes", "draw_bboxes", "bin_headers", "paths", "tiles", "seg_counts", "segments", "ptcl", "blend_spill",
+           "output"]
+
+E_CAPACITY = -4
+
+
+class RenderParams:
+    def __init__(self, base_color, width, height, antialiasing_method=AaConfig.Area):
+        self.base_color, self.width, self.height, self.antialiasing_method = base_color, width, height, antialiasing_method
+
+
+class RendererOptions:
+    def __init__(self, device=0, antialiasing_support=7, capacities=None):
+        self.device, self.antialiasing_support, self.capacities = device, antialiasing_support, capacities
+
+
+def _caps(capacities):
+    if capacities is None:
+        return None
+    c = Capacities()
+    for k, v in capacities.items():
+        setattr(c, k, v)
+    return ctypes.byref(c)
+
+
+def _data_ptr(texture):
+    """Accepts a numpy array (host) or a torch tensor (host or device)."""
+    if isinstance(texture, np.ndarray):
+        assert texture.dtype == np.uint8 and texture.flags["C_CONTIGUOUS"]
+        return texture.ctypes.data, False
+    return texture.data_ptr(), bool(texture.is_cuda)
+
+
+class Renderer:
+    """Renderer::new + Renderer::render_to_texture.  Raises VelloHipError when no GPU is usable."""
+
+    def __init__(self, options=None):
+        options = options or RendererOptions()
+        self._lib = load_library()
+        err = ctypes.create_string_buffer(512)
+        self._h = self._lib.vh_renderer_new(options.device, options.antialiasing_support, _caps(options.capacities), err, 512)
+        if not self._h:
+            raise VelloHipError(err.value.decode() or "vello_hip_create failed")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.vh_renderer_free(self._h)
+        except Exception:
+            pass
+        self._h = None
+
+    def render_to_texture(self, scene, texture, params):
+        ptr, is_dev = _data_ptr(texture)
+        stride = params.width * 4
+        r = self._lib.vh_renderer_render_to_texture(self._h, scene._h, ptr, stride, 1 if is_dev else 0, params.width,
+                                                    params.height, params.base_color._ptr(), int(params.antialiasing_method))
+        if r != 0:
+            raise VelloHipError(f"render_to_texture failed ({r}): {self._lib.vh_renderer_error(self._h).decode()}")
+
+    def last_bump(self):
+        b = Bump()
+        self._lib.vh_renderer_last_bump(self._h, ctypes.byref(b))
+        return b.as_dict()
+
+
+class Engine:
+    """Direct binding of include/vello_hip.h (one context = one GPU, one stream)."""
+
+    def __init__(self, device=0, aa_mask=7, capacities=None):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        r = self._lib.vello_hip_create(device, aa_mask, _caps(capacities), ctypes.byref(h))
+        if r != 0:
+            raise VelloHipError(f"vello_hip_create failed ({r}): {self._lib.vello_hip_last_error(None).decode()}")
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.vello_hip_destroy(self._h)
+        except Exception:
+            pass
+        self._h = None
+
+    def _check(self, r, what):
+        if r != 0:
+            raise VelloHipError(f"{what} failed ({r}): {self._lib.vello_hip_last_error(self._h).decode()}")
+
+    @staticmethod
+    def _params(width, height, base_color, aa):
+        bc = base_color.premul_rgba8() if isinstance(base_color, Color) else int(base_color)
+        return RenderParamsStruct(width, height, bc, int(aa))
+
+    def upload_scene(self, packed, layout):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        lay = LayoutStruct(*layout)
+        self._check(self._lib.vello_hip_upload_scene(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), None, 0), "upload_scene")
+
+    def render_resident(self, width, height, base_color, aa, out=None):
+        p = self._params(width, height, base_color, aa)
+        ptr, stride = None, 0
+        if out is not None:
+            ptr, is_dev = _data_ptr(out)
+            assert is_dev, "render_resident writes to device memory"
+            stride = width * 4
+        self._check(self._lib.vello_hip_render_resident(self._h, ctypes.byref(p), ptr, stride), "render_resident")
+
+    def render(self, packed, layout, width, height, base_color, aa):
+        """One blocking frame; returns (HxWx4 uint8 image, bump dict)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        lay = LayoutStruct(*layout)
+        p = self._params(width, height, base_color, aa)
+        out = np.zeros((height, width, 4), dtype=np.uint8)
+        b = Bump()
+        r = self._lib.vello_hip_render(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), ctypes.byref(p), None, 0,
+                                       out.ctypes.data, width * 4, 0, ctypes.byref(b))
+        if r != 0 and r != E_CAPACITY:
+            self._check(r, "render")
+        return out, b.as_dict()
+
+    def sync(self):
+        return self._lib.vello_hip_sync(self._h)
+
+    def bump(self):
+        b = Bump()
+        self._check(self._lib.vello_hip_get_bump(self._h, ctypes.byref(b)), "get_bump")
+        return b.as_dict()
+
+    def run_stages(self, width, height, base_color, aa, first, last):
+        p = self._params(width, height, base_color, aa)
+        first = STAGES.index(first) if isinstance(first, str) else first
+        last = STAGES.index(last) if isinstance(last, str) else last
+        self._check(self._lib.vello_hip_run_stages(self._h, ctypes.byref(p), first, last), "run_stages")
+
+    def read_buffer(self, name, dtype=np.uint8, count_bytes=None, offset=0):
+        bid = BUFFERS.index(name)
+        size = self._lib.vello_hip_buffer_size(self._h, bid)
+        n = size - offset if count_bytes is None else min(count_bytes, size - offset)
+        out = np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.vello_hip_read_buffer(self._h, bid, out.ctypes.data, offset, n), f"read_buffer({name})")
+        return out.view(dtype) if n % np.dtype(dtype).itemsize == 0 else out
+
+    def write_buffer(self, name, data, offset=0):
+        bid = BUFFERS.index(name)
+        data = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        self._check(self._lib.vello_hip_write_buffer(self._h, bid, data.ctypes.data, offset, data.nbytes), f"write_buffer({name})")
+
+    def set_profiling(self, stages):
+        mask = 0
+        for s in stages:
+            mask |= 1 << (STAGES.index(s) if isinstance(s, str) else s)
+        self._lib.vello_hip_set_profiling(self._h, mask)
+
+    def stage_ms(self):
+        ms = (ctypes.c_float * len(STAGES))()
+        cnt = (ctypes.c_uint32 * len(STAGES))()
+        self._check(self._lib.vello_hip_get_stage_ms(self._h, ms, cnt), "get_stage_ms")
+        return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES))}
