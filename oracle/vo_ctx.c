@@ -38,12 +38,12 @@ static int ensure(vo_ctx *c, int id, size_t bytes) {
 
 int vo_set_scene(vo_ctx *c, const uint8_t *scene, size_t scene_len, const vo_layout *layout, uint32_t width,
                  uint32_t height, uint32_t base_color, int aa) {
-    if (!c || !scene || !layout || (scene_len & 3u)) return -1;
+    if (!c || (!scene && scene_len) || !layout || (scene_len & 3u)) return -1;
     free(c->scene);
     /* slack so that speculative reads just past the tag stream stay in bounds */
     c->scene = (uint32_t *)calloc(1, scene_len + 64);
     if (!c->scene) return -1;
-    memcpy(c->scene, scene, scene_len);
+    if (scene_len) memcpy(c->scene, scene, scene_len);
     c->scene_words = scene_len / 4u;
     c->aa = aa;
     vo_config *g = &c->cfg;

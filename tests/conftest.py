@@ -1,0 +1,46 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Builds the in-tree libraries once (no-op when they are up to date)."""
+    import __graft_entry__
+
+    libs = [os.path.join(ROOT, "vello_amd", "lib", "libvello_hip.so"), os.path.join(ROOT, "oracle", "libvello_oracle.so"),
+            os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so")]
+    if not all(os.path.exists(p) for p in libs):
+        __graft_entry__.build()
+    return True
+
+
+@pytest.fixture()
+def emu_engine(built):
+    """Engine bound to the SIMT-emulated build of the kernel sources (CPU-only CI of kernel logic)."""
+    import vello_amd
+    import vello_amd._lib as L
+
+    L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
+    try:
+        yield vello_amd.Engine()
+    finally:
+        L._use_library(None)
+
+
+@pytest.fixture()
+def gpu_engine(built):
+    import vello_amd
+    import vello_amd._lib as L
+
+    L._use_library(None)
+    return vello_amd.Engine(device=0)

@@ -1,0 +1,36 @@
+"""Generates the committed fixtures under tests/golden/ from the read-only reference checkout.
+
+Run in the build container (where /root/reference exists):  python tests/golden/make_golden.py
+The GPU box has no /root/reference; tests only read the generated .npz files.
+
+  smoke_goldens.npz   decoded vello_tests/snapshots/smoke/filled_{circle,square}.png (the only real,
+                      non-LFS reference snapshots of solid-fill scenes)
+  tiger_scene.npz     Ghostscript_Tiger.svg (examples/assets) encoded through the pico_svg-equivalent
+                      loader: packed scene bytes + Layout for a 1024x1024 fit (BASELINE config C2)
+"""
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+
+
+def main():
+    circle = np.array(Image.open(f"{REF}/vello_tests/snapshots/smoke/filled_circle.png").convert("RGB"))
+    square = np.array(Image.open(f"{REF}/vello_tests/snapshots/smoke/filled_square.png").convert("RGB"))
+    np.savez_compressed(os.path.join(HERE, "smoke_goldens.npz"), filled_circle=circle, filled_square=square)
+    import workloads
+
+    svg = open(f"{REF}/examples/assets/Ghostscript_Tiger.svg").read()
+    scene = workloads.tiger_scene(svg, 1024, 1024)
+    packed, layout = scene.resolve()
+    np.savez_compressed(os.path.join(HERE, "tiger_scene.npz"), packed=packed, layout=np.array(layout, dtype=np.uint32))
+    print("smoke goldens", circle.shape, square.shape, "tiger packed", packed.nbytes, "layout", tuple(layout))
+
+
+if __name__ == "__main__":
+    main()

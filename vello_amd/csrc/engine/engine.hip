@@ -360,7 +360,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
 
 int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                            const uint32_t *ramps, uint32_t n_ramps) {
-    if (!c || !scene || !layout || (scene_len & 3u) || scene_len == 0) return VELLO_HIP_E_INVALID;
+    if (!c || (!scene && scene_len) || !layout || (scene_len & 3u)) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     const vello_hip_layout &L = *layout;
     size_t words = scene_len / 4u;
@@ -396,7 +396,7 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
     if ((r = ensure(c, c->buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, c->buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, c->clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
-    HIP_TRY(c, hipMemcpyAsync(c->buf[VELLO_HIP_BUF_SCENE].ptr, scene, scene_len, hipMemcpyHostToDevice, c->stream));
+    if (scene_len) HIP_TRY(c, hipMemcpyAsync(c->buf[VELLO_HIP_BUF_SCENE].ptr, scene, scene_len, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync((char *)c->buf[VELLO_HIP_BUF_SCENE].ptr + scene_len, 0, 64, c->stream));
     c->n_ramps = 0;
     if (ramps && n_ramps) {

@@ -133,5 +133,8 @@ class Scene:
         ptr = ctypes.c_void_p()
         lay = (ctypes.c_uint32 * 10)()
         n = self._lib.vh_scene_resolve(self._h, ctypes.byref(ptr), lay)
-        packed = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
+        if n == 0:
+            packed = np.zeros(0, dtype=np.uint8)
+        else:
+            packed = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
         return packed, Layout(*list(lay))

@@ -1,0 +1,12 @@
+"""Workload definitions for tests and bench.py: the BASELINE.json configs restated as
+concrete, seeded, synthetic inputs.  Harness code, not a product feature.
+
+  C1  circle_scene            single filled Circle, 256x256, Area           (README example colour)
+  C2  tiger_scene             Ghostscript_Tiger.svg via a pico_svg-equivalent loader, 1024x1024, MSAA8
+  C3  paris_like_scene        SYNTHETIC stand-in for paris-30k (the SVG is not in the reference tree)
+  C4  mmark_scene             port of examples/scenes/src/mmark.rs with a seeded RNG, 50k elements
+  C5  8 x C3 with seeds 0x5EED0001..8, one per GPU (bench.py --gpus 8)
+"""
+from .scenes import (circle_scene, smoke_circle_scene, smoke_square_scene, paris_like_scene, mmark_scene,
+                     random_test_scene, clip_blend_scene, stroke_styles_scene)
+from .pico_svg import load_svg, tiger_scene
