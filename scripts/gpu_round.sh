@@ -13,6 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | 
 echo "== bench"
 timeout 600 python bench.py --steps ${BENCH_STEPS:-100} --warmup 10 2>&1 | tail -3 | tee gpurun_out/bench.log
 echo "== rocprof"
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o bench -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/rocprof.log 2>&1
 ls gpurun_out/prof 2>/dev/null | head
 find gpurun_out/prof -name "*kernel_stats*" | head -2 | xargs -r head -30
+rm -f gpurun_out/prof/*kernel_trace.csv gpurun_out/prof/*.db

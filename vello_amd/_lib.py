@@ -53,6 +53,12 @@ def load_library():
         raise VelloHipError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). vello_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever copy is mapped first
+    # serves the whole process, and torch cannot initialise on a foreign copy -> let torch map its runtime first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     c = ctypes
     vp, u32, sz, i32 = c.c_void_p, c.c_uint32, c.c_size_t, c.c_int

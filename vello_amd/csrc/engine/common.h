@@ -75,9 +75,34 @@ constexpr float ONE_MINUS_ULP = 0.99999994f;
 constexpr float ROBUST_EPSILON = 2e-7f;
 
 // ---------------- scalar helpers ----------------
-__device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float cos_cr(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float atan2_cr(float y, float x) { return (float)atan2((double)y, (double)x); }
+// Small-argument fast paths: for |x| <= 2^-6 the truncated Taylor series evaluated in fp64 is accurate to
+// < 2^-57 relative, i.e. it rounds to the same f32 as the full ocml routine (both are "the exact value
+// rounded once" up to ~2^-29 per call) at a tenth of the instructions.  Nearly-straight path segments, the
+// overwhelming majority of tags in map-like scenes, only ever take these paths.
+__device__ __forceinline__ float sin_cr(float x) {
+    double d = (double)x;
+    if (fabsf(x) <= 0.015625f) {
+        double d2 = d * d;
+        return (float)(d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0))))));
+    }
+    return (float)sin(d);
+}
+__device__ __forceinline__ float cos_cr(float x) {
+    double d = (double)x;
+    if (fabsf(x) <= 0.015625f) {
+        double d2 = d * d;
+        return (float)(1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0)))));
+    }
+    return (float)cos(d);
+}
+__device__ __forceinline__ float atan2_cr(float y, float x) {
+    if (x > 0.0f && fabsf(y) <= 0.015625f * x) {
+        double r = (double)y / (double)x;
+        double r2 = r * r;
+        return (float)(r * (1.0 + r2 * (-1.0 / 3.0 + r2 * (1.0 / 5.0 + r2 * (-1.0 / 7.0 + r2 * (1.0 / 9.0 + r2 * (-1.0 / 11.0)))))));
+    }
+    return (float)atan2((double)y, (double)x);
+}
 __device__ __forceinline__ float asin_cr(float x) { return (float)asin((double)x); }
 __device__ __forceinline__ float acos_cr(float x) { return (float)acos((double)x); }
 __device__ __forceinline__ float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }

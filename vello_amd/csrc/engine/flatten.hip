@@ -270,14 +270,17 @@ __device__ vec2 cubic_end_tangent(vec2 p0, vec2 p1, vec2 p2, vec2 p3) {
 
 enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 };
 
-// flatten.wgsl:328-481
+// flatten.wgsl:328-481.  A stroke calls the reference routine twice (+offset, -offset) and both calls
+// re-derive the identical subdivision of the centre-line cubic; here one walk of the subdivision feeds both
+// offset curves (`two_sided`), which halves the Euler-spiral fitting work of the stroker.  Per side the
+// arithmetic is unchanged, only the order in which lines are appended differs (the soup is unordered).
 template <bool EMIT>
 __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
-                              float offset, vec2 start_p, vec2 end_p) {
+                              float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n) {
     vec2 p0, p1, p2, p3;
     float scale;
     Xform transform;
-    vec2 t_start = start_p, t_end = end_p;
+    vec2 t_start[2] = {start_p, start_n}, t_end[2] = {end_p, end_n};
     if (offset == 0.0f) {
         p0 = xf_apply(local_to_device, cubic.p0);
         p1 = xf_apply(local_to_device, cubic.p1);
@@ -285,8 +288,8 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
         p3 = xf_apply(local_to_device, cubic.p3);
         scale = 1.0f;
         transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
-        t_start = p0;
-        t_end = p3;
+        t_start[0] = p0;
+        t_end[0] = p3;
     } else {
         p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
         transform = local_to_device;
@@ -295,13 +298,14 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
     }
     if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return;
     const float tol = 0.25f;
+    const int n_sides = two_sided ? 2 : 1;
     uint32_t t0_u = 0u;
     float dt = 1.0f;
     vec2 last_p = p0;
     vec2 last_q = p1 - p0;
     if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
     float last_t = 0.0f;
-    vec2 lp0 = t_start;
+    vec2 lp0[2] = {t_start[0], t_start[1]};
     for (;;) {
         float t0 = (float)t0_u * dt;
         if (t0 == 1.0f) break;
@@ -323,57 +327,63 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
             EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
             float k0 = ep.k0 - 0.5f * ep.k1;
             float k1 = ep.k1;
-            float normalized_offset = offset / cp.chord_len;
-            float dist_scaled = normalized_offset * ep.ch;
             float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
-            float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
-            int robust = ESPC_ROBUST_NORMAL;
-            if (fabsf(k1) < K1_THRESH) {
-                float k = ep.k0;
-                n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
-                robust = ESPC_ROBUST_LOW_K1;
-            } else if (fabsf(dist_scaled) < DIST_THRESH) {
-                a = k1;
-                b = k0;
-                int0 = pow_1_5_signed(b);
-                float int1 = pow_1_5_signed(a + b);
-                integral = int1 - int0;
-                n_frac = (2.0f / 3.0f) * integral / a;
-                robust = ESPC_ROBUST_LOW_DIST;
-            } else {
-                a = -2.0f * dist_scaled * k1;
-                b = -1.0f - 2.0f * dist_scaled * k0;
-                int0 = espc_int_approx(b);
-                float int1 = espc_int_approx(a + b);
-                integral = int1 - int0;
-                float k_peak = k0 - k1 * b / a;
-                float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
-                n_frac = integral * integrand_peak / a;
-            }
-            float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
-            uint32_t n_u = f2u(n);
-            uint32_t line_ix = em.alloc(n_u);
-            if constexpr (EMIT) {
-                for (uint32_t i = 0; i < n_u; i++) {
-                    vec2 lp1;
-                    if (i + 1u == n_u && t1 == 1.0f) {
-                        lp1 = t_end;
-                    } else {
-                        float t = (float)(i + 1u) / n;
-                        float sv = t;
-                        if (robust != ESPC_ROBUST_LOW_K1) {
-                            float u = integral * t + int0;
-                            float inv;
-                            if (robust == ESPC_ROBUST_LOW_DIST) inv = pow_cr(fabsf(u), 2.0f / 3.0f) * signf(u);
-                            else inv = espc_int_inv_approx(u);
-                            sv = (inv - b) / a;
+#pragma unroll 1
+            for (int side = 0; side < n_sides; side++) {
+                const float off = side ? -offset : offset;
+                float normalized_offset = off / cp.chord_len;
+                float dist_scaled = normalized_offset * ep.ch;
+                float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+                int robust = ESPC_ROBUST_NORMAL;
+                if (fabsf(k1) < K1_THRESH) {
+                    float k = ep.k0;
+                    n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
+                    robust = ESPC_ROBUST_LOW_K1;
+                } else if (fabsf(dist_scaled) < DIST_THRESH) {
+                    a = k1;
+                    b = k0;
+                    int0 = pow_1_5_signed(b);
+                    float int1 = pow_1_5_signed(a + b);
+                    integral = int1 - int0;
+                    n_frac = (2.0f / 3.0f) * integral / a;
+                    robust = ESPC_ROBUST_LOW_DIST;
+                } else {
+                    a = -2.0f * dist_scaled * k1;
+                    b = -1.0f - 2.0f * dist_scaled * k0;
+                    int0 = espc_int_approx(b);
+                    float int1 = espc_int_approx(a + b);
+                    integral = int1 - int0;
+                    float k_peak = k0 - k1 * b / a;
+                    float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
+                    n_frac = integral * integrand_peak / a;
+                }
+                float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
+                uint32_t n_u = f2u(n);
+                uint32_t line_ix = em.alloc(n_u);
+                if constexpr (EMIT) {
+                    vec2 lp = lp0[side];
+                    for (uint32_t i = 0; i < n_u; i++) {
+                        vec2 lp1;
+                        if (i + 1u == n_u && t1 == 1.0f) {
+                            lp1 = t_end[side];
+                        } else {
+                            float t = (float)(i + 1u) / n;
+                            float sv = t;
+                            if (robust != ESPC_ROBUST_LOW_K1) {
+                                float u = integral * t + int0;
+                                float inv;
+                                if (robust == ESPC_ROBUST_LOW_DIST) inv = pow_cr(fabsf(u), 2.0f / 3.0f) * signf(u);
+                                else inv = espc_int_inv_approx(u);
+                                sv = (inv - b) / a;
+                            }
+                            lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, sv, normalized_offset);
                         }
-                        lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, sv, normalized_offset);
+                        vec2 l0 = off >= 0.0f ? lp : lp1;
+                        vec2 l1 = off >= 0.0f ? lp1 : lp;
+                        em.write_xf(line_ix + i, path_ix, l0, l1, transform);
+                        lp = lp1;
                     }
-                    vec2 l0 = offset >= 0.0f ? lp0 : lp1;
-                    vec2 l1 = offset >= 0.0f ? lp1 : lp0;
-                    em.write_xf(line_ix + i, path_ix, l0, l1, transform);
-                    lp0 = lp1;
+                    lp0[side] = lp;
                 }
             }
             last_p = this_pq1.point;
@@ -646,8 +656,8 @@ __device__ void flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t
             vec2 tnn = normalize(tan_next) * offset;
             vec2 n_next = v2(-tnn.y, tnn.x);
 
-            flatten_euler<EMIT>(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev);
-            flatten_euler<EMIT>(em, pts, path_ix, transform, -offset, pts.p0 - n_start, pts.p3 - n_prev);
+            flatten_euler<EMIT>(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev, true, pts.p0 - n_start,
+                                pts.p3 - n_prev);
             if (do_join) {
                 draw_join<EMIT>(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
             } else {
@@ -656,7 +666,7 @@ __device__ void flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t
             }
         }
     } else {
-        flatten_euler<EMIT>(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3);
+        flatten_euler<EMIT>(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3, false, pts.p0, pts.p3);
     }
     if constexpr (EMIT) {
         if (em.bx1 > em.bx0 || em.by1 > em.by0) {
@@ -671,7 +681,7 @@ __device__ void flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_flatten(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+__global__ void __launch_bounds__(256, 2) k_flatten(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                  const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes, Bump *bump,
                                                  LineSoup *lines) {
     __shared__ uint32_t sh_scan[4];
