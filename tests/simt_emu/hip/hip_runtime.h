@@ -94,6 +94,8 @@ static inline void __syncthreads() { simt_emu::barrier(); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __ffs(int x) { return __builtin_ffs(x); }
+static inline int __clzll(long long x) { return x ? __builtin_clzll((unsigned long long)x) : 64; }
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 static inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 static inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
@@ -116,6 +118,16 @@ static inline T __shfl_up(T v, int delta) {
     if (lane < delta) return v;
     T r;
     std::memcpy(&r, &vals[lane - delta], sizeof(T));
+    return r;
+}
+template <class T>
+static inline T __shfl_down(T v, int delta) {
+    unsigned long long bits = 0, vals[64], active;
+    std::memcpy(&bits, &v, sizeof(T));
+    int lane = simt_emu::wave_exchange(bits, vals, &active);
+    if (lane + delta > 63) return v;
+    T r;
+    std::memcpy(&r, &vals[lane + delta], sizeof(T));
     return r;
 }
 template <class T>

@@ -23,10 +23,7 @@ struct LineWalk {
 };
 
 __device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths) {
-    LineWalk w;
-    w.valid = false;
-    w.imin = 0u;
-    w.imax = 0u;
+    LineWalk w = {};
     const float TILE_SCALE = 0.0625f;
     bool is_down = line.p1y >= line.p0y;
     vec2 xy0 = is_down ? v2(line.p0x, line.p0y) : v2(line.p1x, line.p1y);
@@ -142,40 +139,68 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         if (tid == 0u) sh_base = total ? atomicAdd(&bump->seg_counts, total) : 0u;
         __syncthreads();
         uint32_t seg_base = sh_base + (incl - my_total);
+        const int lane = (int)(tid & 63u);
 #pragma unroll 1
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
-            if (line_ix >= n_lines) continue;
-            LineWalk w = setup_line_walk(lines[line_ix], paths);
-            if (!w.valid) continue;
-            int32_t delta = w.is_down ? -1 : 1;
-            for (int32_t y = w.ymin; y < w.ymax; y++) {
-                int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride;
-                atomicAdd(&tile[base].backdrop, delta);
+            LineWalk w = {};
+            if (line_ix < n_lines) w = setup_line_walk(lines[line_ix], paths);
+            const uint32_t count = w.valid ? w.imax - w.imin : 0u;
+            const int32_t delta = w.is_down ? -1 : 1;
+            if (w.valid) {
+                for (int32_t y = w.ymin; y < w.ymax; y++) {
+                    int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride;
+                    atomicAdd(&tile[base].backdrop, delta);
+                }
             }
             float last_z = floorf(w.a * ((float)w.imin - 1.0f) + w.b);
-            for (uint32_t i = w.imin; i < w.imax; i++) {
-                float zf = w.a * (float)i + w.b;
-                float z = floorf(zf);
-                int32_t y = f2i(w.y0 + (float)i - z);
-                int32_t x = f2i(w.x0 + w.x_sign * z);
-                int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
-                bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
-                if (top_edge && x + 1 < w.bbox2) {
-                    int32_t x_bump = maxi(x + 1, w.bbox0);
-                    atomicAdd(&tile[base + x_bump].backdrop, delta);
+            // The wave walks crossings in lockstep.  Consecutive lanes hold consecutive lines of the soup, which
+            // (flatten writes in tag order) are consecutive short segments of one path and mostly fall into the
+            // same tile: runs of adjacent lanes hitting the same tile reserve their slots with ONE returning
+            // atomic issued by the run head (the reference does one per crossing, path_count.wgsl:189).
+            uint32_t max_count = count;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) max_count = maxu(max_count, __shfl_xor(max_count, d));
+            for (uint32_t s = 0; s < max_count; s++) {
+                const bool act = s < count;
+                uint32_t key = 0xffffffffu;
+                uint32_t i = w.imin + s;
+                if (act) {
+                    float zf = w.a * (float)i + w.b;
+                    float z = floorf(zf);
+                    int32_t y = f2i(w.y0 + (float)i - z);
+                    int32_t x = f2i(w.x0 + w.x_sign * z);
+                    int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
+                    bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
+                    if (top_edge && x + 1 < w.bbox2) {
+                        int32_t x_bump = maxi(x + 1, w.bbox0);
+                        atomicAdd(&tile[base + x_bump].backdrop, delta);
+                    }
+                    key = (uint32_t)(base + x);
+                    last_z = z;
                 }
-                uint32_t seg_within_slice = atomicAdd(&tile[base + x].segment_count_or_ix, 1u);
-                uint32_t seg_ix = seg_base + (i - w.imin);
-                if (seg_ix < cfg.seg_counts_size) {
-                    SegmentCount sc;
-                    sc.line_ix = line_ix;
-                    sc.counts = (seg_within_slice << 16) | i;
-                    seg_counts[seg_ix] = sc;
+                uint32_t prev_key = __shfl_up(key, 1);
+                bool head = !act || lane == 0 || prev_key != key;
+                unsigned long long heads = __ballot(head);
+                unsigned long long le = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
+                int head_lane = 63 - __clzll((long long)le);
+                unsigned long long gt = lane == 63 ? 0ull : (heads & (~0ull << (lane + 1)));  // heads after me
+                int run_end = gt ? (__ffsll((long long)gt) - 1) : 64;
+                uint32_t r = 0u;
+                if (act && head) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
+                uint32_t base_slot = __shfl(r, head_lane);
+                if (act) {
+                    uint32_t seg_within_slice = base_slot + (uint32_t)(lane - head_lane);
+                    uint32_t seg_ix = seg_base + s;
+                    if (seg_ix < cfg.seg_counts_size) {
+                        SegmentCount sc;
+                        sc.line_ix = line_ix;
+                        sc.counts = (seg_within_slice << 16) | i;
+                        seg_counts[seg_ix] = sc;
+                    }
                 }
-                last_z = z;
             }
-            seg_base += w.imax - w.imin;
+            seg_base += count;
         }
         __syncthreads();  // sh_base / sh_scan reuse in the next chunk
     }
