@@ -32,9 +32,15 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
     ref = oracle.render()
     img, bump = engine.render(packed, layout, width, height, base_color, aa)
     ob = oracle.bump()
-    if bump != ob:
+    # Occlusion culling in coarse (scenes without clips) skips draws hidden under an opaque full-tile cover:
+    # the segment / PTCL demand can only shrink; every other counter must match exactly.
+    exact = [k for k in BUMP_KEYS if k not in ("segments", "ptcl")]
+    ok = all(bump[k] == ob[k] for k in exact) and bump["segments"] <= ob["segments"] and bump["ptcl"] <= ob["ptcl"]
+    if layout.n_clips != 0:
+        ok = ok and bump == ob
+    if not ok:
         _dump(name + "_bump", img=img, ref=ref)
-    assert bump == ob, f"{name}: bump counters differ: hip {bump} oracle {ob}"
+    assert ok, f"{name}: bump counters differ: hip {bump} oracle {ob}"
     L = layout
     if check_stages:
         n_tw = (L.path_data_base - L.path_tag_base)

@@ -139,6 +139,12 @@ static inline T __shfl_xor(T v, int mask) {
     std::memcpy(&r, &vals[(lane ^ mask) & 63], sizeof(T));
     return r;
 }
+static inline int __builtin_amdgcn_readlane(int v, int lane) { return __shfl(v, lane); }
+static inline int __builtin_amdgcn_readfirstlane(int v) {
+    unsigned long long vals[64], active;
+    simt_emu::wave_exchange((unsigned long long)(unsigned)v, vals, &active);
+    return (int)(unsigned)vals[__builtin_ctzll(active)];
+}
 static inline unsigned long long __ballot(int pred) {
     unsigned long long vals[64], active;
     simt_emu::wave_exchange(pred ? 1ull : 0ull, vals, &active);

@@ -9,7 +9,14 @@
 //  * the reference bumps `bump.segments` once per (tile, path) and `bump.ptcl` once per PTCL chunk
 //    with global atomics (coarse.wgsl:70,92).  Here every batch of 256 draw objects is walked
 //    twice: a SIMULATE pass totals the segments and PTCL chunks each tile will need, a workgroup
-//    scan turns them into offsets behind ONE atomic per counter, and the EMIT pass writes.
+//    scan turns them into offsets behind ONE atomic per counter, and the EMIT pass writes;
+//  * per-element data (tag, draw flags, first draw-data word, offsets) is staged into LDS once per batch
+//    instead of being re-read from global memory for every (tile, element) pair;
+//  * occlusion culling (not in the reference): when a batch holds, for a tile, a fully covering OPAQUE
+//    solid-colour draw (CMD_SOLID + CMD_COLOR with alpha 255) outside any clip/blend layer, premultiplied
+//    src-over makes everything underneath irrelevant bit-exactly (x*0 + c == c), so the tile's list is
+//    restarted at that draw and the covered draws of the batch are never emitted nor given segments.
+//    Enabled only for scenes without clips (the clip state machine must otherwise see every draw).
 #include "engine.h"
 
 namespace vk {
@@ -98,47 +105,59 @@ __device__ __forceinline__ void write3(TileState &st, Alloc &al, uint32_t a, uin
     st.cmd_offset += 3u;
 }
 
+struct ElemLds {
+    uint32_t tag[256];
+    uint32_t flags[256];  // draw_flags = info[di]
+    uint32_t w0[256];     // scene[dd]: colour / gradient index / blend mode
+    uint32_t dd[256];
+    uint32_t di[256];
+};
+
 // One batch of (up to) 256 draw objects for this thread's tile: coarse.wgsl:349-452.
+// `first_el` / `has_kill`: elements before `first_el` are occluded by the opaque solid draw `first_el`.
 template <bool EMIT>
-__device__ void process_batch(TileState &st, Alloc &al, const uint32_t (*sh_bitmaps)[N_TILE], const uint32_t *sh_drawobj_ix,
+__device__ void process_batch(TileState &st, Alloc &al, const uint32_t (*sh_bitmaps)[N_TILE], const ElemLds &el,
                               const uint32_t *sh_tile_base, const uint32_t *sh_tile_stride, uint32_t tid, uint32_t tile_x,
-                              uint32_t tile_y, const Config &cfg, const uint32_t *__restrict__ scene,
-                              const DrawMonoid *__restrict__ draw_monoids, const uint32_t *__restrict__ info_bin_data, Tile *tiles,
-                              Bump *bump, uint32_t *ptcl) {
-    for (uint32_t slice_ix = 0; slice_ix < N_SLICE; slice_ix++) {
+                              uint32_t tile_y, uint32_t first_el, bool has_kill, uint32_t list_start, const Config &cfg,
+                              const uint32_t *__restrict__ scene, Tile *tiles, Bump *bump, uint32_t *ptcl) {
+    for (uint32_t slice_ix = first_el / 32u; slice_ix < N_SLICE; slice_ix++) {
         uint32_t bitmap = sh_bitmaps[slice_ix][tid];
+        if (slice_ix == first_el / 32u) bitmap &= ~((1u << (first_el & 31u)) - 1u);
         while (bitmap != 0u) {
             uint32_t el_ix = slice_ix * 32u + (uint32_t)(__ffs((int)bitmap) - 1);
             bitmap &= bitmap - 1u;
-            uint32_t drawobj_ix = sh_drawobj_ix[el_ix];
-            uint32_t drawtag = scene[cfg.layout.draw_tag_base + drawobj_ix];
+            uint32_t drawtag = el.tag[el_ix];
             if (st.clip_zero_depth == 0u) {
-                DrawMonoid dm = draw_monoids[drawobj_ix];
-                uint32_t dd = cfg.layout.draw_data_base + dm.scene_offset;
-                uint32_t di = dm.info_offset;
-                uint32_t draw_flags = info_bin_data[di];
+                uint32_t dd = el.dd[el_ix];
+                uint32_t di = el.di[el_ix];
+                uint32_t draw_flags = el.flags[el_ix];
                 uint32_t tile_ix = sh_tile_base[el_ix] + sh_tile_stride[el_ix] * tile_y + tile_x;
                 Tile tile = tiles[tile_ix];
+                if (has_kill && el_ix == first_el) {
+                    // everything emitted so far for this tile is covered: restart the list here
+                    st.cmd_offset = list_start;
+                    st.cmd_limit = list_start - 1u + (PTCL_INITIAL_ALLOC - PTCL_HEADROOM);
+                }
                 switch (drawtag) {
                 case DRAWTAG_FILL_COLOR:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write2<EMIT>(st, al, CMD_COLOR, scene[dd], cfg, bump, ptcl);
+                    write2<EMIT>(st, al, CMD_COLOR, el.w0[el_ix], cfg, bump, ptcl);
                     break;
                 case DRAWTAG_BLURRED_ROUNDED_RECT:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write3<EMIT>(st, al, CMD_BLUR_RECT, di + 1u, scene[dd], cfg, bump, ptcl);
+                    write3<EMIT>(st, al, CMD_BLUR_RECT, di + 1u, el.w0[el_ix], cfg, bump, ptcl);
                     break;
                 case DRAWTAG_FILL_LIN_GRADIENT:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write3<EMIT>(st, al, CMD_LIN_GRAD, scene[dd], di + 1u, cfg, bump, ptcl);
+                    write3<EMIT>(st, al, CMD_LIN_GRAD, el.w0[el_ix], di + 1u, cfg, bump, ptcl);
                     break;
                 case DRAWTAG_FILL_RAD_GRADIENT:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write3<EMIT>(st, al, CMD_RAD_GRAD, scene[dd], di + 1u, cfg, bump, ptcl);
+                    write3<EMIT>(st, al, CMD_RAD_GRAD, el.w0[el_ix], di + 1u, cfg, bump, ptcl);
                     break;
                 case DRAWTAG_FILL_SWEEP_GRADIENT:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write3<EMIT>(st, al, CMD_SWEEP_GRAD, scene[dd], di + 1u, cfg, bump, ptcl);
+                    write3<EMIT>(st, al, CMD_SWEEP_GRAD, el.w0[el_ix], di + 1u, cfg, bump, ptcl);
                     break;
                 case DRAWTAG_FILL_IMAGE:
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
@@ -162,7 +181,7 @@ __device__ void process_batch(TileState &st, Alloc &al, const uint32_t (*sh_bitm
                 case DRAWTAG_END_CLIP:
                     st.clip_depth -= 1u;
                     write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                    write3<EMIT>(st, al, CMD_END_CLIP, scene[dd], scene[dd + 1u], cfg, bump, ptcl);
+                    write3<EMIT>(st, al, CMD_END_CLIP, el.w0[el_ix], scene[dd + 1u], cfg, bump, ptcl);
                     st.render_blend_depth -= 1u;
                     break;
                 default: break;
@@ -185,6 +204,8 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                                                 const BinHeader *__restrict__ bin_headers, const uint32_t *__restrict__ info_bin_data,
                                                 const Path *__restrict__ paths, Tile *tiles, Bump *bump, uint32_t *ptcl) {
     __shared__ uint32_t sh_bitmaps[N_SLICE][N_TILE];
+    __shared__ uint32_t sh_kill[N_SLICE][N_TILE];
+    __shared__ ElemLds sh_el;
     __shared__ uint32_t sh_part_count[256];
     __shared__ uint32_t sh_part_offsets[256];
     __shared__ uint32_t sh_drawobj_ix[256];
@@ -221,11 +242,16 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     st.clip_zero_depth = 0u; st.clip_depth = 0u; st.render_blend_depth = 0u; st.max_blend_depth = 0u;
     const uint32_t blend_offset = st.cmd_offset;
     st.cmd_offset += 1u;
+    const uint32_t list_start = st.cmd_offset;
+    const bool cull = cfg.layout.n_clips == 0u;
 
     uint32_t partition_ix = 0u, rd_ix = 0u, wr_ix = 0u, part_start_ix = 0u, ready_ix = 0u;
 
     while (true) {
-        for (uint32_t i = 0; i < N_SLICE; i++) sh_bitmaps[i][tid] = 0u;
+        for (uint32_t i = 0; i < N_SLICE; i++) {
+            sh_bitmaps[i][tid] = 0u;
+            sh_kill[i][tid] = 0u;
+        }
 
         // merge the per-partition bin lists of this bin, 256 elements at a time (coarse.wgsl:218-263)
         while (true) {
@@ -269,8 +295,15 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             tag = scene[cfg.layout.draw_tag_base + drawobj_ix];
         }
         uint32_t tile_count = 0u;
+        sh_el.tag[tid] = tag;
         if (tag != DRAWTAG_NOP) {
-            uint32_t path_ix = draw_monoids[drawobj_ix].path_ix;
+            DrawMonoid dm = draw_monoids[drawobj_ix];
+            uint32_t dd = cfg.layout.draw_data_base + dm.scene_offset;
+            sh_el.dd[tid] = dd;
+            sh_el.di[tid] = dm.info_offset;
+            sh_el.flags[tid] = info_bin_data[dm.info_offset];
+            sh_el.w0[tid] = scene[dd];
+            uint32_t path_ix = dm.path_ix;
             Path path = paths[path_ix];
             uint32_t stride = path.bbox[2] - path.bbox[0];
             sh_tile_stride[tid] = stride;
@@ -298,8 +331,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 uint32_t probe = el_ix + (128u >> i);
                 if (ix >= sh_tile_count[probe - 1u]) el_ix = probe;
             }
-            uint32_t el_obj = sh_drawobj_ix[el_ix];
-            uint32_t el_tag = scene[cfg.layout.draw_tag_base + el_obj];
+            uint32_t el_tag = sh_el.tag[el_ix];
             uint32_t seq_ix = ix - (el_ix > 0u ? sh_tile_count[el_ix - 1u] : 0u);
             uint32_t width = sh_tile_width[el_ix];
             uint32_t x0y0 = sh_tile_x0y0[el_ix];
@@ -309,29 +341,42 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             Tile tile = tiles[tile_ix];
             bool is_clip = (el_tag & 1u) != 0u;
             bool is_blend = false;
-            DrawMonoid dm = draw_monoids[el_obj];
             if (is_clip) {
                 const uint32_t BLEND_CLIP = (128u << 8) | 3u;
-                uint32_t blend = scene[cfg.layout.draw_data_base + dm.scene_offset];
-                is_blend = blend != BLEND_CLIP;
+                is_blend = sh_el.w0[el_ix] != BLEND_CLIP;
             }
-            uint32_t draw_flags = info_bin_data[dm.info_offset];
-            bool even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
+            bool even_odd = (sh_el.flags[el_ix] & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
             uint32_t n_segs = tile.segment_count_or_ix;
             int32_t bd = even_odd ? (abs(tile.backdrop) & 1) : tile.backdrop;
             bool backdrop_clear = bd == 0;
             bool include_tile = n_segs != 0u || (backdrop_clear == is_clip) || is_blend;
-            if (include_tile) atomicOr(&sh_bitmaps[el_ix / 32u][y * N_TILE_X + x], 1u << (el_ix & 31u));
+            if (include_tile) {
+                atomicOr(&sh_bitmaps[el_ix / 32u][y * N_TILE_X + x], 1u << (el_ix & 31u));
+                // fully covering opaque solid colour: occludes every earlier draw of this tile
+                if (cull && el_tag == DRAWTAG_FILL_COLOR && n_segs == 0u && (sh_el.w0[el_ix] >> 24) == 0xffu)
+                    atomicOr(&sh_kill[el_ix / 32u][y * N_TILE_X + x], 1u << (el_ix & 31u));
+            }
         }
         __syncthreads();
 
+        // last occluder of this tile in the batch (if any): earlier elements are skipped by both passes
+        uint32_t first_el = 0u;
+        bool has_kill = false;
+        for (int sl = (int)N_SLICE - 1; sl >= 0; sl--) {
+            uint32_t kb = sh_kill[sl][tid];
+            if (kb != 0u) {
+                first_el = (uint32_t)sl * 32u + (31u - (uint32_t)__clz((int)kb));
+                has_kill = true;
+                break;
+            }
+        }
         // SIMULATE: how many segments / PTCL chunks does this tile need for the batch?
         TileState sim = st;
         Alloc cnt;
         cnt.seg_next = 0u;
         cnt.chunk_next = 0u;
-        process_batch<false>(sim, cnt, sh_bitmaps, sh_drawobj_ix, sh_tile_base, sh_tile_stride, tid, tile_x, tile_y, cfg, scene,
-                             draw_monoids, info_bin_data, tiles, bump, ptcl);
+        process_batch<false>(sim, cnt, sh_bitmaps, sh_el, sh_tile_base, sh_tile_stride, tid, tile_x, tile_y, first_el, has_kill,
+                             list_start, cfg, scene, tiles, bump, ptcl);
         uint32_t total_segs, total_chunks;
         uint32_t seg_incl = block256_incl_scan_u32(cnt.seg_next, sh_scan, &total_segs);
         uint32_t chunk_incl = block256_incl_scan_u32(cnt.chunk_next, sh_scan, &total_chunks);
@@ -344,8 +389,8 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
         Alloc al;
         al.seg_next = sh_seg_base + (seg_incl - cnt.seg_next);
         al.chunk_next = sh_chunk_base + (chunk_incl - cnt.chunk_next) * PTCL_INCREMENT;
-        process_batch<true>(st, al, sh_bitmaps, sh_drawobj_ix, sh_tile_base, sh_tile_stride, tid, tile_x, tile_y, cfg, scene,
-                            draw_monoids, info_bin_data, tiles, bump, ptcl);
+        process_batch<true>(st, al, sh_bitmaps, sh_el, sh_tile_base, sh_tile_stride, tid, tile_x, tile_y, first_el, has_kill,
+                            list_start, cfg, scene, tiles, bump, ptcl);
 
         rd_ix += N_TILE;
         if (rd_ix >= ready_ix && partition_ix >= n_partitions) break;

@@ -52,7 +52,8 @@ struct FineShared {
 };
 
 // ---------------- area AA (fine.wgsl:1005-1059) ----------------
-__device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t lane, float (&area)[4]) {
+__device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t lane, float (&area)[4],
+                               const Segment &first) {
     const uint32_t n_segs = fill.size_and_rule >> 1;
     const bool even_odd = (fill.size_and_rule & 1u) != 0u;
     const float xy_x = (float)((lane & 3u) * PIXELS_PER_THREAD);
@@ -63,7 +64,7 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
     for (uint32_t base = 0; base < n_segs; base += 64u) {
         uint32_t slice = minu(n_segs - base, 64u);
         __syncthreads();
-        if (lane < slice) sh.seg[lane] = segments[fill.seg_data + base + lane];
+        if (lane < slice) sh.seg[lane] = base == 0u ? first : segments[fill.seg_data + base + lane];
         __syncthreads();
         for (uint32_t i = 0; i < slice; i++) {
             Segment sg = sh.seg[i];
@@ -111,7 +112,7 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
 // ---------------- MSAA (fine.wgsl:146-709) ----------------
 template <int AA>
 __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
-                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4]) {
+                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4], const Segment &first) {
     constexpr bool MSAA16 = AA == 2;
     constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
     constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
@@ -138,7 +139,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
         const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
         uint32_t count = 0u;
         if (lane < slice_size) {
-            Segment sg = segments[fill.seg_data + batch * 64u + lane];
+            Segment sg = batch == 0u ? first : segments[fill.seg_data + batch * 64u + lane];
             sh.seg[lane] = sg;
             float y_edge_f = (float)TILE_HEIGHT;
             uint32_t delta = (sg.p1x <= sg.p0x) ? 1u : 0xffffffffu;
@@ -469,7 +470,7 @@ __device__ __forceinline__ void src_over(vec4 &rgba, vec4 fg, float area) {
 }  // namespace
 
 template <int AA>
-__global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+__global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
                                              const uint32_t *__restrict__ mask_lut) {
@@ -490,25 +491,57 @@ __global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restri
     uint32_t clip_depth = 0u;
     float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
-    const uint32_t blend_offset = ptcl[cmd_ix];
+    // The command stream is read 64 words at a time by the whole wave (one 256-B transaction; the tile's
+    // initial PTCL block is exactly one window) and decoded with readlane, instead of a dependent scalar
+    // load per word.  The segments of the NEXT fill are requested while the current one is rasterized.
+    uint32_t win_base = cmd_ix;
+    uint32_t win = ptcl[win_base + lane];
+    auto rd = [&](uint32_t ix) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
+    };
+    auto ensure = [&](uint32_t ix, uint32_t n_words) {
+        if (ix + n_words > win_base + 64u) {
+            win_base = ix;
+            uint32_t a = win_base + lane;
+            win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+        }
+    };
+    const uint32_t blend_offset = rd(cmd_ix);
     cmd_ix += 1u;
+    Segment pre;
+    pre.p0x = 0.0f; pre.p0y = 0.0f; pre.p1x = 0.0f; pre.p1y = 0.0f; pre.y_edge = 0.0f; pre.pad = 0u;
+    uint32_t pre_seg_data = ~0u;
     for (;;) {
-        const uint32_t tag = ptcl[cmd_ix];
+        ensure(cmd_ix, 4u);
+        const uint32_t tag = rd(cmd_ix);
         if (tag == CMD_END) break;
         if (tag == CMD_FILL) {
             CmdFill fill;
-            fill.size_and_rule = ptcl[cmd_ix + 1u];
-            fill.seg_data = ptcl[cmd_ix + 2u];
-            fill.backdrop = (int32_t)ptcl[cmd_ix + 3u];
-            if constexpr (AA == 0) fill_path_area(sh, segments, fill, lane, area);
-            else fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area);
+            fill.size_and_rule = rd(cmd_ix + 1u);
+            fill.seg_data = rd(cmd_ix + 2u);
+            fill.backdrop = (int32_t)rd(cmd_ix + 3u);
+            Segment first = pre;
+            if (pre_seg_data != fill.seg_data) {
+                if (lane < minu(fill.size_and_rule >> 1, 64u)) first = segments[fill.seg_data + lane];
+            }
+            // look ahead: [COLOR] FILL -> prefetch its first segment batch into registers
+            pre_seg_data = ~0u;
+            uint32_t nx = cmd_ix + 4u;
+            if (nx + 2u <= win_base + 64u && rd(nx) == CMD_COLOR) nx += 2u;
+            if (nx + 4u <= win_base + 64u && rd(nx) == CMD_FILL) {
+                uint32_t n2 = rd(nx + 1u) >> 1;
+                pre_seg_data = rd(nx + 2u);
+                if (lane < minu(n2, 64u)) pre = segments[pre_seg_data + lane];
+            }
+            if constexpr (AA == 0) fill_path_area(sh, segments, fill, lane, area, first);
+            else fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area, first);
             cmd_ix += 4u;
         } else if (tag == CMD_SOLID) {
 #pragma unroll
             for (int i = 0; i < 4; i++) area[i] = 1.0f;
             cmd_ix += 1u;
         } else if (tag == CMD_COLOR) {
-            const vec4 fg = unpack4x8unorm(ptcl[cmd_ix + 1u]);
+            const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
 #pragma unroll
             for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
             cmd_ix += 2u;
@@ -529,8 +562,8 @@ __global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restri
             clip_depth += 1u;
             cmd_ix += 1u;
         } else if (tag == CMD_END_CLIP) {
-            const uint32_t blend = ptcl[cmd_ix + 1u];
-            const float alpha = __uint_as_float(ptcl[cmd_ix + 2u]);
+            const uint32_t blend = rd(cmd_ix + 1u);
+            const float alpha = __uint_as_float(rd(cmd_ix + 2u));
             clip_depth -= 1u;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -558,11 +591,11 @@ __global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restri
             }
             cmd_ix += 3u;
         } else if (tag == CMD_JUMP) {
-            cmd_ix = ptcl[cmd_ix + 1u];
+            cmd_ix = rd(cmd_ix + 1u);
         } else if (tag == CMD_LIN_GRAD) {
-            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = ptcl[cmd_ix + 2u];
+            const uint32_t io = rd(cmd_ix + 2u);
             const float line_x = __uint_as_float(info[io]), line_y = __uint_as_float(info[io + 1u]), line_c = __uint_as_float(info[io + 2u]);
             const float d = line_x * xy_x + line_y * xy_y + line_c;
 #pragma unroll
@@ -573,9 +606,9 @@ __global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restri
             }
             cmd_ix += 3u;
         } else if (tag == CMD_RAD_GRAD) {
-            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = ptcl[cmd_ix + 2u];
+            const uint32_t io = rd(cmd_ix + 2u);
             const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
                         m3 = __uint_as_float(info[io + 3u]);
             const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
@@ -619,9 +652,9 @@ __global__ void __launch_bounds__(64) k_fine(Config cfg, const Segment *__restri
             }
             cmd_ix += 3u;
         } else if (tag == CMD_SWEEP_GRAD) {
-            const uint32_t index_mode = ptcl[cmd_ix + 1u];
+            const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = ptcl[cmd_ix + 2u];
+            const uint32_t io = rd(cmd_ix + 2u);
             const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
                         m3 = __uint_as_float(info[io + 3u]);
             const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
