@@ -92,11 +92,13 @@ def main():
     frame = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
     gathered = [torch.zeros_like(frame) for _ in range(world)] if (distributed and rank == 0) else None
 
+    from vello_amd.distributed import gather_frames
+
     def step():
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
         if distributed:
             engine.sync()  # frame complete before the collective on torch's stream
-            dist.gather(frame, gathered, dst=0)
+            gather_frames(frame, rank, world, dst=0, out=gathered)
 
     # warmup, with every stage under HIP events to find the dominant kernel
     engine.set_profiling(vello_amd.renderer.STAGES)
@@ -137,6 +139,16 @@ def main():
     all_ms = engine.stage_ms()
     engine.set_profiling([])
 
+    # PCIe-inclusive rate (never `value`): host scene bytes -> H2D -> full frame, one frame in flight
+    n_pcie = 20
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_pcie):
+        engine.upload_scene(packed, layout)
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync()
+    pcie_fps = n_pcie / (time.perf_counter() - t1)
+
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
@@ -171,6 +183,7 @@ def main():
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
             "bump": bump,
+            "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
         },
         "roofline": {
             "bound": "hbm",
