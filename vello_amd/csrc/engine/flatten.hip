@@ -299,6 +299,39 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
     if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return;
     const float tol = 0.25f;
     const int n_sides = two_sided ? 2 : 1;
+    {
+        // Straight-segment shortcut (exact).  For a nearly straight cubic the general loop below accepts the
+        // whole range [0,1] in its first iteration and emits ONE line t_start -> t_end per side, whatever the
+        // (tiny) tangent angles are.  With q0 = p1-p0, q1 = p3-p2, chord = p3-p0, theta >= |th0|,|th1| (from
+        // |atan(y/x)| <= |y/x|), S = scale*|chord| and |q| <= |chord| (d0,d1 <= 1) the quantities the loop tests
+        // are bounded by  err*scale <= 2.05*theta*S  (tol = 0.25)  and  n_frac*scale_multiplier <=
+        // 4.5*sqrt(theta)*sqrt(S/2)  in each of the three ESPC branches (needs |offset/chord|*theta < 2.5e-3 in
+        // the parallel-curve branch); theta*S <= 0.02 keeps both decisions 2-6x inside their thresholds, far
+        // beyond f32 rounding, so "accept, n = 1" is what the loop would compute.  Polylines (most of a
+        // map-like scene) then cost ~40 flops per pass instead of six fp64 transcendentals.
+        vec2 q0 = p1 - p0, q1 = p3 - p2, chd = p3 - p0;
+        float c2 = dot(chd, chd), a0 = dot(q0, q0), a1 = dot(q1, q1);
+        float h0x = dot(q0, chd), h0y = q0.y * chd.x - q0.x * chd.y;
+        float h1x = dot(q1, chd), h1y = q1.x * chd.y - q1.y * chd.x;
+        float clen = sqrtf(c2);
+        float S = scale * clen;
+        float ay0 = fabsf(h0y), ay1 = fabsf(h1y), aoff = fabsf(offset);
+        bool straight = c2 >= 4e-12f && a0 >= 4e-12f && a1 >= 4e-12f && a0 <= c2 && a1 <= c2 && h0x > 0.0f && h1x > 0.0f &&
+                        ay0 * S <= 0.02f * h0x && ay1 * S <= 0.02f * h1x && aoff * ay0 <= 2.5e-3f * h0x * clen &&
+                        aoff * ay1 <= 2.5e-3f * h1x * clen;
+        if (straight) {
+            uint32_t line_ix = em.alloc((uint32_t)n_sides);
+            if constexpr (EMIT) {
+                for (int side = 0; side < n_sides; side++) {
+                    const float off = side ? -offset : offset;
+                    vec2 l0 = off >= 0.0f ? t_start[side] : t_end[side];
+                    vec2 l1 = off >= 0.0f ? t_end[side] : t_start[side];
+                    em.write_xf(line_ix + (uint32_t)side, path_ix, l0, l1, transform);
+                }
+            }
+            return;
+        }
+    }
     uint32_t t0_u = 0u;
     float dt = 1.0f;
     vec2 last_p = p0;
