@@ -12,7 +12,9 @@ the timed region (PCIe-inclusive numbers are in DESIGN.md).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic bytes of that stage
 (DESIGN.md "algorithmic bytes") / its mean launch duration measured with HIP events on the engine's stream
-inside the timed region.  `cpu_baseline` times the CPU oracle (a port of the reference's CPU shaders +
+inside the timed region (with --in-flight > 1 the kernels of neighbouring frames share the CUs during that
+launch; `avg_launch_ms_isolated`/`achieved_isolated` repeat the measurement with one frame at a time).
+`cpu_baseline` times the CPU oracle (a port of the reference's CPU shaders +
 fine.wgsl, single thread) on a bounded sample of the same workload on rank 0 at N=1.
 """
 import argparse
@@ -62,6 +64,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="frames the engine keeps in flight (wgpu queues recordings the same way); 1 = serial frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,21 +93,40 @@ def main():
     engine = vello_amd.Engine(device=local_rank)
     engine.upload_scene(packed, layout)
     aa = vello_amd.AaConfig.Msaa16
-    frame = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=f"cuda:{local_rank}")
+    nif = max(1, min(args.in_flight, 8))
+    engine.set_frames_in_flight(nif)
+    # every in-flight frame owns its target (a swapchain of nif images)
+    ring = [torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(nif)]
+    frame = ring[0]
     gathered = [torch.zeros_like(frame) for _ in range(world)] if (distributed and rank == 0) else None
 
     from vello_amd.distributed import gather_frames
 
+    issued = [0]
+
     def step():
-        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        i = issued[0]
+        issued[0] = i + 1
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
+        if distributed and i >= nif - 1:
+            # the oldest in-flight frame is complete before its collective goes on torch's stream
+            engine.sync_frame(nif - 1)
+            gather_frames(ring[(i - (nif - 1)) % nif], rank, world, dst=0, out=gathered)
+
+    def flush():
+        # gather the nif-1 frames still in flight (every rendered frame is exchanged exactly once)
         if distributed:
-            engine.sync()  # frame complete before the collective on torch's stream
-            gather_frames(frame, rank, world, dst=0, out=gathered)
+            i = issued[0]
+            for age in range(min(nif - 1, i) - 1, -1, -1):
+                engine.sync_frame(age)
+                gather_frames(ring[(i - 1 - age) % nif], rank, world, dst=0, out=gathered)
+        issued[0] = 0
 
     # warmup, with every stage under HIP events to find the dominant kernel
     engine.set_profiling(vello_amd.renderer.STAGES)
     for _ in range(max(args.warmup, 1)):
         step()
+    flush()
     torch.cuda.synchronize()
     rc = engine.sync()
     if rc != 0:
@@ -120,21 +143,34 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    engine.sync()
+    flush()
+    rc = engine.sync()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit(f"frame failed in the timed region: {rc} {engine.bump()}")
     dom_ms, dom_n = engine.stage_ms()[dominant]
     if distributed:
         t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-stage breakdown (separate pass, not part of `value`)
-    engine.set_profiling(vello_amd.renderer.STAGES)
-    for _ in range(min(args.steps, 50)):
+    # serial-frame passes (separate, not part of `value`): one frame at a time gives the frame latency and
+    # the isolated per-kernel durations (no other frame's kernels sharing the CUs)
+    n_serial = min(args.steps, 50)
+    engine.set_profiling([])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_serial):
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync_frame(0)
+    serial_ms = (time.perf_counter() - t1) / n_serial * 1e3
+    engine.set_profiling(vello_amd.renderer.STAGES)
+    for _ in range(n_serial):
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync_frame(0)
     engine.sync()
     all_ms = engine.stage_ms()
     engine.set_profiling([])
@@ -183,6 +219,8 @@ def main():
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
             "bump": bump,
+            "frames_in_flight": nif,
+            "serial_frame_latency_ms": round(serial_ms, 4),
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
         },
         "roofline": {
@@ -195,6 +233,8 @@ def main():
             "traffic": None,
             "algorithmic_bytes_per_launch": int(sb[dominant]),
             "avg_launch_ms": round(dom_avg_s * 1e3, 5),
+            "avg_launch_ms_isolated": round(all_ms[dominant][0] / max(all_ms[dominant][1], 1), 5),
+            "achieved_isolated": round(sb[dominant] / (all_ms[dominant][0] / max(all_ms[dominant][1], 1) * 1e-3) / 1e9, 2),
             "frame_algorithmic_bytes": int(frame_bytes),
             "frame_achieved_GBps": round(frame_bytes / (elapsed / args.steps) / 1e9 * (1 if not distributed else 1), 2),
             "stage_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in all_ms.items()},

@@ -18,6 +18,7 @@
  *                              Command::UploadUniform("vello.config")    vello/src/recording.rs:124-140
  *   vello_hip_render_resident  the Dispatch/DispatchIndirect chain       vello/src/render.rs:250-502, :560-629
  *   vello_hip_sync             queue.submit + device.poll                vello/src/wgpu_engine.rs:757
+ *   vello_hip_set_frames_in_flight  back-to-back queue.submit without waiting  vello/src/wgpu_engine.rs:757
  *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
  *   vello_hip_run_stages /     CpuShaderType::Present per-stage seam     vello/src/wgpu_engine.rs:57-61, :541-553,
  *   vello_hip_{read,write}_buffer  (CpuBinding byte buffers)             vello_shaders/src/cpu.rs:58-62
@@ -140,7 +141,14 @@ int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scen
 /* ... then each call enqueues one full frame (all stages) on the context's stream and returns
  * without waiting.  `out_device` may be NULL (render into the internal target only). */
 int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
-/* Waits for everything enqueued; returns VELLO_HIP_E_CAPACITY if the last frame overflowed. */
+/* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting
+ * (wgpu_engine.rs:757); with n > 1 consecutive vello_hip_render_resident calls rotate over n private buffer
+ * sets and streams and overlap on the GPU.  The caller must hand each in-flight frame its own target. */
+int vello_hip_set_frames_in_flight(vello_hip_ctx *ctx, uint32_t n);
+/* Waits for the frame enqueued `age` vello_hip_render_resident calls ago (0 = newest, age < frames in flight)
+ * without draining the younger ones; does not inspect bump.failed (vello_hip_sync does). */
+int vello_hip_sync_frame(vello_hip_ctx *ctx, uint32_t age);
+/* Waits for everything enqueued; returns VELLO_HIP_E_CAPACITY if a frame overflowed. */
 int vello_hip_sync(vello_hip_ctx *ctx);
 int vello_hip_get_bump(vello_hip_ctx *ctx, vello_hip_bump *out);
 /* The hipStream_t the context launches on (for callers that record their own events). */

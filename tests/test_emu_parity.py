@@ -61,3 +61,33 @@ def test_emu_capacity_overflow_leaves_target_untouched(built):
         assert eng.sync() == -4
     finally:
         L._use_library(None)
+
+
+def test_emu_frames_in_flight_rotate_lanes(built):
+    # host logic of vello_hip_set_frames_in_flight: the ring of private buffer sets, sync_frame ages,
+    # read_buffer following the newest lane
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        eng = vello_amd.Engine()
+        packed, layout = workloads.stroke_styles_scene().resolve()
+        eng.upload_scene(packed, layout)
+        eng.set_frames_in_flight(3)
+        o = Oracle()
+        variants = [(96, 96, BLACK, AaConfig.Area), (128, 64, WHITE, AaConfig.Msaa8), (64, 128, BLACK, AaConfig.Msaa16)]
+        for i in range(5):
+            w, h, base, aa = variants[i % 3]
+            eng.render_resident(w, h, base, aa)
+            eng.sync_frame(0)
+            img = eng.read_buffer("output", np.uint8, w * h * 4).reshape(h, w, 4)
+            o.set_scene(packed, layout, w, h, base, int(aa))
+            ref = o.render()
+            assert np.abs(img.astype(int) - ref.astype(int)).max() <= (1 if aa == AaConfig.Area else 0)
+        assert eng.sync() == 0
+        with pytest.raises(Exception):
+            eng.sync_frame(3)
+    finally:
+        L._use_library(None)

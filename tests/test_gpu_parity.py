@@ -169,3 +169,36 @@ def test_config_c4_mmark_reduced(gpu_engine):
     # mmark generator at a size the oracle finishes quickly (5k elements); binning stress at 2048^2
     packed, layout = workloads.mmark_scene(n=5000).resolve()
     compare_frame(gpu_engine, packed, layout, 2048, 2048, WHITE, AaConfig.Msaa16, "gpu_mmark5k")
+
+
+def test_frames_in_flight_match_oracle(built):
+    # three frames of one resident scene in flight on three lanes, each with its own target and its own
+    # params (size / base colour / AA): every one must equal the oracle's frame for those params
+    import torch
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    packed, layout = workloads.random_test_scene(5, n_paths=500, size=384.0, strokes=True, clips=False).resolve()
+    eng = vello_amd.Engine()
+    eng.set_frames_in_flight(3)
+    eng.upload_scene(packed, layout)
+    variants = [(384, 384, BLACK, AaConfig.Msaa16), (320, 256, WHITE, AaConfig.Msaa8), (384, 200, 0xFF204060, AaConfig.Msaa16)]
+    targets = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for (w, h, _, _) in variants]
+    for rep in range(4):
+        for (w, h, base, aa), t in zip(variants, targets):
+            eng.render_resident(w, h, base, aa, out=t)
+    eng.sync_frame(2)
+    assert eng.sync() == 0
+    o = Oracle()
+    for (w, h, base, aa), t in zip(variants, targets):
+        o.set_scene(packed, layout, w, h, base, int(aa))
+        assert np.array_equal(o.render(), t.cpu().numpy()), (w, h, hex(base), int(aa))
+    # growing the ring after the scene is resident allocates the new lanes' scene buffers as well
+    eng.set_frames_in_flight(4)
+    for i in range(8):
+        (w, h, base, aa), t = variants[i % 3], targets[i % 3]
+        eng.render_resident(w, h, base, aa, out=t)
+    assert eng.sync() == 0
+    for (w, h, base, aa), t in zip(variants, targets):
+        o.set_scene(packed, layout, w, h, base, int(aa))
+        assert np.array_equal(o.render(), t.cpu().numpy())

@@ -74,6 +74,8 @@ def load_library():
     sig("vello_hip_render", i32, [vp, vp, sz, c.POINTER(LayoutStruct), c.POINTER(RenderParamsStruct), vp, u32, vp, sz, i32, c.POINTER(Bump)])
     sig("vello_hip_upload_scene", i32, [vp, vp, sz, c.POINTER(LayoutStruct), vp, u32])
     sig("vello_hip_render_resident", i32, [vp, c.POINTER(RenderParamsStruct), vp, sz])
+    sig("vello_hip_set_frames_in_flight", i32, [vp, u32])
+    sig("vello_hip_sync_frame", i32, [vp, u32])
     sig("vello_hip_sync", i32, [vp])
     sig("vello_hip_get_bump", i32, [vp, c.POINTER(Bump)])
     sig("vello_hip_get_stream", vp, [vp])

@@ -30,14 +30,31 @@ uint32_t align_up(uint32_t len, uint32_t alignment) { return len + ((0u - len) &
 
 }  // namespace
 
+// One frame in flight = one lane: its own stream and its own set of transient buffers.  The packed scene,
+// ramps and mask LUTs are shared read-only.  wgpu queues recordings without waiting (wgpu_engine.rs:757); here
+// consecutive frames additionally overlap on the GPU (coarse launches only one workgroup per bin, fine and
+// flatten are latency-bound, so a second frame fills the idle CUs): vello_hip_set_frames_in_flight.
+struct Lane {
+    hipStream_t stream = nullptr;
+    DevBuf buf[VELLO_HIP_BUF_COUNT];  // SCENE / CONFIG entries unused (shared, see ctx)
+    DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
+    DevBuf clip_stack;
+    struct EvPair {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<EvPair> events;
+    bool used = false;
+};
+
 struct vello_hip_ctx {
     int device = 0;
     uint32_t aa_mask = 0;
-    hipStream_t stream = nullptr;
     vello_hip_capacities caps{};
-    DevBuf buf[VELLO_HIP_BUF_COUNT];
-    DevBuf zero_region;  // Control + look-back states (BUF_BUMP aliases its head)
-    DevBuf clip_stack, ramps, mask8, mask16;
+    DevBuf scene, config;
+    DevBuf ramps, mask8, mask16;
+    std::vector<Lane> lanes;
+    uint32_t next_lane = 0, last_lane = 0;
     uint32_t n_ramps = 0;
     bool scene_resident = false;
     vello_hip_layout layout{};
@@ -49,11 +66,6 @@ struct vello_hip_ctx {
     bool have_cfg = false;
     // profiling
     uint32_t prof_mask = 0;
-    struct EvPair {
-        int stage;
-        hipEvent_t a, b;
-    };
-    std::vector<EvPair> events;
     std::vector<hipEvent_t> event_pool;
     float stage_ms[VELLO_HIP_STAGE_COUNT] = {};
     uint32_t stage_count[VELLO_HIP_STAGE_COUNT] = {};
@@ -91,6 +103,45 @@ hipEvent_t get_event(vello_hip_ctx *c) {
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
+}
+
+int sync_all(vello_hip_ctx *c) {
+    for (auto &l : c->lanes)
+        if (l.stream) HIP_TRY(c, hipStreamSynchronize(l.stream));
+    return 0;
+}
+
+// pool-capacity buffers of one lane (reference sizes: config.rs:398-408)
+int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
+    const vello_hip_capacities &d = c->caps;
+    int r;
+    if (!l.stream) HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_SEG_COUNTS], (size_t)d.seg_counts * sizeof(SegmentCount)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_SEGMENTS], (size_t)d.segments * sizeof(Segment)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
+    return 0;
+}
+
+// scene-dependent buffers of one lane
+int alloc_lane_scene(vello_hip_ctx *c, Lane &l) {
+    const vello_hip_layout &L = c->layout;
+    int r;
+    if ((r = ensure(c, l.zero_region, c->zero_bytes))) return r;
+    l.buf[VELLO_HIP_BUF_BUMP].ptr = l.zero_region.ptr;
+    l.buf[VELLO_HIP_BUF_BUMP].size = sizeof(Bump);
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(c->n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATH_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(PathBbox)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_MONOIDS], (size_t)(L.n_draw_objects + 1u) * sizeof(DrawMonoid)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_CLIP_INP], (size_t)(L.n_clips + 1u) * sizeof(Clip)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_CLIP_BBOXES], (size_t)(L.n_clips + 1u) * sizeof(Bbox4)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
+    if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
+    return 0;
 }
 
 // RenderConfig::new + BufferSizes::new, vello_encoding/src/config.rs:168-196, :363-435
@@ -131,7 +182,8 @@ int configure(vello_hip_ctx *c, const vello_hip_render_params *p, Config &cfg) {
     return 0;
 }
 
-int prepare_frame(vello_hip_ctx *c, const vello_hip_render_params *p, void *out_device, size_t out_stride, Frame &f, bool upload_cfg) {
+int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, void *out_device, size_t out_stride, Frame &f,
+                  bool upload_cfg) {
     if (!c->scene_resident) {
         c->last_error = "no scene uploaded";
         return VELLO_HIP_E_INVALID;
@@ -144,94 +196,104 @@ int prepare_frame(vello_hip_ctx *c, const vello_hip_render_params *p, void *out_
     uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
     uint32_t aligned_n_bins = align_up(wb * hb, 256u);
     uint32_t binning_wgs = (c->layout.n_draw_objects + 255u) / 256u;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
+    if (!out_device && (r = ensure(c, l.buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
     // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
-    if (upload_cfg) HIP_TRY(c, hipMemcpy(c->buf[VELLO_HIP_BUF_CONFIG].ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
+    if (upload_cfg) HIP_TRY(c, hipMemcpy(c->config.ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
     f.n_tag_words = c->n_tag_words;
     f.aa = p->aa;
-    f.scene = (const uint32_t *)c->buf[VELLO_HIP_BUF_SCENE].ptr;
-    f.control = (Control *)c->zero_region.ptr;
-    f.pathtag_state = (unsigned long long *)((char *)c->zero_region.ptr + sizeof(Control));
+    f.scene = (const uint32_t *)c->scene.ptr;
+    f.control = (Control *)l.zero_region.ptr;
+    f.pathtag_state = (unsigned long long *)((char *)l.zero_region.ptr + sizeof(Control));
     f.draw_state = f.pathtag_state + (size_t)c->n_pathtag_parts * 10u;
-    f.tag_monoids = (TagMonoid *)c->buf[VELLO_HIP_BUF_TAG_MONOIDS].ptr;
-    f.path_bboxes = (PathBbox *)c->buf[VELLO_HIP_BUF_PATH_BBOXES].ptr;
-    f.lines = (LineSoup *)c->buf[VELLO_HIP_BUF_LINES].ptr;
-    f.draw_monoids = (DrawMonoid *)c->buf[VELLO_HIP_BUF_DRAW_MONOIDS].ptr;
-    f.info_bin_data = (uint32_t *)c->buf[VELLO_HIP_BUF_INFO_BIN_DATA].ptr;
-    f.clip_inp = (Clip *)c->buf[VELLO_HIP_BUF_CLIP_INP].ptr;
-    f.clip_bboxes = (Bbox4 *)c->buf[VELLO_HIP_BUF_CLIP_BBOXES].ptr;
-    f.draw_bboxes = (Bbox4 *)c->buf[VELLO_HIP_BUF_DRAW_BBOXES].ptr;
-    f.bin_headers = (BinHeader *)c->buf[VELLO_HIP_BUF_BIN_HEADERS].ptr;
-    f.paths = (Path *)c->buf[VELLO_HIP_BUF_PATHS].ptr;
-    f.tiles = (Tile *)c->buf[VELLO_HIP_BUF_TILES].ptr;
-    f.seg_counts = (SegmentCount *)c->buf[VELLO_HIP_BUF_SEG_COUNTS].ptr;
-    f.segments = (Segment *)c->buf[VELLO_HIP_BUF_SEGMENTS].ptr;
-    f.ptcl = (uint32_t *)c->buf[VELLO_HIP_BUF_PTCL].ptr;
-    f.blend_spill = (uint32_t *)c->buf[VELLO_HIP_BUF_BLEND_SPILL].ptr;
-    f.clip_stack = (uint32_t *)c->clip_stack.ptr;
+    f.tag_monoids = (TagMonoid *)l.buf[VELLO_HIP_BUF_TAG_MONOIDS].ptr;
+    f.path_bboxes = (PathBbox *)l.buf[VELLO_HIP_BUF_PATH_BBOXES].ptr;
+    f.lines = (LineSoup *)l.buf[VELLO_HIP_BUF_LINES].ptr;
+    f.draw_monoids = (DrawMonoid *)l.buf[VELLO_HIP_BUF_DRAW_MONOIDS].ptr;
+    f.info_bin_data = (uint32_t *)l.buf[VELLO_HIP_BUF_INFO_BIN_DATA].ptr;
+    f.clip_inp = (Clip *)l.buf[VELLO_HIP_BUF_CLIP_INP].ptr;
+    f.clip_bboxes = (Bbox4 *)l.buf[VELLO_HIP_BUF_CLIP_BBOXES].ptr;
+    f.draw_bboxes = (Bbox4 *)l.buf[VELLO_HIP_BUF_DRAW_BBOXES].ptr;
+    f.bin_headers = (BinHeader *)l.buf[VELLO_HIP_BUF_BIN_HEADERS].ptr;
+    f.paths = (Path *)l.buf[VELLO_HIP_BUF_PATHS].ptr;
+    f.tiles = (Tile *)l.buf[VELLO_HIP_BUF_TILES].ptr;
+    f.seg_counts = (SegmentCount *)l.buf[VELLO_HIP_BUF_SEG_COUNTS].ptr;
+    f.segments = (Segment *)l.buf[VELLO_HIP_BUF_SEGMENTS].ptr;
+    f.ptcl = (uint32_t *)l.buf[VELLO_HIP_BUF_PTCL].ptr;
+    f.blend_spill = (uint32_t *)l.buf[VELLO_HIP_BUF_BLEND_SPILL].ptr;
+    f.clip_stack = (uint32_t *)l.clip_stack.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
         f.out_stride = out_stride ? out_stride : (size_t)p->width * 4u;
     } else {
-        f.output = (uint8_t *)c->buf[VELLO_HIP_BUF_OUTPUT].ptr;
+        f.output = (uint8_t *)l.buf[VELLO_HIP_BUF_OUTPUT].ptr;
         f.out_stride = (size_t)p->width * 4u;
     }
     f.ramps = c->n_ramps ? (const uint32_t *)c->ramps.ptr : nullptr;
     f.n_ramps = c->n_ramps;
     f.mask_lut8 = (const uint32_t *)c->mask8.ptr;
     f.mask_lut16 = (const uint32_t *)c->mask16.ptr;
+    l.used = true;
     return 0;
 }
 
-int run_stage_range(vello_hip_ctx *c, const Frame &f, int first, int last) {
+int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f, int first, int last) {
+    hipStream_t st = l.stream;
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
-        vello_hip_ctx::EvPair ev{s, nullptr, nullptr};
+        Lane::EvPair ev{s, nullptr, nullptr};
         if (prof) {
             ev.a = get_event(c);
             ev.b = get_event(c);
-            HIP_TRY(c, hipEventRecord(ev.a, c->stream));
+            HIP_TRY(c, hipEventRecord(ev.a, st));
         }
         switch (s) {
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
-            HIP_TRY(c, hipMemsetAsync(c->zero_region.ptr, 0, c->zero_bytes, c->stream));
-            launch_pathtag_scan(f, c->stream);
+            HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, c->zero_bytes, st));
+            launch_pathtag_scan(f, st);
             break;
-        case VELLO_HIP_STAGE_FLATTEN: launch_flatten(f, c->stream); break;
-        case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, c->stream); break;
-        case VELLO_HIP_STAGE_CLIP: launch_clip(f, c->stream); break;
-        case VELLO_HIP_STAGE_BINNING: launch_binning(f, c->stream); break;
-        case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, c->stream); break;
-        case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, c->stream); break;
-        case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, c->stream); break;
-        case VELLO_HIP_STAGE_COARSE: launch_coarse(f, c->stream); break;
-        case VELLO_HIP_STAGE_PATH_TILING: launch_path_tiling(f, c->stream); break;
-        case VELLO_HIP_STAGE_FINE: launch_fine(f, c->stream); break;
+        case VELLO_HIP_STAGE_FLATTEN: launch_flatten(f, st); break;
+        case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, st); break;
+        case VELLO_HIP_STAGE_CLIP: launch_clip(f, st); break;
+        case VELLO_HIP_STAGE_BINNING: launch_binning(f, st); break;
+        case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, st); break;
+        case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, st); break;
+        case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, st); break;
+        case VELLO_HIP_STAGE_COARSE: launch_coarse(f, st); break;
+        case VELLO_HIP_STAGE_PATH_TILING: launch_path_tiling(f, st); break;
+        case VELLO_HIP_STAGE_FINE: launch_fine(f, st); break;
         default: return VELLO_HIP_E_INVALID;
         }
         HIP_TRY(c, hipGetLastError());
         if (prof) {
-            HIP_TRY(c, hipEventRecord(ev.b, c->stream));
-            c->events.push_back(ev);
+            HIP_TRY(c, hipEventRecord(ev.b, st));
+            l.events.push_back(ev);
         }
     }
     return 0;
 }
 
 int drain_events(vello_hip_ctx *c) {
-    for (auto &ev : c->events) {
-        float ms = 0.f;
-        HIP_TRY(c, hipEventSynchronize(ev.b));
-        HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
-        c->stage_ms[ev.stage] += ms;
-        c->stage_count[ev.stage] += 1;
-        c->event_pool.push_back(ev.a);
-        c->event_pool.push_back(ev.b);
+    for (auto &l : c->lanes) {
+        for (auto &ev : l.events) {
+            float ms = 0.f;
+            HIP_TRY(c, hipEventSynchronize(ev.b));
+            HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
+            c->stage_ms[ev.stage] += ms;
+            c->stage_count[ev.stage] += 1;
+            c->event_pool.push_back(ev.a);
+            c->event_pool.push_back(ev.b);
+        }
+        l.events.clear();
     }
-    c->events.clear();
     return 0;
+}
+
+DevBuf *find_buf(vello_hip_ctx *c, int id) {
+    if (id == VELLO_HIP_BUF_SCENE) return &c->scene;
+    if (id == VELLO_HIP_BUF_CONFIG) return &c->config;
+    return &c->lanes[c->last_lane].buf[id];
 }
 
 // vello_encoding/src/mask.rs:11-98
@@ -319,15 +381,9 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
         vello_hip_destroy(c);
         return VELLO_HIP_E_HIP;
     };
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_CONFIG], sizeof(Config))) return fail("config");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup))) return fail("lines");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u)) return fail("bin_data");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile))) return fail("tiles");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_SEG_COUNTS], (size_t)d.seg_counts * sizeof(SegmentCount))) return fail("seg_counts");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_SEGMENTS], (size_t)d.segments * sizeof(Segment))) return fail("segments");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u)) return fail("blend_spill");
-    if (ensure(c, c->buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u)) return fail("ptcl");
+    c->lanes.resize(1);
+    if (alloc_lane_pools(c, c->lanes[0])) return fail("pool allocation");
+    if (ensure(c, c->config, sizeof(Config))) return fail("config");
     if (ensure(c, c->mask8, 1024) || ensure(c, c->mask16, 8192)) return fail("mask lut");
     {
         std::vector<uint8_t> l8(1024), l16(8192);
@@ -344,18 +400,38 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
 void vello_hip_destroy(vello_hip_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &ev : c->events) {
-        (void)hipEventDestroy(ev.a);
-        (void)hipEventDestroy(ev.b);
+    for (auto &l : c->lanes) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (auto &ev : l.events) {
+            (void)hipEventDestroy(ev.a);
+            (void)hipEventDestroy(ev.b);
+        }
+        for (int i = 0; i < VELLO_HIP_BUF_COUNT; i++)
+            if (l.buf[i].ptr && i != VELLO_HIP_BUF_BUMP) (void)hipFree(l.buf[i].ptr);
+        if (l.zero_region.ptr) (void)hipFree(l.zero_region.ptr);
+        if (l.clip_stack.ptr) (void)hipFree(l.clip_stack.ptr);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (auto &b : c->buf)
-        if (b.ptr && &b != &c->buf[VELLO_HIP_BUF_BUMP]) (void)hipFree(b.ptr);
-    for (DevBuf *b : {&c->zero_region, &c->clip_stack, &c->ramps, &c->mask8, &c->mask16})
+    for (DevBuf *b : {&c->scene, &c->config, &c->ramps, &c->mask8, &c->mask16})
         if (b->ptr) (void)hipFree(b->ptr);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int vello_hip_set_frames_in_flight(vello_hip_ctx *c, uint32_t n) {
+    if (!c || n < 1 || n > 8) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = sync_all(c);
+    if (r) return r;
+    size_t old = c->lanes.size();
+    if (n < old) return VELLO_HIP_OK;  // lanes are kept; only the rotation shrinks
+    c->lanes.resize(n);
+    for (size_t i = old; i < n; i++) {
+        if ((r = alloc_lane_pools(c, c->lanes[i]))) return r;
+        if (c->scene_resident && (r = alloc_lane_scene(c, c->lanes[i]))) return r;
+    }
+    c->next_lane = 0;
+    return VELLO_HIP_OK;
 }
 
 int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
@@ -375,8 +451,10 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
         return VELLO_HIP_E_INVALID;
     }
     int r;
+    // frames still in flight read the old scene
+    if ((r = sync_all(c))) return r;
     // 64 B of slack: flatten reads tag ix+1 and the (wrapped) style word of pre-style tags speculatively
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_SCENE], scene_len + 64))) return r;
+    if ((r = ensure(c, c->scene, scene_len + 64))) return r;
     c->layout = L;
     c->scene_len = scene_len;
     uint32_t n_path_tags = (L.path_data_base - L.path_tag_base) * 4u;
@@ -385,27 +463,19 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
     if (c->n_pathtag_parts == 0) c->n_pathtag_parts = 1;
     c->n_draw_parts = (L.n_draw_objects + DRAW_PART - 1u) / DRAW_PART;
     c->zero_bytes = sizeof(Control) + ((size_t)c->n_pathtag_parts * 10u + (size_t)c->n_draw_parts * 8u) * 8u;
-    if ((r = ensure(c, c->zero_region, c->zero_bytes))) return r;
-    c->buf[VELLO_HIP_BUF_BUMP].ptr = c->zero_region.ptr;
-    c->buf[VELLO_HIP_BUF_BUMP].size = sizeof(Bump);
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(c->n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_PATH_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(PathBbox)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_DRAW_MONOIDS], (size_t)(L.n_draw_objects + 1u) * sizeof(DrawMonoid)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_CLIP_INP], (size_t)(L.n_clips + 1u) * sizeof(Clip)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_CLIP_BBOXES], (size_t)(L.n_clips + 1u) * sizeof(Bbox4)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
-    if ((r = ensure(c, c->buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
-    if ((r = ensure(c, c->clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
-    if (scene_len) HIP_TRY(c, hipMemcpyAsync(c->buf[VELLO_HIP_BUF_SCENE].ptr, scene, scene_len, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync((char *)c->buf[VELLO_HIP_BUF_SCENE].ptr + scene_len, 0, 64, c->stream));
+    for (auto &l : c->lanes)
+        if ((r = alloc_lane_scene(c, l))) return r;
+    hipStream_t st = c->lanes[0].stream;
+    if (scene_len) HIP_TRY(c, hipMemcpyAsync(c->scene.ptr, scene, scene_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync((char *)c->scene.ptr + scene_len, 0, 64, st));
     c->n_ramps = 0;
     if (ramps && n_ramps) {
         if ((r = ensure(c, c->ramps, (size_t)n_ramps * 512u * 4u))) return r;
-        HIP_TRY(c, hipMemcpyAsync(c->ramps.ptr, ramps, (size_t)n_ramps * 512u * 4u, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->ramps.ptr, ramps, (size_t)n_ramps * 512u * 4u, hipMemcpyHostToDevice, st));
         c->n_ramps = n_ramps;
     }
     // the source buffers are caller-owned only for the duration of the call (recording.rs:124-129)
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(st));
     c->scene_resident = true;
     return VELLO_HIP_OK;
 }
@@ -413,38 +483,55 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
 int vello_hip_render_resident(vello_hip_ctx *c, const vello_hip_render_params *params, void *out_device, size_t out_stride) {
     if (!c) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t li = c->next_lane % (uint32_t)c->lanes.size();
+    c->next_lane = (li + 1u) % (uint32_t)c->lanes.size();
+    c->last_lane = li;
     Frame f;
-    int r = prepare_frame(c, params, out_device, out_stride, f, false);
+    int r = prepare_frame(c, c->lanes[li], params, out_device, out_stride, f, false);
     if (r) return r;
-    return run_stage_range(c, f, 0, VELLO_HIP_STAGE_FINE);
+    return run_stage_range(c, c->lanes[li], f, 0, VELLO_HIP_STAGE_FINE);
 }
 
 int vello_hip_run_stages(vello_hip_ctx *c, const vello_hip_render_params *params, int first, int last) {
     if (!c || first < 0 || last >= VELLO_HIP_STAGE_COUNT || first > last) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
+    Lane &l = c->lanes[c->last_lane];
     Frame f;
-    int r = prepare_frame(c, params, nullptr, 0, f, true);
+    int r = prepare_frame(c, l, params, nullptr, 0, f, true);
     if (r) return r;
-    if ((r = run_stage_range(c, f, first, last))) return r;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((r = run_stage_range(c, l, f, first, last))) return r;
+    HIP_TRY(c, hipStreamSynchronize(l.stream));
     return VELLO_HIP_OK;
 }
 
 int vello_hip_get_bump(vello_hip_ctx *c, vello_hip_bump *out) {
-    if (!c || !out || !c->zero_region.ptr) return VELLO_HIP_E_INVALID;
+    if (!c || !out || !c->lanes[c->last_lane].zero_region.ptr) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->zero_region.ptr, sizeof(vello_hip_bump), hipMemcpyDeviceToHost));
+    Lane &l = c->lanes[c->last_lane];
+    HIP_TRY(c, hipStreamSynchronize(l.stream));
+    HIP_TRY(c, hipMemcpy(out, l.zero_region.ptr, sizeof(vello_hip_bump), hipMemcpyDeviceToHost));
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
+    if (!c || age >= c->lanes.size()) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t n = (uint32_t)c->lanes.size();
+    Lane &l = c->lanes[(c->last_lane + n - age) % n];
+    HIP_TRY(c, hipStreamSynchronize(l.stream));
     return VELLO_HIP_OK;
 }
 
 int vello_hip_sync(vello_hip_ctx *c) {
     if (!c) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->zero_region.ptr && c->have_cfg) {
+    int r = sync_all(c);
+    if (r) return r;
+    if (!c->have_cfg) return VELLO_HIP_OK;
+    for (auto &l : c->lanes) {
+        if (!l.used || !l.zero_region.ptr) continue;
         vello_hip_bump b;
-        HIP_TRY(c, hipMemcpy(&b, c->zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
         if (b.failed != 0u) {
             char msg[160];
             std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,
@@ -456,7 +543,7 @@ int vello_hip_sync(vello_hip_ctx *c) {
     return VELLO_HIP_OK;
 }
 
-void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->stream : nullptr; }
+void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
 
 int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                      const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_rgba8, size_t out_stride,
@@ -475,37 +562,42 @@ int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, c
     if (out_rgba8 && !out_is_device) {
         size_t row = (size_t)params->width * 4u;
         size_t stride = out_stride ? out_stride : row;
-        HIP_TRY(c, hipMemcpy2D(out_rgba8, stride, c->buf[VELLO_HIP_BUF_OUTPUT].ptr, row, row, params->height, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy2D(out_rgba8, stride, c->lanes[c->last_lane].buf[VELLO_HIP_BUF_OUTPUT].ptr, row, row, params->height,
+                               hipMemcpyDeviceToHost));
     }
     return VELLO_HIP_OK;
 }
 
 size_t vello_hip_buffer_size(vello_hip_ctx *c, int id) {
     if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT) return 0;
-    return c->buf[id].size;
+    return find_buf(c, id)->size;
 }
 
 int vello_hip_read_buffer(vello_hip_ctx *c, int id, void *dst, size_t offset, size_t size) {
     if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT || !dst) return VELLO_HIP_E_INVALID;
-    if (!c->buf[id].ptr || offset + size > c->buf[id].size) {
+    DevBuf *b = find_buf(c, id);
+    if (!b->ptr || offset + size > b->size) {
         c->last_error = "read_buffer out of range";
         return VELLO_HIP_E_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(dst, (const char *)c->buf[id].ptr + offset, size, hipMemcpyDeviceToHost));
+    int r = sync_all(c);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(dst, (const char *)b->ptr + offset, size, hipMemcpyDeviceToHost));
     return VELLO_HIP_OK;
 }
 
 int vello_hip_write_buffer(vello_hip_ctx *c, int id, const void *src, size_t offset, size_t size) {
     if (!c || id < 0 || id >= VELLO_HIP_BUF_COUNT || !src) return VELLO_HIP_E_INVALID;
-    if (!c->buf[id].ptr || offset + size > c->buf[id].size) {
+    DevBuf *b = find_buf(c, id);
+    if (!b->ptr || offset + size > b->size) {
         c->last_error = "write_buffer out of range";
         return VELLO_HIP_E_INVALID;
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy((char *)c->buf[id].ptr + offset, src, size, hipMemcpyHostToDevice));
+    int r = sync_all(c);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy((char *)b->ptr + offset, src, size, hipMemcpyHostToDevice));
     return VELLO_HIP_OK;
 }
 

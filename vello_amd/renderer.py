@@ -144,6 +144,12 @@ class Engine:
             self._check(r, "render")
         return out, b.as_dict()
 
+    def set_frames_in_flight(self, n):
+        self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
+
+    def sync_frame(self, age=0):
+        self._check(self._lib.vello_hip_sync_frame(self._h, age), "sync_frame")
+
     def sync(self):
         return self._lib.vello_hip_sync(self._h)
 
