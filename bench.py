@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="frames the engine keeps in flight (wgpu queues recordings the same way); 1 = serial frames")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="skip the serial / PCIe / CPU passes (for rocprofv3 runs: every launch it sees is then a "
+                         "warm-up or timed-region launch)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -159,14 +162,14 @@ def main():
 
     # serial-frame passes (separate, not part of `value`): one frame at a time gives the frame latency and
     # the isolated per-kernel durations (no other frame's kernels sharing the CUs)
-    n_serial = min(args.steps, 50)
+    n_serial = 0 if args.timed_only else min(args.steps, 50)
     engine.set_profiling([])
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(n_serial):
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
         engine.sync_frame(0)
-    serial_ms = (time.perf_counter() - t1) / n_serial * 1e3
+    serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
     engine.set_profiling(vello_amd.renderer.STAGES)
     for _ in range(n_serial):
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
@@ -176,7 +179,7 @@ def main():
     engine.set_profiling([])
 
     # PCIe-inclusive rate (never `value`): host scene bytes -> H2D -> full frame, one frame in flight
-    n_pcie = 20
+    n_pcie = 0 if args.timed_only else 20
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(n_pcie):
@@ -184,6 +187,9 @@ def main():
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
         engine.sync()
     pcie_fps = n_pcie / (time.perf_counter() - t1)
+    if args.timed_only:
+        all_ms = {k: (0.0, 0) for k in vello_amd.renderer.STAGES}
+        all_ms[dominant] = (dom_ms, dom_n)
 
     if rank != 0:
         if distributed:
@@ -197,6 +203,15 @@ def main():
     frame_bytes = sum(sb.values())
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.steps / elapsed
+
+    # HBM traffic of the dominant kernel from the PMC passes (collected separately, as the pool requires, by
+    # scripts/gpu_calib.sh; corrected with the factors calibrated in the same session)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            traffic = json.load(fh)["kernels"].get(f"k_{dominant}", {}).get("traffic_bytes")
+    except (OSError, ValueError):
+        pass
 
     result = {
         "metric": "frames/sec paris-30k 1600x1600 MSAA16; scenes/sec at 1/2/4/8 GPU",
@@ -230,7 +245,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
             "algorithmic_bytes_per_launch": int(sb[dominant]),
             "avg_launch_ms": round(dom_avg_s * 1e3, 5),
             "avg_launch_ms_isolated": round(all_ms[dominant][0] / max(all_ms[dominant][1], 1), 5),
@@ -241,7 +257,7 @@ def main():
         },
     }
 
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.timed_only:
         from oracle.oracle import Oracle
 
         o = Oracle()

@@ -13,7 +13,7 @@ for r in rows:
     acc[k][c] += v
     cnt[k][c] += 1
 for k in sorted(acc):
-    if not k.startswith(("vk::", "void vk::")):
+    if not k.startswith(("vk::", "void vk::", "calib_")):
         continue
     print(k)
     for c in sorted(acc[k]):
