@@ -17,6 +17,8 @@
  *   vello_hip_upload_scene     Command::Upload("vello.scene") +          vello/src/render.rs:229-232,
  *                              Command::UploadUniform("vello.config")    vello/src/recording.rs:124-140
  *   vello_hip_render_resident  the Dispatch/DispatchIndirect chain       vello/src/render.rs:250-502, :560-629
+ *   vello_hip_resize_image_atlas  ImageProxy::new(atlas_width, atlas_height)  vello/src/render.rs:160-176
+ *   vello_hip_write_image      Recording::write_image(image_atlas, x, y, ..) vello/src/render.rs:201-203
  *   vello_hip_sync             queue.submit + device.poll                vello/src/wgpu_engine.rs:757
  *   vello_hip_set_frames_in_flight  back-to-back queue.submit without waiting  vello/src/wgpu_engine.rs:757
  *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
@@ -141,6 +143,15 @@ int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scen
 /* ... then each call enqueues one full frame (all stages) on the context's stream and returns
  * without waiting.  `out_device` may be NULL (render into the internal target only). */
 int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
+/* The image atlas: one RGBA8 texture that persists across frames (render.rs:160-176).  The Resolver owns
+ * the packing: it patches every DrawImage's atlas xy (resolve.rs:300-316) and lists the images to (re)write.
+ * resize discards the contents (zero-filled), as creating a new ImageProxy does.  Texel bytes are stored
+ * verbatim; BGRA / straight-alpha images are normalised while sampling (fine.wgsl:829-858).
+ * Both calls wait for the frames in flight. */
+int vello_hip_resize_image_atlas(vello_hip_ctx *ctx, uint32_t width, uint32_t height);
+int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const uint8_t *rgba8,
+                          size_t stride /* bytes per source row; 0 = width*4 */);
+
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting
  * (wgpu_engine.rs:757); with n > 1 consecutive vello_hip_render_resident calls rotate over n private buffer
  * sets and streams and overlap on the GPU.  The caller must hand each in-flight frame its own target. */

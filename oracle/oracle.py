@@ -36,6 +36,7 @@ def _lib():
         lib.vo_set_scene.restype = i32
         lib.vo_set_scene.argtypes = [vp, vp, sz, vp, u32, u32, u32, i32]
         lib.vo_set_ramps.argtypes = [vp, vp, u32]
+        lib.vo_set_image_atlas.argtypes = [vp, vp, u32, u32]
         lib.vo_get_config.restype = vp
         lib.vo_get_config.argtypes = [vp]
         lib.vo_run.restype = i32
@@ -87,6 +88,22 @@ class Oracle:
         if r != 0:
             raise RuntimeError("vo_set_scene failed")
         self.width, self.height = width, height
+
+    def set_ramps(self, ramps):
+        """Gradient ramp texture: n_ramps x 512 RGBA8 texels as uint32 (ramp_cache.rs), or None."""
+        if ramps is None or len(ramps) == 0:
+            self._lib.vo_set_ramps(self._h, None, 0)
+            return
+        ramps = np.ascontiguousarray(ramps, dtype=np.uint32)
+        self._lib.vo_set_ramps(self._h, ramps.ctypes.data, ramps.size // 512)
+
+    def set_image_atlas(self, atlas):
+        """Image atlas as an HxWx4 uint8 array (render.rs:160-203), or None."""
+        if atlas is None:
+            self._lib.vo_set_image_atlas(self._h, None, 0, 0)
+            return
+        atlas = np.ascontiguousarray(atlas, dtype=np.uint8)
+        self._lib.vo_set_image_atlas(self._h, atlas.ctypes.data, atlas.shape[1], atlas.shape[0])
 
     def config(self):
         p = self._lib.vo_get_config(self._h)

@@ -104,6 +104,10 @@ int vo_set_scene(vo_ctx *, const uint8_t *scene, size_t scene_len,
 /* Optional gradient ramp texture (ramp_cache.rs: 512 RGBA8 texels per ramp). */
 int vo_set_ramps(vo_ctx *, const uint32_t *ramps, uint32_t n_ramps);
 
+/* Optional image atlas (render.rs:160-203: one Rgba8Unorm texture, images written at the xy the Resolver
+ * patched into DrawImage).  `rgba8` holds width*height texels, row-major, 4 bytes each; copied. */
+int vo_set_image_atlas(vo_ctx *, const uint8_t *rgba8, uint32_t width, uint32_t height);
+
 const vo_config *vo_get_config(const vo_ctx *);
 
 /* Runs stages first..last (inclusive).  Stage VO_STAGE_PATHTAG_SCAN also

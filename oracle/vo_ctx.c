@@ -22,6 +22,7 @@ void vo_destroy(vo_ctx *c) {
     for (int i = 0; i < VO_BUF_COUNT; i++) free(c->buf[i]);
     free(c->scene);
     free(c->ramps);
+    free(c->atlas);
     free(c);
 }
 
@@ -95,6 +96,19 @@ int vo_set_scene(vo_ctx *c, const uint8_t *scene, size_t scene_len, const vo_lay
     e |= ensure(c, VO_BUF_BLEND_SPILL, (size_t)blend * 4u);
     e |= ensure(c, VO_BUF_OUTPUT, (size_t)width * height * 4u);
     return e;
+}
+
+int vo_set_image_atlas(vo_ctx *c, const uint8_t *rgba8, uint32_t width, uint32_t height) {
+    free(c->atlas);
+    c->atlas = NULL;
+    c->atlas_w = c->atlas_h = 0;
+    if (!rgba8 || !width || !height) return 0;
+    c->atlas = (uint32_t *)malloc((size_t)width * height * 4u);
+    if (!c->atlas) return -1;
+    memcpy(c->atlas, rgba8, (size_t)width * height * 4u);
+    c->atlas_w = width;
+    c->atlas_h = height;
+    return 0;
 }
 
 int vo_set_ramps(vo_ctx *c, const uint32_t *ramps, uint32_t n_ramps) {

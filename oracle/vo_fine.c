@@ -504,6 +504,60 @@ static void src_over(vec4 *rgba, vec4 fg, float area) {
     for (int k = 0; k < 4; k++) rgba->v[k] = rgba->v[k] * (1.0f - fa) + fg.v[k] * area;
 }
 
+/* ---------------- images: fine.wgsl:804-993 ---------------- */
+/* textureLoad(image_atlas, vec2<i32>(uv), 0): out-of-range loads return transparent black */
+static vec4 atlas_load(const vo_ctx *c, float u, float v, uint32_t alpha_type) {
+    vec4 z = {{0, 0, 0, 0}};
+    int32_t x = f2i(truncf(u)), y = f2i(truncf(v));
+    if (!c->atlas || x < 0 || y < 0 || (uint32_t)x >= c->atlas_w || (uint32_t)y >= c->atlas_h) return z;
+    vec4 p = unpack4x8unorm(c->atlas[(size_t)y * c->atlas_w + (uint32_t)x]);
+    if (alpha_type == 0u) { /* maybe_premul_alpha, fine.wgsl:847-858 */
+        p.v[0] *= p.v[3]; p.v[1] *= p.v[3]; p.v[2] *= p.v[3];
+    }
+    return p;
+}
+static float extend_mode_px(float t, uint32_t mode, float max) { /* fine.wgsl:877-889 */
+    if (mode == 0u) return vo_clamp(t, 0.0f, max);
+    return extend_mode_normalized(t / max, mode) * max;
+}
+static float single_weight(float t, float a, float b, float c, float d) { return t * (t * (t * d + c) + b) + a; }
+static void cubic_weights(float fr, float w[4]) { /* fine.wgsl:893-931, Mitchell B = C = 1/3 */
+    static const float MF[4][4] = {
+        {(1.0f / 6.0f) / 3.0f, -(3.0f / 6.0f) / 3.0f - 1.0f / 3.0f, (3.0f / 6.0f) / 3.0f + 2.0f * 1.0f / 3.0f, -(1.0f / 6.0f) / 3.0f - 1.0f / 3.0f},
+        {1.0f - (2.0f / 6.0f) / 3.0f, 0.0f, -3.0f + (12.0f / 6.0f) / 3.0f + 1.0f / 3.0f, 2.0f - (9.0f / 6.0f) / 3.0f - 1.0f / 3.0f},
+        {(1.0f / 6.0f) / 3.0f, (3.0f / 6.0f) / 3.0f + 1.0f / 3.0f, 3.0f - (15.0f / 6.0f) / 3.0f - 2.0f * 1.0f / 3.0f, -2.0f + (9.0f / 6.0f) / 3.0f + 1.0f / 3.0f},
+        {0.0f, 0.0f, -1.0f / 3.0f, (1.0f / 6.0f) / 3.0f + 1.0f / 3.0f}};
+    for (int k = 0; k < 4; k++) w[k] = single_weight(fr, MF[k][0], MF[k][1], MF[k][2], MF[k][3]);
+}
+static vec4 bicubic_sample(const vo_ctx *c, float cx_, float cy_, float ox, float oy, float mx, float my, uint32_t alpha_type) {
+    float fx = (cx_ + 0.5f) - floorf(cx_ + 0.5f), fy = (cy_ + 0.5f) - floorf(cy_ + 0.5f);
+    float wx[4], wy[4];
+    cubic_weights(fx, wx);
+    cubic_weights(fy, wy);
+    static const float off[4] = {-1.5f, -0.5f, 0.5f, 1.5f};
+    vec4 res = {{0, 0, 0, 0}};
+    vec4 rows[4];
+    for (int j = 0; j < 4; j++) {
+        vec4 s[4];
+        for (int i = 0; i < 4; i++)
+            s[i] = atlas_load(c, vo_clamp(cx_ + off[i], ox, mx), vo_clamp(cy_ + off[j], oy, my), alpha_type);
+        for (int k = 0; k < 4; k++) rows[j].v[k] = wx[0] * s[0].v[k] + wx[1] * s[1].v[k] + wx[2] * s[2].v[k] + wx[3] * s[3].v[k];
+    }
+    for (int k = 0; k < 4; k++) res.v[k] = wy[0] * rows[0].v[k] + wy[1] * rows[1].v[k] + wy[2] * rows[2].v[k] + wy[3] * rows[3].v[k];
+    float a = vo_clamp(res.v[3], 0.0f, 1.0f);
+    for (int k = 0; k < 3; k++) res.v[k] = vo_clamp(res.v[k], 0.0f, a);
+    res.v[3] = a;
+    return res;
+}
+/* fine.wgsl:715-726 */
+static float erf7(float x) {
+    float y = vo_clamp(x * 1.1283791671f, -100.0f, 100.0f);
+    float yy = y * y;
+    float z = y + (0.24295f + (0.03395f + 0.0104f * yy) * yy) * (y * yy);
+    return z / sqrtf(1.0f + z * z);
+}
+static float hypot_wgsl(float a, float b) { return sqrtf(a * a + b * b); }
+
 /* ---------------- tile interpreter: fine.wgsl:1064-1398 ---------------- */
 static void fine_tile(const vo_ctx *c, fine_shared *sh, uint32_t tile_x, uint32_t tile_y) {
     const vo_config *cfg = &c->cfg;
@@ -687,8 +741,87 @@ static void fine_tile(const vo_ctx *c, fine_shared *sh, uint32_t tile_x, uint32_
             cmd_ix += 3u;
             break;
         }
-        case CMD_IMAGE: cmd_ix += 2u; break;     /* images: out of scope */
-        case CMD_BLUR_RECT: cmd_ix += 3u; break; /* blurred rrect: out of scope */
+        case CMD_IMAGE: { /* fine.wgsl:804-827 (read_image), :1315-1382 */
+            uint32_t io = ptcl[cmd_ix + 1u];
+            float m0 = bits2f(info[io]), m1 = bits2f(info[io + 1u]), m2 = bits2f(info[io + 2u]), m3 = bits2f(info[io + 3u]);
+            float xl0 = bits2f(info[io + 4u]), xl1 = bits2f(info[io + 5u]);
+            uint32_t xy = info[io + 6u], width_height = info[io + 7u], sample_alpha = info[io + 8u];
+            float alpha = (float)(sample_alpha & 0xFFu) / 255.0f;
+            uint32_t format = sample_alpha >> 15, alpha_type = (sample_alpha >> 14) & 1u, quality = (sample_alpha >> 12) & 3u;
+            uint32_t x_extend = (sample_alpha >> 10) & 3u, y_extend = (sample_alpha >> 8) & 3u;
+            float ox = (float)(xy >> 16), oy = (float)(xy & 0xffffu);
+            float ew = (float)(width_height >> 16), eh = (float)(width_height & 0xffffu);
+            float amx = ox + ew - 1.0f, amy = oy + eh - 1.0f;
+            for (uint32_t i = 0; i < 256; i++) {
+                if (area[i] == 0.0f) continue;
+                float px = (float)(tile_x * TILE_WIDTH + (i & 15u)) + 0.5f;
+                float py = (float)(tile_y * TILE_HEIGHT + (i >> 4)) + 0.5f;
+                float u = m0 * px + m2 * py + xl0;
+                float v = m1 * px + m3 * py + xl1;
+                u = extend_mode_px(u, x_extend, ew);
+                v = extend_mode_px(v, y_extend, eh);
+                vec4 fg;
+                if (quality == 0u) {
+                    u += ox; v += oy;
+                    fg = atlas_load(c, vo_clamp(u, ox, amx), vo_clamp(v, oy, amy), alpha_type);
+                } else if (quality == 2u) {
+                    u += ox; v += oy;
+                    fg = bicubic_sample(c, u, v, ox, oy, amx, amy, alpha_type);
+                } else {
+                    u = u + ox - 0.5f; v = v + oy - 0.5f;
+                    float uc = vo_clamp(u, ox, amx), vc = vo_clamp(v, oy, amy);
+                    float x0 = floorf(uc), y0 = floorf(vc), x1 = ceilf(uc), y1 = ceilf(vc);
+                    float frx = u - floorf(u), fry = v - floorf(v);
+                    vec4 a = atlas_load(c, x0, y0, alpha_type), b = atlas_load(c, x0, y1, alpha_type);
+                    vec4 cc = atlas_load(c, x1, y0, alpha_type), d = atlas_load(c, x1, y1, alpha_type);
+                    for (int k = 0; k < 4; k++) fg.v[k] = mixf(mixf(a.v[k], b.v[k], fry), mixf(cc.v[k], d.v[k], fry), frx);
+                }
+                vec4 fg_i;
+                for (int k = 0; k < 4; k++) fg_i.v[k] = fg.v[k] * area[i] * alpha;
+                if (format == 1u) { float t = fg_i.v[0]; fg_i.v[0] = fg_i.v[2]; fg_i.v[2] = t; } /* pixel_format: .bgra */
+                for (int k = 0; k < 4; k++) rgba[i].v[k] = rgba[i].v[k] * (1.0f - fg_i.v[3]) + fg_i.v[k];
+            }
+            cmd_ix += 2u;
+            break;
+        }
+        case CMD_BLUR_RECT: { /* fine.wgsl:740-756 (read_blur_rect), :1173-1224 */
+            uint32_t io = ptcl[cmd_ix + 1u];
+            vec4 blur_rgba = unpack4x8unorm(ptcl[cmd_ix + 2u]);
+            float m0 = bits2f(info[io]), m1 = bits2f(info[io + 1u]), m2 = bits2f(info[io + 2u]), m3 = bits2f(info[io + 3u]);
+            float xl0 = bits2f(info[io + 4u]), xl1 = bits2f(info[io + 5u]);
+            float bw = bits2f(info[io + 6u]), bh = bits2f(info[io + 7u]), bradius = bits2f(info[io + 8u]), bstd = bits2f(info[io + 9u]);
+            float std_dev = vo_max(bstd, 1e-5f);
+            float inv_std_dev = 1.0f / std_dev;
+            float min_edge = vo_min(bw, bh);
+            float radius_max = 0.5f * min_edge;
+            float r0 = vo_min(hypot_wgsl(bradius, std_dev * 1.15f), radius_max);
+            float r1 = vo_min(hypot_wgsl(bradius, std_dev * 2.0f), radius_max);
+            float exponent = 2.0f * r1 / r0;
+            float inv_exponent = 1.0f / exponent;
+            float delta = 1.25f * std_dev * (vo_expf(-vo_powf(0.5f * inv_std_dev * bw, 2.0f)) - vo_expf(-vo_powf(0.5f * inv_std_dev * bh, 2.0f)));
+            float width = bw + vo_min(delta, 0.0f);
+            float height = bh - vo_max(delta, 0.0f);
+            float scale = 0.5f * erf7(inv_std_dev * 0.5f * (vo_max(width, height) - 0.5f * bradius));
+            for (uint32_t i = 0; i < 256; i++) {
+                float px = (float)(tile_x * TILE_WIDTH + (i & 15u));
+                float py = (float)(tile_y * TILE_HEIGHT + (i >> 4));
+                float x = m0 * px + m2 * py + xl0;
+                float y = m1 * px + m3 * py + xl1;
+                float y0 = fabsf(y) - (height * 0.5f - r1);
+                float y1 = vo_max(y0, 0.0f);
+                float x0 = fabsf(x) - (width * 0.5f - r1);
+                float x1 = vo_max(x0, 0.0f);
+                float d_pos = vo_powf(vo_powf(x1, exponent) + vo_powf(y1, exponent), inv_exponent);
+                float d_neg = vo_min(vo_max(x0, y0), 0.0f);
+                float d = d_pos + d_neg - r1;
+                float alpha = scale * (erf7(inv_std_dev * (min_edge + d)) - erf7(inv_std_dev * d));
+                vec4 fg;
+                for (int k = 0; k < 4; k++) fg.v[k] = blur_rgba.v[k] * alpha;
+                src_over(&rgba[i], fg, area[i]);
+            }
+            cmd_ix += 3u;
+            break;
+        }
         default: cmd_ix += 1u; break;
         }
     }

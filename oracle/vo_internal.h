@@ -117,6 +117,8 @@ struct vo_ctx {
     uint32_t n_tag_words; /* padded tag bytes / 4 */
     uint32_t n_ramps;
     uint32_t *ramps;
+    uint32_t atlas_w, atlas_h;
+    uint32_t *atlas;
     void *buf[VO_BUF_COUNT];
     size_t buf_size[VO_BUF_COUNT];
     uint8_t mask_lut8[1024];
@@ -136,6 +138,7 @@ static inline float vo_atan2f(float y, float x) { return (float)atan2((double)y,
 static inline float vo_asinf(float x) { return (float)asin((double)x); }
 static inline float vo_acosf(float x) { return (float)acos((double)x); }
 static inline float vo_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+static inline float vo_expf(float x) { return (float)exp((double)x); }
 
 static inline uint32_t f2bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float bits2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }

@@ -23,14 +23,24 @@ def sorted_rows(a, ncol):
     return a[order]
 
 
-def compare_frame(engine, packed, layout, width, height, base_color, aa, name, tol=0, check_stages=True, oracle=None):
+def compare_frame(engine, packed, layout, width, height, base_color, aa, name, tol=0, check_stages=True, oracle=None,
+                  resolved=None):
     """Renders with both, asserts bump counters, intermediates (up to documented permutations) and the
     final RGBA8 image agree.  tol is the per-channel tolerance on the image (0 for MSAA: integer coverage;
     <=1 for area AA where segment order changes f32 summation order)."""
     oracle = oracle or Oracle()
     oracle.set_scene(packed, layout, width, height, base_color, int(aa))
+    ramps = None
+    if resolved is not None:  # late-bound resources: gradient ramps + image atlas (vello_amd.Resolver)
+        ramps = resolved.ramps
+        oracle.set_ramps(ramps)
+        oracle.set_image_atlas(resolved.atlas_image())
+        if resolved.atlas_size:
+            engine.resize_image_atlas(resolved.atlas_size, resolved.atlas_size)
+            for x, y, px in resolved.uploads:
+                engine.write_image(x, y, px)
     ref = oracle.render()
-    img, bump = engine.render(packed, layout, width, height, base_color, aa)
+    img, bump = engine.render(packed, layout, width, height, base_color, aa, ramps=ramps)
     ob = oracle.bump()
     # Occlusion culling in coarse (scenes without clips) skips draws hidden under an opaque full-tile cover:
     # the segment / PTCL demand can only shrink; every other counter must match exactly.

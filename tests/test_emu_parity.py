@@ -91,3 +91,15 @@ def test_emu_frames_in_flight_rotate_lanes(built):
             eng.sync_frame(3)
     finally:
         L._use_library(None)
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
+def test_emu_gradient_image_blur_brushes(emu_engine, aa):
+    # late-bound resources end to end: Resolver (ramps, atlas placement, draw-data patches) -> draw_leaf info ->
+    # coarse commands -> fine's gradient / image / blurred-rounded-rect arms
+    import vello_amd
+
+    r = vello_amd.Resolver().resolve(workloads.brushes_scene())
+    assert r.ramps is not None and r.atlas_size == 1024 and len(r.uploads) == 3
+    compare_frame(emu_engine, r.packed, r.layout, 256, 256, WHITE, aa, f"emu_brushes_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                  resolved=r)

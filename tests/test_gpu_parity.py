@@ -202,3 +202,26 @@ def test_frames_in_flight_match_oracle(built):
     for (w, h, base, aa), t in zip(variants, targets):
         o.set_scene(packed, layout, w, h, base, int(aa))
         assert np.array_equal(o.render(), t.cpu().numpy())
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16])
+def test_gradient_image_blur_brushes(gpu_engine, aa):
+    # gradients (all kinds x extend modes), images (3 qualities, extend modes, BGRA, premultiplied)
+    # and blurred rounded rects; exp/pow in the blur follow the fp64-rounded-once rule on both sides
+    import vello_amd
+
+    r = vello_amd.Resolver().resolve(workloads.brushes_scene())
+    compare_frame(gpu_engine, r.packed, r.layout, 256, 256, WHITE, aa, f"gpu_brushes_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                  resolved=r)
+
+
+def test_brushes_at_scale(gpu_engine):
+    # the same brushes under a 3x zoom and rotation: larger sampled areas, bicubic / bilinear minification paths
+    import vello_amd
+    from vello_amd import Affine, Scene
+
+    base = workloads.brushes_scene()
+    s = Scene()
+    s.append(base, Affine.translate(60, -40) * Affine.rotate(0.15) * Affine.scale(3.0))
+    r = vello_amd.Resolver().resolve(s)
+    compare_frame(gpu_engine, r.packed, r.layout, 800, 800, BLACK, AaConfig.Msaa16, "gpu_brushes_zoom", resolved=r)

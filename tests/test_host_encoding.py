@@ -103,3 +103,109 @@ def test_append_premultiplies_transforms(built):
     outer = Scene()
     outer.append(inner, Affine.scale(2.0))
     assert list(outer.stream("transforms")) == [2, 0, 0, 2, 2, 4]
+
+
+def test_brush_enum_values_match_the_shader_constants(built):
+    # vello_encoding/src/encoding.rs:622-642 (ensure_image_quality_values / ensure_extend_values)
+    from vello_amd import Extend, ImageQuality, ImageFormat, ImageAlphaType
+
+    assert (int(ImageQuality.Low), int(ImageQuality.Medium), int(ImageQuality.High)) == (0, 1, 2)
+    assert (int(Extend.Pad), int(Extend.Repeat), int(Extend.Reflect)) == (0, 1, 2)
+    assert (int(ImageFormat.Rgba8), int(ImageFormat.Bgra8)) == (0, 1)          # fine.wgsl:829-830
+    assert (int(ImageAlphaType.Alpha), int(ImageAlphaType.AlphaPremultiplied)) == (0, 1)  # fine.wgsl:845-846
+
+
+def test_gradient_encoding_and_ramp_known_answers(built):
+    # encode_linear_gradient -> DrawTag::LINEAR_GRADIENT + 5 words, index patched to (ramp_id << 2) | extend
+    # (encoding.rs:352-372, resolve.rs:284-296); ramp texels per ramp_cache.rs:119-155
+    from vello_amd import Gradient, Extend, Resolver, Rect
+
+    s = Scene()
+    red, blue = Color.from_rgb8(255, 0, 0), Color.from_rgb8(0, 0, 255)
+    g = Gradient.new_linear((1, 2), (3, 4)).with_stops([red, blue]).with_extend(Extend.Reflect)
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(0, 0, 10, 10))
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(5, 5, 20, 20))          # same stops: same ramp
+    half = Gradient.new_linear((0, 0), (1, 0)).with_stops([(0.0, red), (1.0, Color.from_rgba8(0, 0, 255, 0))])
+    s.fill(Fill.NonZero, Affine.IDENTITY, half, None, Rect(0, 0, 4, 4))
+    assert list(s.stream("draw_tags")) == [0x114, 0x114, 0x114]
+    dd = s.stream("draw_data")
+    assert dd.size == 15 and list(dd[1:5].view(np.float32)) == [1, 2, 3, 4]
+    r = Resolver().resolve(s)
+    words = r.packed.view(np.uint32)
+    base = r.layout.draw_data_base
+    assert words[base] == (0 << 2) | 2 and words[base + 5] == (0 << 2) | 2 and words[base + 10] == (1 << 2) | 0
+    assert r.layout.bin_data_start == 3 * 4                                       # info_size of LINEAR_GRADIENT
+    ramps = r.ramps.reshape(-1, 512)
+    assert ramps.shape[0] == 2
+    assert ramps[0, 0] == 0xFF0000FF and ramps[0, 511] == 0xFFFF0000               # RGBA8, R in the low byte
+    mid = ramps[0, 256]
+    assert abs((mid & 0xFF) - 127) <= 1 and abs(((mid >> 16) & 0xFF) - 128) <= 1 and (mid >> 24) == 0xFF
+    # premultiplied-space interpolation towards a transparent stop: texels are premultiplied, alpha falls linearly
+    assert ramps[1, 511] == 0 and abs((ramps[1, 256] >> 24) - 127) <= 1
+    a = (ramps[1] >> 24).astype(int)
+    assert np.all(np.diff(a) <= 0) and np.all((ramps[1] & 0xFF) <= (ramps[1] >> 24))
+
+
+def test_degenerate_gradients_fall_back_to_colours(built):
+    # encoding.rs:360-364 (no / one stop), :396-401 (radial with equal circles), :432-436 (empty sweep)
+    from vello_amd import Gradient, Rect
+
+    s = Scene()
+    c = Color.from_rgb8(9, 8, 7)
+    shape = Rect(0, 0, 4, 4)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_linear((0, 0), (1, 1)).with_stops([]), None, shape)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_linear((0, 0), (1, 1)).with_stops([c]), None, shape)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_two_point_radial((1, 1), 2.0, (1, 1), 2.0).with_stops([c, c]), None, shape)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_sweep((1, 1), 1.0, 1.0).with_stops([c, c]), None, shape)
+    assert list(s.stream("draw_tags")) == [0x44] * 4
+    assert list(s.stream("draw_data")) == [0, 0xFF070809, 0, 0]
+
+
+def test_image_and_blur_rect_draw_data(built):
+    # encode_image (encoding.rs:440-470): xy patched by the Resolver, width_height and the packed sampler word;
+    # encode_blurred_rounded_rect (:473-491); the brush transform precedes the PATH marker (scene.rs:296-300)
+    from vello_amd import ImageData, ImageBrush, ImageFormat, ImageAlphaType, ImageQuality, Extend, Resolver
+
+    s = Scene()
+    px = np.zeros((5, 7, 4), dtype=np.uint8)
+    im = ImageData(px, ImageFormat.Bgra8, ImageAlphaType.AlphaPremultiplied)
+    s.draw_image(ImageBrush(im, Extend.Repeat, Extend.Reflect, ImageQuality.High, 0.5), Affine.IDENTITY)
+    s.draw_image(ImageBrush(im), Affine.translate(10, 0))                         # same blob: one atlas slot
+    s.draw_blurred_rounded_rect(Affine.IDENTITY, (10, 20, 30, 60), Color.from_rgb8(1, 2, 3), 4.0, 2.0)
+    assert list(s.stream("draw_tags")) == [0x28C, 0x28C, 0x2D4]
+    dd = s.stream("draw_data")
+    assert dd[1] == (7 << 16) | 5
+    assert dd[2] == (1 << 15) | (1 << 14) | (2 << 12) | (1 << 10) | (2 << 8) | 128   # (0.5 * 255).round() = 128
+    assert dd[5] == (1 << 15) | (1 << 14) | (1 << 12) | 255                           # defaults: Pad, Pad, Medium, alpha 1
+    assert dd[6] == 0xFF030201 and list(dd[7:11].view(np.float32)) == [20.0, 40.0, 4.0, 2.0]
+    tags = list(s.stream("path_tags"))
+    assert tags[-2:] == [0x20, 0x10]                                               # TRANSFORM swapped before PATH
+    assert list(s.stream("transforms"))[-6:] == [1, 0, 0, 1, 20, 40]               # translate(rect.center())
+    res = Resolver()
+    r = res.resolve(s)
+    assert r.atlas_size == 1024 and r.atlas_resized and r.new_uploads == 1
+    words = r.packed.view(np.uint32)
+    base = r.layout.draw_data_base
+    assert words[base] == words[base + 3] == 0                                      # both images at atlas (0, 0)
+    # image_cache.rs:236-250: resident entries are reused (no new upload) by the next resolve
+    r2 = res.resolve(s)
+    assert r2.new_uploads == 0 and not r2.atlas_resized and np.array_equal(r2.packed, r.packed)
+
+
+def test_append_moves_resource_patches(built):
+    # encoding.rs:95-152: patch offsets and stop ranges shift by the parent's stream lengths
+    from vello_amd import Gradient, Rect, Resolver
+
+    inner = Scene()
+    g = Gradient.new_linear((0, 0), (8, 0)).with_stops([Color.from_rgb8(0, 0, 0), Color.from_rgb8(255, 255, 255)])
+    inner.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(0, 0, 8, 8))
+    outer = Scene()
+    outer.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(1, 1, 1), None, Rect(0, 0, 2, 2))
+    g2 = Gradient.new_linear((0, 0), (8, 0)).with_stops([Color.from_rgb8(255, 0, 0), Color.from_rgb8(0, 255, 0)])
+    outer.fill(Fill.NonZero, Affine.IDENTITY, g2, None, Rect(0, 0, 2, 2))
+    outer.append(inner, Affine.scale(2.0))
+    r = Resolver().resolve(outer)
+    words = r.packed.view(np.uint32)
+    base = r.layout.draw_data_base
+    assert words[base] == 0xFF010101 and words[base + 1] == (0 << 2) and words[base + 6] == (1 << 2)
+    assert r.ramps.reshape(-1, 512)[1, 511] == 0xFFFFFFFF

@@ -9,11 +9,13 @@ There is no CPU fallback: importing works without a GPU (so CPU tests can check 
 """
 from ._lib import load_library, library_path, VelloHipError
 from .kurbo import Affine, BezPath, Circle, Rect, RoundedRect, Line, Stroke, Join, Cap
-from .scene import Scene, Fill, Color, BlendMode, Mix, Compose
+from .scene import (Scene, Fill, Color, BlendMode, Mix, Compose, Gradient, Extend, InterpolationAlphaSpace, ImageData, ImageBrush,
+                    ImageFormat, ImageAlphaType, ImageQuality, Resolver, Resolved)
 from .renderer import Renderer, RenderParams, AaConfig, RendererOptions, Engine, Layout
 
 __all__ = [
     "load_library", "library_path", "VelloHipError", "Affine", "BezPath", "Circle", "Rect", "RoundedRect", "Line",
     "Stroke", "Join", "Cap", "Scene", "Fill", "Color", "BlendMode", "Mix", "Compose", "Renderer", "RenderParams",
-    "AaConfig", "RendererOptions", "Engine", "Layout",
+    "AaConfig", "RendererOptions", "Engine", "Layout", "Gradient", "Extend", "InterpolationAlphaSpace", "ImageData", "ImageBrush",
+    "ImageFormat", "ImageAlphaType", "ImageQuality", "Resolver", "Resolved",
 ]

@@ -75,6 +75,8 @@ def load_library():
     sig("vello_hip_upload_scene", i32, [vp, vp, sz, c.POINTER(LayoutStruct), vp, u32])
     sig("vello_hip_render_resident", i32, [vp, c.POINTER(RenderParamsStruct), vp, sz])
     sig("vello_hip_set_frames_in_flight", i32, [vp, u32])
+    sig("vello_hip_resize_image_atlas", i32, [vp, u32, u32])
+    sig("vello_hip_write_image", i32, [vp, u32, u32, u32, u32, vp, sz])
     sig("vello_hip_sync_frame", i32, [vp, u32])
     sig("vello_hip_sync", i32, [vp])
     sig("vello_hip_get_bump", i32, [vp, c.POINTER(Bump)])
@@ -111,6 +113,20 @@ def load_library():
     sig("vh_scene_push_clip_layer", None, [vp, i32, dp, vp, vp, sz])
     sig("vh_scene_pop_layer", None, [vp])
     sig("vh_scene_append", None, [vp, vp, dp])
+    sig("vh_brush_solid", vp, [fp])
+    sig("vh_brush_gradient", vp, [i32, dp, u32, u32, fp, sz])
+    sig("vh_brush_image", vp, [c.c_uint64, u32, u32, u32, u32, vp, u32, u32, u32, c.c_float])
+    sig("vh_brush_free", None, [vp])
+    sig("vh_scene_fill_brush", None, [vp, i32, dp, vp, dp, vp, vp, sz])
+    sig("vh_scene_stroke_brush", i32, [vp, c.c_double, i32, c.c_double, i32, i32, dp, vp, dp, vp, vp, sz])
+    sig("vh_scene_draw_blurred_rounded_rect", None, [vp, dp, dp, fp, c.c_double, c.c_double])
+    sig("vh_scene_draw_blurred_rounded_rect_in", None, [vp, vp, vp, sz, dp, dp, fp, c.c_double, c.c_double])
+    sig("vh_scene_draw_image", None, [vp, vp, dp])
+    sig("vh_scene_n_patches", sz, [vp])
+    sig("vh_resolver_new", vp, [])
+    sig("vh_resolver_free", None, [vp])
+    sig("vh_resolver_resolve", sz, [vp, vp, c.POINTER(vp), c.POINTER(u32), c.POINTER(vp), c.POINTER(u32)])
+    sig("vh_resolver_upload", vp, [vp, u32, c.POINTER(u32)])
     sig("vh_scene_stream_bytes", sz, [vp, i32])
     sig("vh_scene_stream_copy", None, [vp, i32, vp])
     sig("vh_scene_counts", None, [vp, c.POINTER(u32)])

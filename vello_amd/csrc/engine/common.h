@@ -106,6 +106,7 @@ __device__ __forceinline__ float atan2_cr(float y, float x) {
 __device__ __forceinline__ float asin_cr(float x) { return (float)asin((double)x); }
 __device__ __forceinline__ float acos_cr(float x) { return (float)acos((double)x); }
 __device__ __forceinline__ float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
 __device__ __forceinline__ uint32_t f2u(float f) {
     if (!(f > 0.0f)) return 0u;

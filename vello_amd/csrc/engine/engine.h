@@ -60,6 +60,9 @@ struct Frame {
     size_t out_stride;
     const uint32_t *ramps;
     uint32_t n_ramps;
+    const uint32_t *atlas;  // RGBA8 image atlas (render.rs:160-203), atlas_w x atlas_h texels
+    uint32_t atlas_w, atlas_h;
+    bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;
     const uint32_t *mask_lut16;
     Bump *bump() const { return &control->bump; }

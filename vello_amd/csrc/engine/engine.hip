@@ -53,10 +53,13 @@ struct vello_hip_ctx {
     vello_hip_capacities caps{};
     DevBuf scene, config;
     DevBuf ramps, mask8, mask16;
+    DevBuf atlas;  // persistent image atlas (render.rs:160-176), shared by all lanes
+    uint32_t atlas_w = 0, atlas_h = 0;
     std::vector<Lane> lanes;
     uint32_t next_lane = 0, last_lane = 0;
     uint32_t n_ramps = 0;
     bool scene_resident = false;
+    bool scene_brushes = false;
     vello_hip_layout layout{};
     size_t scene_len = 0;
     uint32_t n_tag_words = 0, n_pathtag_parts = 0, n_draw_parts = 0;
@@ -231,6 +234,10 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     }
     f.ramps = c->n_ramps ? (const uint32_t *)c->ramps.ptr : nullptr;
     f.n_ramps = c->n_ramps;
+    f.brushes = c->scene_brushes;
+    f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
+    f.atlas_w = c->atlas_w;
+    f.atlas_h = c->atlas_h;
     f.mask_lut8 = (const uint32_t *)c->mask8.ptr;
     f.mask_lut16 = (const uint32_t *)c->mask16.ptr;
     l.used = true;
@@ -413,7 +420,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&c->scene, &c->config, &c->ramps, &c->mask8, &c->mask16})
+    for (DevBuf *b : {&c->scene, &c->config, &c->ramps, &c->mask8, &c->mask16, &c->atlas})
         if (b->ptr) (void)hipFree(b->ptr);
     delete c;
 }
@@ -465,6 +472,19 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
     c->zero_bytes = sizeof(Control) + ((size_t)c->n_pathtag_parts * 10u + (size_t)c->n_draw_parts * 8u) * 8u;
     for (auto &l : c->lanes)
         if ((r = alloc_lane_scene(c, l))) return r;
+    // Which fine specialisation the scene needs: any draw tag other than COLOR / BEGIN_CLIP / END_CLIP / NOP
+    // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
+    c->scene_brushes = false;
+    {
+        const uint32_t *words_p = reinterpret_cast<const uint32_t *>(scene);
+        for (uint32_t i = 0; i < L.n_draw_objects; i++) {
+            uint32_t t = words_p[L.draw_tag_base + i];
+            if (t != DRAWTAG_FILL_COLOR && t != DRAWTAG_BEGIN_CLIP && t != DRAWTAG_END_CLIP && t != DRAWTAG_NOP) {
+                c->scene_brushes = true;
+                break;
+            }
+        }
+    }
     hipStream_t st = c->lanes[0].stream;
     if (scene_len) HIP_TRY(c, hipMemcpyAsync(c->scene.ptr, scene, scene_len, hipMemcpyHostToDevice, st));
     HIP_TRY(c, hipMemsetAsync((char *)c->scene.ptr + scene_len, 0, 64, st));
@@ -477,6 +497,38 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
     // the source buffers are caller-owned only for the duration of the call (recording.rs:124-129)
     HIP_TRY(c, hipStreamSynchronize(st));
     c->scene_resident = true;
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_resize_image_atlas(vello_hip_ctx *c, uint32_t width, uint32_t height) {
+    if (!c || width > 0xffffu || height > 0xffffu) return VELLO_HIP_E_INVALID;  // DrawImage packs xy / extents in 16 bits
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = sync_all(c);
+    if (r) return r;
+    c->atlas_w = c->atlas_h = 0;
+    if (width == 0 || height == 0) return VELLO_HIP_OK;
+    size_t bytes = (size_t)width * height * 4u;
+    if ((r = ensure(c, c->atlas, bytes))) return r;
+    HIP_TRY(c, hipMemset(c->atlas.ptr, 0, bytes));
+    c->atlas_w = width;
+    c->atlas_h = height;
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_write_image(vello_hip_ctx *c, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const uint8_t *rgba8,
+                          size_t stride) {
+    if (!c || !rgba8) return VELLO_HIP_E_INVALID;
+    if ((uint64_t)x + width > c->atlas_w || (uint64_t)y + height > c->atlas_h) {
+        c->last_error = "write_image outside the atlas";
+        return VELLO_HIP_E_INVALID;
+    }
+    if (width == 0 || height == 0) return VELLO_HIP_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = sync_all(c);  // frames in flight sample the atlas
+    if (r) return r;
+    if (stride == 0) stride = (size_t)width * 4u;
+    HIP_TRY(c, hipMemcpy2D((char *)c->atlas.ptr + ((size_t)y * c->atlas_w + x) * 4u, (size_t)c->atlas_w * 4u, rgba8, stride,
+                           (size_t)width * 4u, height, hipMemcpyHostToDevice));
     return VELLO_HIP_OK;
 }
 

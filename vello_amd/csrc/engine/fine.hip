@@ -467,13 +467,141 @@ __device__ __forceinline__ void src_over(vec4 &rgba, vec4 fg, float area) {
     rgba = rgba * (1.0f - fg_i.w) + fg_i;
 }
 
+// ---------------- images (fine.wgsl:804-993, :1315-1382) ----------------
+// Kept out of line: image and blur commands are rare and must not cost the solid-colour path registers.
+struct Atlas {
+    const uint32_t *texels;
+    uint32_t w, h;
+};
+__device__ __forceinline__ vec4 atlas_load(Atlas at, float u, float v, uint32_t alpha_type) {
+    // textureLoad(image_atlas, vec2<i32>(uv), 0); out-of-range loads return transparent black
+    const int32_t x = f2i(truncf(u)), y = f2i(truncf(v));
+    if (!at.texels || x < 0 || y < 0 || (uint32_t)x >= at.w || (uint32_t)y >= at.h) return vec4{0.0f, 0.0f, 0.0f, 0.0f};
+    vec4 p = unpack4x8unorm(at.texels[(size_t)y * at.w + (uint32_t)x]);
+    if (alpha_type == 0u) {  // maybe_premul_alpha
+        p.x *= p.w;
+        p.y *= p.w;
+        p.z *= p.w;
+    }
+    return p;
+}
+__device__ __forceinline__ float extend_mode_px(float t, uint32_t mode, float max) {  // fine.wgsl:877-889
+    if (mode == 0u) return clampf(t, 0.0f, max);
+    return extend_mode_normalized(t / max, mode) * max;
+}
+__device__ __forceinline__ float single_weight(float t, float a, float b, float c, float d) { return t * (t * (t * d + c) + b) + a; }
+__device__ __forceinline__ void cubic_weights(float fr, float (&w)[4]) {  // Mitchell B = C = 1/3, fine.wgsl:893-931
+    w[0] = single_weight(fr, (1.0f / 6.0f) / 3.0f, -(3.0f / 6.0f) / 3.0f - 1.0f / 3.0f, (3.0f / 6.0f) / 3.0f + 2.0f * 1.0f / 3.0f,
+                         -(1.0f / 6.0f) / 3.0f - 1.0f / 3.0f);
+    w[1] = single_weight(fr, 1.0f - (2.0f / 6.0f) / 3.0f, 0.0f, -3.0f + (12.0f / 6.0f) / 3.0f + 1.0f / 3.0f,
+                         2.0f - (9.0f / 6.0f) / 3.0f - 1.0f / 3.0f);
+    w[2] = single_weight(fr, (1.0f / 6.0f) / 3.0f, (3.0f / 6.0f) / 3.0f + 1.0f / 3.0f, 3.0f - (15.0f / 6.0f) / 3.0f - 2.0f * 1.0f / 3.0f,
+                         -2.0f + (9.0f / 6.0f) / 3.0f + 1.0f / 3.0f);
+    w[3] = single_weight(fr, 0.0f, 0.0f, -1.0f / 3.0f, (1.0f / 6.0f) / 3.0f + 1.0f / 3.0f);
+}
+// Premultiplied sample of the image brush at pixel centre (px, py): read_image + the quality switch.
+__device__ __attribute__((noinline)) vec4 image_sample(Atlas at, const uint32_t *__restrict__ info, uint32_t io, float px, float py) {
+    const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                m3 = __uint_as_float(info[io + 3u]);
+    const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+    const uint32_t xy = info[io + 6u], width_height = info[io + 7u], sample_alpha = info[io + 8u];
+    const uint32_t alpha_type = (sample_alpha >> 14) & 1u, quality = (sample_alpha >> 12) & 3u;
+    const uint32_t x_extend = (sample_alpha >> 10) & 3u, y_extend = (sample_alpha >> 8) & 3u;
+    const float ox = (float)(xy >> 16), oy = (float)(xy & 0xffffu);
+    const float ew = (float)(width_height >> 16), eh = (float)(width_height & 0xffffu);
+    const float amx = ox + ew - 1.0f, amy = oy + eh - 1.0f;
+    float u = m0 * px + m2 * py + xl0;
+    float v = m1 * px + m3 * py + xl1;
+    u = extend_mode_px(u, x_extend, ew);
+    v = extend_mode_px(v, y_extend, eh);
+    if (quality == 0u) {  // IMAGE_QUALITY_LOW: nearest
+        u += ox;
+        v += oy;
+        return atlas_load(at, clampf(u, ox, amx), clampf(v, oy, amy), alpha_type);
+    }
+    if (quality == 2u) {  // IMAGE_QUALITY_HIGH: bicubic_sample
+        u += ox;
+        v += oy;
+        const float fx = (u + 0.5f) - floorf(u + 0.5f), fy = (v + 0.5f) - floorf(v + 0.5f);
+        float wx[4], wy[4];
+        cubic_weights(fx, wx);
+        cubic_weights(fy, wy);
+        vec4 res{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < 4; j++) {
+            const float vv = clampf(v + ((float)j - 1.5f), oy, amy);
+            vec4 s0 = atlas_load(at, clampf(u - 1.5f, ox, amx), vv, alpha_type);
+            vec4 s1 = atlas_load(at, clampf(u - 0.5f, ox, amx), vv, alpha_type);
+            vec4 s2 = atlas_load(at, clampf(u + 0.5f, ox, amx), vv, alpha_type);
+            vec4 s3 = atlas_load(at, clampf(u + 1.5f, ox, amx), vv, alpha_type);
+            vec4 row = s0 * wx[0] + s1 * wx[1] + s2 * wx[2] + s3 * wx[3];
+            res = j == 0 ? row * wy[0] : res + row * wy[j];
+        }
+        const float a = clampf(res.w, 0.0f, 1.0f);
+        return vec4{clampf(res.x, 0.0f, a), clampf(res.y, 0.0f, a), clampf(res.z, 0.0f, a), a};
+    }
+    // IMAGE_QUALITY_MEDIUM (default): bilinear
+    u = u + ox - 0.5f;
+    v = v + oy - 0.5f;
+    const float uc = clampf(u, ox, amx), vc = clampf(v, oy, amy);
+    const float x0 = floorf(uc), y0 = floorf(vc), x1 = ceilf(uc), y1 = ceilf(vc);
+    const float frx = u - floorf(u), fry = v - floorf(v);
+    const vec4 a = atlas_load(at, x0, y0, alpha_type), b = atlas_load(at, x0, y1, alpha_type);
+    const vec4 c = atlas_load(at, x1, y0, alpha_type), d = atlas_load(at, x1, y1, alpha_type);
+    return vec4{mixf(mixf(a.x, b.x, fry), mixf(c.x, d.x, fry), frx), mixf(mixf(a.y, b.y, fry), mixf(c.y, d.y, fry), frx),
+                mixf(mixf(a.z, b.z, fry), mixf(c.z, d.z, fry), frx), mixf(mixf(a.w, b.w, fry), mixf(c.w, d.w, fry), frx)};
+}
+
+// ---------------- blurred rounded rectangle (fine.wgsl:715-726, :1173-1224) ----------------
+__device__ __forceinline__ float erf7(float x) {
+    const float y = clampf(x * 1.1283791671f, -100.0f, 100.0f);
+    const float yy = y * y;
+    const float z = y + (0.24295f + (0.03395f + 0.0104f * yy) * yy) * (y * yy);
+    return z / sqrtf(1.0f + z * z);
+}
+__device__ __forceinline__ float hypot_wgsl(float a, float b) { return sqrtf(a * a + b * b); }
+// Coverage factor `alpha` of the blurred rounded rect at pixel corner (px, py).
+__device__ __attribute__((noinline)) float blur_rect_alpha(const uint32_t *__restrict__ info, uint32_t io, float px, float py) {
+    const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                m3 = __uint_as_float(info[io + 3u]);
+    const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+    const float bw = __uint_as_float(info[io + 6u]), bh = __uint_as_float(info[io + 7u]);
+    const float bradius = __uint_as_float(info[io + 8u]), bstd = __uint_as_float(info[io + 9u]);
+    const float std_dev = maxf(bstd, 1e-5f);
+    const float inv_std_dev = 1.0f / std_dev;
+    const float min_edge = minf(bw, bh);
+    const float radius_max = 0.5f * min_edge;
+    const float r0 = minf(hypot_wgsl(bradius, std_dev * 1.15f), radius_max);
+    const float r1 = minf(hypot_wgsl(bradius, std_dev * 2.0f), radius_max);
+    const float exponent = 2.0f * r1 / r0;
+    const float inv_exponent = 1.0f / exponent;
+    const float delta =
+        1.25f * std_dev * (exp_cr(-pow_cr(0.5f * inv_std_dev * bw, 2.0f)) - exp_cr(-pow_cr(0.5f * inv_std_dev * bh, 2.0f)));
+    const float width = bw + minf(delta, 0.0f);
+    const float height = bh - maxf(delta, 0.0f);
+    const float scale = 0.5f * erf7(inv_std_dev * 0.5f * (maxf(width, height) - 0.5f * bradius));
+    const float x = m0 * px + m2 * py + xl0;
+    const float y = m1 * px + m3 * py + xl1;
+    const float y0 = fabsf(y) - (height * 0.5f - r1);
+    const float y1 = maxf(y0, 0.0f);
+    const float x0 = fabsf(x) - (width * 0.5f - r1);
+    const float x1 = maxf(x0, 0.0f);
+    const float d_pos = pow_cr(pow_cr(x1, exponent) + pow_cr(y1, exponent), inv_exponent);
+    const float d_neg = minf(maxf(x0, y0), 0.0f);
+    const float d = d_pos + d_neg - r1;
+    return scale * (erf7(inv_std_dev * (min_edge + d)) - erf7(inv_std_dev * d));
+}
+
 }  // namespace
 
-template <int AA>
+// BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
+// on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
+// solid-colour interpreter does not pay their registers.
+template <int AA, bool BRUSHES>
 __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
-                                             const uint32_t *__restrict__ mask_lut) {
+                                             const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
+                                             uint32_t atlas_w, uint32_t atlas_h) {
     __shared__ FineShared sh;
     __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
     if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
@@ -592,7 +720,11 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
             cmd_ix += 3u;
         } else if (tag == CMD_JUMP) {
             cmd_ix = rd(cmd_ix + 1u);
-        } else if (tag == CMD_LIN_GRAD) {
+        } else if (!BRUSHES && (tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT)) {
+            cmd_ix += 3u;  // unreachable by construction; keeps the stream in step if the contract is broken
+        } else if (!BRUSHES && tag == CMD_IMAGE) {
+            cmd_ix += 2u;
+        } else if (BRUSHES && tag == CMD_LIN_GRAD) {
             const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
             const uint32_t io = rd(cmd_ix + 2u);
@@ -605,7 +737,7 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
                 src_over(rgba[i], ramp_load(ramps, n_ramps, x, index), area[i]);
             }
             cmd_ix += 3u;
-        } else if (tag == CMD_RAD_GRAD) {
+        } else if (BRUSHES && tag == CMD_RAD_GRAD) {
             const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
             const uint32_t io = rd(cmd_ix + 2u);
@@ -651,7 +783,7 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
                 }
             }
             cmd_ix += 3u;
-        } else if (tag == CMD_SWEEP_GRAD) {
+        } else if (BRUSHES && tag == CMD_SWEEP_GRAD) {
             const uint32_t index_mode = rd(cmd_ix + 1u);
             const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
             const uint32_t io = rd(cmd_ix + 2u);
@@ -681,10 +813,31 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
                 src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
             }
             cmd_ix += 3u;
-        } else if (tag == CMD_IMAGE) {
-            cmd_ix += 2u;  // images: SURVEY.md 8f f3 (next)
-        } else if (tag == CMD_BLUR_RECT) {
-            cmd_ix += 3u;  // blurred rounded rect: SURVEY.md 8f f3 (next)
+        } else if (BRUSHES && tag == CMD_IMAGE) {
+            const uint32_t io = rd(cmd_ix + 1u);
+            const uint32_t sample_alpha = info[io + 8u];
+            const float alpha = (float)(sample_alpha & 0xFFu) / 255.0f;
+            const bool bgra = (sample_alpha >> 15) == 1u;
+            const Atlas at{atlas_texels, atlas_w, atlas_h};
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                if (area[i] != 0.0f) {
+                    vec4 fg = image_sample(at, info, io, xy_x + (float)i + 0.5f, xy_y + 0.5f);
+                    vec4 fg_i = fg * area[i] * alpha;
+                    if (bgra) fg_i = vec4{fg_i.z, fg_i.y, fg_i.x, fg_i.w};  // pixel_format: .bgra
+                    rgba[i] = rgba[i] * (1.0f - fg_i.w) + fg_i;
+                }
+            }
+            cmd_ix += 2u;
+        } else if (BRUSHES && tag == CMD_BLUR_RECT) {
+            const uint32_t io = rd(cmd_ix + 1u);
+            const vec4 blur_rgba = unpack4x8unorm(rd(cmd_ix + 2u));
+#pragma unroll 1
+            for (int i = 0; i < 4; i++) {
+                const float alpha = blur_rect_alpha(info, io, xy_x + (float)i, xy_y);
+                src_over(rgba[i], blur_rgba * alpha, area[i]);
+            }
+            cmd_ix += 3u;
         } else {
             cmd_ix += 1u;
         }
@@ -711,20 +864,23 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
     }
 }
 
-void launch_fine(const Frame &f, hipStream_t s) {
+template <int AA>
+static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_lut) {
     dim3 grid(f.cfg.width_in_tiles, f.cfg.height_in_tiles);
-    if (grid.x * grid.y == 0) return;
-    const Segment *seg = f.segments;
     uint32_t stride = (uint32_t)f.out_stride;
-    if (f.aa == 0)
-        hipLaunchKernelGGL(k_fine<0>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
-                           f.n_ramps, f.mask_lut8);
-    else if (f.aa == 1)
-        hipLaunchKernelGGL(k_fine<1>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
-                           f.n_ramps, f.mask_lut8);
+    if (f.brushes)
+        hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h);
     else
-        hipLaunchKernelGGL(k_fine<2>, grid, dim3(64), 0, s, f.cfg, seg, f.ptcl, f.info_bin_data, f.blend_spill, f.output, stride, f.ramps,
-                           f.n_ramps, f.mask_lut16);
+        hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h);
+}
+
+void launch_fine(const Frame &f, hipStream_t s) {
+    if (f.cfg.width_in_tiles * f.cfg.height_in_tiles == 0) return;
+    if (f.aa == 0) launch_fine_aa<0>(f, s, f.mask_lut8);
+    else if (f.aa == 1) launch_fine_aa<1>(f, s, f.mask_lut8);
+    else launch_fine_aa<2>(f, s, f.mask_lut16);
 }
 
 }  // namespace vk

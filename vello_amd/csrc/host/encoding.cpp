@@ -296,10 +296,25 @@ void Encoding::reset() {
     draw_data.clear();
     transforms.clear();
     styles.clear();
+    resources.reset();
     n_paths = n_path_segments = n_clips = n_open_clips = flags = 0;
 }
 
 void Encoding::append(const Encoding &other, const std::optional<Transform> &transform) {
+    // encoding.rs:95-152: late-bound resources move with their stream offsets
+    {
+        const size_t draw_data_base = draw_data.size();
+        const size_t stops_base = resources.color_stops.size();
+        for (Patch p : other.resources.patches) {
+            p.draw_data_offset += draw_data_base;
+            if (p.kind == Patch::Kind::Ramp) {
+                p.stops_begin += stops_base;
+                p.stops_end += stops_base;
+            }
+            resources.patches.push_back(std::move(p));
+        }
+        resources.color_stops.insert(resources.color_stops.end(), other.resources.color_stops.begin(), other.resources.color_stops.end());
+    }
     path_tags.insert(path_tags.end(), other.path_tags.begin(), other.path_tags.end());
     path_data.insert(path_data.end(), other.path_data.begin(), other.path_data.end());
     draw_tags.insert(draw_tags.end(), other.draw_tags.begin(), other.draw_tags.end());
@@ -359,6 +374,134 @@ void Encoding::encode_empty_shape() {
 void Encoding::encode_color(uint32_t rgba) {
     draw_tags.push_back(DrawTag::COLOR);
     draw_data.push_back(rgba);
+}
+
+// ---------------- brushes with late-bound resources (encoding.rs:286-484) ----------------
+static void push_words(std::vector<uint32_t> &v, const void *p, size_t n_words) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(p);
+    v.insert(v.end(), w, w + n_words);
+}
+
+Encoding::RampStops Encoding::add_ramp(const std::vector<ColorStop> &stops, float alpha, Extend extend, InterpolationAlphaSpace space,
+                                       Color *one) {
+    const size_t offset = draw_data.size();
+    const size_t stops_start = resources.color_stops.size();
+    for (const ColorStop &st : stops) resources.color_stops.push_back(alpha != 1.0f ? st.multiply_alpha(alpha) : st);
+    const size_t stops_end = resources.color_stops.size();
+    switch (stops_end - stops_start) {
+    case 0: return RampStops::Empty;
+    case 1:
+        *one = resources.color_stops.back().color;
+        resources.color_stops.pop_back();
+        return RampStops::One;
+    default: {
+        Patch p;
+        p.kind = Patch::Kind::Ramp;
+        p.draw_data_offset = offset;
+        p.stops_begin = stops_start;
+        p.stops_end = stops_end;
+        p.extend = extend;
+        p.interpolation_alpha_space = space;
+        resources.patches.push_back(p);
+        return RampStops::Many;
+    }
+    }
+}
+
+void Encoding::encode_linear_gradient(DrawLinearGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                                      InterpolationAlphaSpace space) {
+    Color one{};
+    switch (add_ramp(stops, alpha, extend, space, &one)) {
+    case RampStops::Empty: encode_color(0u); break;  // palette::css::TRANSPARENT
+    case RampStops::One: encode_color(one.premul_rgba8()); break;
+    case RampStops::Many:
+        draw_tags.push_back(DrawTag::LINEAR_GRADIENT);
+        push_words(draw_data, &gradient, sizeof gradient / 4);
+        break;
+    }
+}
+
+void Encoding::encode_radial_gradient(DrawRadialGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                                      InterpolationAlphaSpace space) {
+    // Skia's epsilon for radii comparison (encoding.rs:396-401)
+    const float SKIA_EPSILON = 1.0f / (float)(1 << 12);
+    if (gradient.p0[0] == gradient.p1[0] && gradient.p0[1] == gradient.p1[1] && std::fabs(gradient.r0 - gradient.r1) < SKIA_EPSILON) {
+        encode_color(0u);
+        return;
+    }
+    Color one{};
+    switch (add_ramp(stops, alpha, extend, space, &one)) {
+    case RampStops::Empty: encode_color(0u); break;
+    case RampStops::One: encode_color(one.premul_rgba8()); break;
+    case RampStops::Many:
+        draw_tags.push_back(DrawTag::RADIAL_GRADIENT);
+        push_words(draw_data, &gradient, sizeof gradient / 4);
+        break;
+    }
+}
+
+void Encoding::encode_sweep_gradient(DrawSweepGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                                     InterpolationAlphaSpace space) {
+    const float SKIA_DEGENERATE_THRESHOLD = 1.0f / (float)(1 << 15);
+    if (std::fabs(gradient.t0 - gradient.t1) < SKIA_DEGENERATE_THRESHOLD) {
+        encode_color(0u);
+        return;
+    }
+    Color one{};
+    switch (add_ramp(stops, alpha, extend, space, &one)) {
+    case RampStops::Empty: encode_color(0u); break;
+    case RampStops::One: encode_color(one.premul_rgba8()); break;
+    case RampStops::Many:
+        draw_tags.push_back(DrawTag::SWEEP_GRADIENT);
+        push_words(draw_data, &gradient, sizeof gradient / 4);
+        break;
+    }
+}
+
+// encode_brush's Gradient arm (encoding.rs:286-345)
+void Encoding::encode_gradient(const Gradient &g, float alpha) {
+    switch (g.kind) {
+    case Gradient::Kind::Linear:
+        encode_linear_gradient({0u, {(float)g.p0[0], (float)g.p0[1]}, {(float)g.p1[0], (float)g.p1[1]}}, g.stops, alpha, g.extend,
+                               g.interpolation_alpha_space);
+        break;
+    case Gradient::Kind::Radial:
+        encode_radial_gradient({0u, {(float)g.p0[0], (float)g.p0[1]}, {(float)g.p1[0], (float)g.p1[1]}, g.r0, g.r1}, g.stops, alpha,
+                               g.extend, g.interpolation_alpha_space);
+        break;
+    case Gradient::Kind::Sweep: {
+        const float TAU = 6.28318530717958647692528676655900577f;
+        encode_sweep_gradient({0u, {(float)g.p0[0], (float)g.p0[1]}, g.start_angle / TAU, g.end_angle / TAU}, g.stops, alpha, g.extend,
+                              g.interpolation_alpha_space);
+        break;
+    }
+    }
+}
+
+void Encoding::encode_image(const ImageBrush &brush, float alpha) {
+    const ImageSampler &sm = brush.sampler;
+    // (global_alpha * alpha * 255.0).round() as u8: round half away from zero, saturating
+    float av = std::round(sm.alpha * alpha * 255.0f);
+    uint32_t a8 = !(av > 0.0f) ? 0u : (av >= 255.0f ? 255u : (uint32_t)av);
+    Patch p;
+    p.kind = Patch::Kind::Image;
+    p.draw_data_offset = draw_data.size();
+    p.image = brush.image;
+    resources.patches.push_back(p);
+    draw_tags.push_back(DrawTag::IMAGE);
+    draw_data.push_back(0u);  // xy, patched by the Resolver
+    draw_data.push_back((brush.image.width << 16) | (brush.image.height & 0xFFFFu));
+    draw_data.push_back(((uint32_t)brush.image.format << 15) | ((uint32_t)brush.image.alpha_type << 14) | ((uint32_t)sm.quality << 12) |
+                        ((uint32_t)sm.x_extend << 10) | ((uint32_t)sm.y_extend << 8) | a8);
+}
+
+void Encoding::encode_blurred_rounded_rect(uint32_t rgba, float width, float height, float radius, float std_dev) {
+    draw_tags.push_back(DrawTag::BLUR_RECT);
+    draw_data.push_back(rgba);
+    push_words(draw_data, &width, 1);
+    push_words(draw_data, &height, 1);
+    push_words(draw_data, &radius, 1);
+    push_words(draw_data, &std_dev, 1);
 }
 
 void Encoding::encode_begin_clip(const DrawBeginClip &p) {

@@ -10,6 +10,7 @@
 //   RenderConfig   vello_encoding/src/config.rs:124-273
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <optional>
 #include <vector>
 
@@ -68,6 +69,80 @@ struct Color {
     uint32_t premul_rgba8() const;
 };
 
+// peniko::{Extend, ColorStop, InterpolationAlphaSpace, ImageFormat, ImageAlphaType, ImageQuality}: the enum values
+// are the ones the shaders decode (fine.wgsl:829-875, :26-28)
+enum class Extend : uint32_t { Pad = 0, Repeat = 1, Reflect = 2 };
+enum class InterpolationAlphaSpace : uint32_t { Premultiplied = 0, Unpremultiplied = 1 };
+enum class ImageFormat : uint32_t { Rgba8 = 0, Bgra8 = 1 };
+enum class ImageAlphaType : uint32_t { Alpha = 0, AlphaPremultiplied = 1 };
+enum class ImageQuality : uint32_t { Low = 0, Medium = 1, High = 2 };
+struct ColorStop {
+    float offset;
+    Color color;
+    ColorStop multiply_alpha(float alpha) const { return {offset, color.multiply_alpha(alpha)}; }
+};
+
+// peniko::ImageData: `id` plays the role of Blob::id() (the atlas cache key, image_cache.rs:101)
+struct ImageData {
+    uint64_t id = 0;
+    uint32_t width = 0, height = 0;
+    ImageFormat format = ImageFormat::Rgba8;
+    ImageAlphaType alpha_type = ImageAlphaType::Alpha;
+    std::shared_ptr<const std::vector<uint8_t>> data;  // width * height * 4 bytes
+};
+struct ImageSampler {
+    Extend x_extend = Extend::Pad, y_extend = Extend::Pad;
+    ImageQuality quality = ImageQuality::Medium;
+    float alpha = 1.0f;
+};
+struct ImageBrush {
+    ImageData image;
+    ImageSampler sampler;
+};
+
+// draw.rs:117-186
+struct DrawLinearGradient {
+    uint32_t index;
+    float p0[2], p1[2];
+};
+struct DrawRadialGradient {
+    uint32_t index;
+    float p0[2], p1[2], r0, r1;
+};
+struct DrawSweepGradient {
+    uint32_t index;
+    float p0[2], t0, t1;
+};
+
+// peniko::Gradient
+struct Gradient {
+    enum class Kind { Linear, Radial, Sweep } kind = Kind::Linear;
+    double p0[2] = {0, 0}, p1[2] = {0, 0};  // linear: start/end; radial: start_center/end_center; sweep: center = p0
+    float r0 = 0, r1 = 0;                   // radial radii
+    float start_angle = 0, end_angle = 0;   // sweep
+    Extend extend = Extend::Pad;
+    InterpolationAlphaSpace interpolation_alpha_space = InterpolationAlphaSpace::Premultiplied;
+    std::vector<ColorStop> stops;
+};
+
+// resolve.rs:563-590 (Patch), encoding.rs:560-590 (Resources); glyph runs are not restated
+struct Patch {
+    enum class Kind { Ramp, Image } kind;
+    size_t draw_data_offset;  // in u32 words of draw_data
+    size_t stops_begin = 0, stops_end = 0;
+    Extend extend = Extend::Pad;
+    InterpolationAlphaSpace interpolation_alpha_space = InterpolationAlphaSpace::Premultiplied;
+    ImageData image;
+};
+struct Resources {
+    std::vector<Patch> patches;
+    std::vector<ColorStop> color_stops;
+    void reset() {
+        patches.clear();
+        color_stops.clear();
+    }
+};
+
 // peniko::BlendMode -> DrawBeginClip (draw.rs:191-236)
 struct DrawBeginClip {
     uint32_t blend_mode;
@@ -112,6 +187,7 @@ struct Encoding {
     std::vector<uint32_t> draw_data;
     std::vector<Transform> transforms;
     std::vector<Style> styles;
+    Resources resources;
     uint32_t n_paths = 0, n_path_segments = 0, n_clips = 0, n_open_clips = 0, flags = 0;
     static constexpr uint32_t FORCE_NEXT_TRANSFORM = 1, FORCE_NEXT_STYLE = 2;
 
@@ -124,12 +200,24 @@ struct Encoding {
     bool encode_path_elements(const kurbo::BezPath &path, bool is_fill);
     void encode_empty_shape();
     void encode_color(uint32_t premul_rgba8);
+    // encoding.rs:352-484
+    void encode_gradient(const Gradient &gradient, float alpha);
+    void encode_linear_gradient(DrawLinearGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                                InterpolationAlphaSpace space);
+    void encode_radial_gradient(DrawRadialGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                                InterpolationAlphaSpace space);
+    void encode_sweep_gradient(DrawSweepGradient gradient, const std::vector<ColorStop> &stops, float alpha, Extend extend,
+                               InterpolationAlphaSpace space);
+    void encode_image(const ImageBrush &brush, float alpha);
+    void encode_blurred_rounded_rect(uint32_t premul_rgba8, float width, float height, float radius, float std_dev);
     void encode_begin_clip(const DrawBeginClip &p);
     void encode_end_clip();
     void swap_last_path_tags();
 
   private:
     void encode_style(const Style &s);
+    enum class RampStops { Empty, One, Many };
+    RampStops add_ramp(const std::vector<ColorStop> &stops, float alpha, Extend extend, InterpolationAlphaSpace space, Color *one);
 };
 
 struct Layout {
@@ -141,5 +229,76 @@ static_assert(sizeof(Layout) == 40, "Layout");
 
 // resolve.rs:107-154
 Layout resolve_solid_paths_only(const Encoding &encoding, std::vector<uint8_t> &packed);
+
+// ramp_cache.rs:12-155.  make_ramp interpolates with the `color` crate (0.3.x, not in the reference tree):
+// AlphaColor<Srgb>::lerp = premultiply, component-wise a + t*(b-a), un-premultiply; restated here.
+class RampCache {
+  public:
+    static constexpr size_t N_SAMPLES = 512, RETAINED_COUNT = 64;
+    void maintain();
+    uint32_t add(InterpolationAlphaSpace space, const ColorStop *stops, size_t n);
+    const std::vector<uint32_t> &data() const { return data_; }
+    uint32_t height() const { return (uint32_t)(data_.size() / N_SAMPLES); }
+
+  private:
+    struct Entry {
+        std::vector<uint32_t> key;  // bit pattern of (space, offset, r, g, b, a)*
+        uint32_t id;
+        uint64_t epoch;
+    };
+    uint64_t epoch_ = 0;
+    std::vector<Entry> map_;
+    std::vector<uint32_t> data_;
+};
+
+// image_cache.rs: residency map keyed by image id + an atlas allocator.  The reference packs with guillotiere
+// 0.7 (not in the tree); the positions are free for the host to choose (the kernels only read the xy the
+// Resolver patches into DrawImage), so this mirror uses a shelf packer with the same sizes and growth rule
+// (1024 -> 8192, doubling, image_cache.rs:9-11, :76-86).
+struct ImageUpload {
+    ImageData image;
+    uint32_t x, y;
+};
+class ImageCache {
+  public:
+    static constexpr uint32_t DEFAULT_ATLAS_SIZE = 1024, MAX_ATLAS_SIZE = 8192;
+    void begin_resolve() { uploads_.clear(); }
+    bool get_or_insert(const ImageData &image, uint32_t *x, uint32_t *y);
+    bool bump_size();
+    uint32_t size() const { return size_; }
+    const std::vector<ImageUpload> &uploads() const { return uploads_; }
+    bool resized() const { return resized_; }
+    void clear_resized() { resized_ = false; }
+
+  private:
+    struct Resident {
+        ImageData image;
+        uint32_t x, y;
+    };
+    bool alloc(uint32_t w, uint32_t h, uint32_t *x, uint32_t *y);
+    uint32_t size_ = DEFAULT_ATLAS_SIZE;
+    uint32_t shelf_y_ = 0, shelf_h_ = 0, shelf_x_ = 0;
+    std::vector<Resident> resident_;
+    std::vector<ImageUpload> uploads_;
+    bool resized_ = true;  // the atlas texture has to be (re)created before the first upload
+};
+
+// Resolver::resolve (resolve.rs:172-393) for encodings with ramp / image patches.
+struct Resolved {
+    Layout layout;
+    const uint32_t *ramps = nullptr;  // 512 texels per ramp
+    uint32_t n_ramps = 0;
+    uint32_t atlas_size = 0;          // square atlas side; 0 when the scene has no images
+    bool atlas_resized = false;       // the atlas must be re-created (all resident images are in `uploads`)
+    const std::vector<ImageUpload> *uploads = nullptr;
+};
+class Resolver {
+  public:
+    Resolved resolve(const Encoding &encoding, std::vector<uint8_t> &packed);
+
+  private:
+    RampCache ramp_cache_;
+    ImageCache image_cache_;
+};
 
 }  // namespace vello_encoding

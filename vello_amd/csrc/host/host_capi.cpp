@@ -37,6 +37,11 @@ struct SceneHandle {
     vello::Scene scene;
     std::vector<uint8_t> packed;
 };
+struct ResolverHandle {
+    vello_encoding::Resolver resolver;
+    std::vector<uint8_t> packed;
+    vello_encoding::Resolved last;
+};
 
 }  // namespace
 
@@ -111,6 +116,110 @@ void vh_scene_append(void *s, void *other, const double *affine) {
     std::optional<Affine> t;
     if (affine) t = affine_from(affine);
     ((SceneHandle *)s)->scene.append(((SceneHandle *)other)->scene, t);
+}
+
+// ---- brushes (peniko::BrushRef) ----
+void *vh_brush_solid(const float *color) { return new vello::Brush(color_from(color)); }
+// kind 0 linear (p = x0 y0 x1 y1), 1 radial (p = cx0 cy0 cx1 cy1 r0 r1), 2 sweep (p = cx cy start_angle end_angle);
+// stops = n_stops x (offset, r, g, b, a)
+void *vh_brush_gradient(int kind, const double *p, uint32_t extend, uint32_t alpha_space, const float *stops, size_t n_stops) {
+    vello_encoding::Gradient g;
+    g.kind = (vello_encoding::Gradient::Kind)kind;
+    g.p0[0] = p[0];
+    g.p0[1] = p[1];
+    if (kind == 0 || kind == 1) {
+        g.p1[0] = p[2];
+        g.p1[1] = p[3];
+    }
+    if (kind == 1) {
+        g.r0 = (float)p[4];
+        g.r1 = (float)p[5];
+    }
+    if (kind == 2) {
+        g.start_angle = (float)p[2];
+        g.end_angle = (float)p[3];
+    }
+    g.extend = (vello_encoding::Extend)extend;
+    g.interpolation_alpha_space = (vello_encoding::InterpolationAlphaSpace)alpha_space;
+    for (size_t i = 0; i < n_stops; i++)
+        g.stops.push_back({stops[5 * i], vello::Color{stops[5 * i + 1], stops[5 * i + 2], stops[5 * i + 3], stops[5 * i + 4]}});
+    return new vello::Brush(g);
+}
+void *vh_brush_image(uint64_t id, uint32_t width, uint32_t height, uint32_t format, uint32_t alpha_type, const uint8_t *rgba8,
+                     uint32_t x_extend, uint32_t y_extend, uint32_t quality, float alpha) {
+    vello_encoding::ImageBrush b;
+    b.image.id = id;
+    b.image.width = width;
+    b.image.height = height;
+    b.image.format = (vello_encoding::ImageFormat)format;
+    b.image.alpha_type = (vello_encoding::ImageAlphaType)alpha_type;
+    b.image.data = std::make_shared<const std::vector<uint8_t>>(rgba8, rgba8 + (size_t)width * height * 4u);
+    b.sampler.x_extend = (vello_encoding::Extend)x_extend;
+    b.sampler.y_extend = (vello_encoding::Extend)y_extend;
+    b.sampler.quality = (vello_encoding::ImageQuality)quality;
+    b.sampler.alpha = alpha;
+    return new vello::Brush(b);
+}
+void vh_brush_free(void *b) { delete (vello::Brush *)b; }
+void vh_scene_fill_brush(void *s, int fill_rule, const double *affine, void *brush, const double *brush_affine, const uint8_t *verbs,
+                         const double *pts, size_t n) {
+    std::optional<Affine> bt;
+    if (brush_affine) bt = affine_from(brush_affine);
+    ((SceneHandle *)s)->scene.fill((vello::Fill)fill_rule, affine_from(affine), *(vello::Brush *)brush, bt, path_from_arrays(verbs, pts, n));
+}
+int vh_scene_stroke_brush(void *s, double width, int join, double miter_limit, int start_cap, int end_cap, const double *affine,
+                          void *brush, const double *brush_affine, const uint8_t *verbs, const double *pts, size_t n) {
+    kurbo::Stroke st;
+    st.width = width;
+    st.join = (kurbo::Join)join;
+    st.miter_limit = miter_limit;
+    st.start_cap = (kurbo::Cap)start_cap;
+    st.end_cap = (kurbo::Cap)end_cap;
+    std::optional<Affine> bt;
+    if (brush_affine) bt = affine_from(brush_affine);
+    return ((SceneHandle *)s)->scene.stroke(st, affine_from(affine), *(vello::Brush *)brush, bt, path_from_arrays(verbs, pts, n)) ? 0 : -1;
+}
+void vh_scene_draw_blurred_rounded_rect(void *s, const double *affine, const double *rect, const float *color, double radius,
+                                        double std_dev) {
+    ((SceneHandle *)s)->scene.draw_blurred_rounded_rect(affine_from(affine), kurbo::Rect{rect[0], rect[1], rect[2], rect[3]},
+                                                        color_from(color), radius, std_dev);
+}
+void vh_scene_draw_blurred_rounded_rect_in(void *s, const uint8_t *verbs, const double *pts, size_t n, const double *affine,
+                                           const double *rect, const float *color, double radius, double std_dev) {
+    ((SceneHandle *)s)->scene.draw_blurred_rounded_rect_in(path_from_arrays(verbs, pts, n), affine_from(affine),
+                                                           kurbo::Rect{rect[0], rect[1], rect[2], rect[3]}, color_from(color), radius,
+                                                           std_dev);
+}
+void vh_scene_draw_image(void *s, void *brush, const double *affine) {
+    ((SceneHandle *)s)->scene.draw_image(((vello::Brush *)brush)->image, affine_from(affine));
+}
+size_t vh_scene_n_patches(void *s) { return ((SceneHandle *)s)->scene.encoding().resources.patches.size(); }
+
+// ---- Resolver (resolve.rs:172-393): ramps + image atlas placement + packed scene ----
+void *vh_resolver_new() { return new ResolverHandle(); }
+void vh_resolver_free(void *r) { delete (ResolverHandle *)r; }
+// info_out: n_ramps, atlas_size, atlas_resized, n_uploads.  Pointers stay valid until the next resolve on this resolver.
+size_t vh_resolver_resolve(void *r, void *scene, const uint8_t **packed, uint32_t layout_out[10], const uint32_t **ramps,
+                           uint32_t info_out[4]) {
+    ResolverHandle *h = (ResolverHandle *)r;
+    h->last = h->resolver.resolve(((SceneHandle *)scene)->scene.encoding(), h->packed);
+    std::memcpy(layout_out, &h->last.layout, sizeof h->last.layout);
+    *packed = h->packed.data();
+    *ramps = h->last.ramps;
+    info_out[0] = h->last.n_ramps;
+    info_out[1] = h->last.atlas_size;
+    info_out[2] = h->last.atlas_resized ? 1u : 0u;
+    info_out[3] = h->last.uploads ? (uint32_t)h->last.uploads->size() : 0u;
+    return h->packed.size();
+}
+const uint8_t *vh_resolver_upload(void *r, uint32_t i, uint32_t xywh_out[4]) {
+    ResolverHandle *h = (ResolverHandle *)r;
+    const vello_encoding::ImageUpload &u = (*h->last.uploads)[i];
+    xywh_out[0] = u.x;
+    xywh_out[1] = u.y;
+    xywh_out[2] = u.image.width;
+    xywh_out[3] = u.image.height;
+    return u.image.data ? u.image.data->data() : nullptr;
 }
 
 // stream access: 0 path_tags(u8) 1 path_data(u32) 2 draw_tags(u32) 3 draw_data(u32) 4 transforms(6 f32) 5 styles(2 u32)

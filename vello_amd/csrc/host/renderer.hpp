@@ -40,6 +40,7 @@ class Renderer {
   private:
     Renderer() = default;
     vello_hip_ctx *ctx_ = nullptr;
+    vello_encoding::Resolver resolver_;
     std::vector<uint8_t> packed_;
     vello_hip_bump bump_{};
     std::string error_;

@@ -17,6 +17,70 @@ void Scene::fill(Fill style, const Affine &transform, const Color &brush, const 
     }
 }
 
+void Scene::encode_brush(const Brush &brush, float alpha) {
+    switch (brush.kind) {
+    case Brush::Kind::Solid: {
+        Color c = alpha != 1.0f ? brush.color.multiply_alpha(alpha) : brush.color;
+        encoding_.encode_color(c.premul_rgba8());
+        break;
+    }
+    case Brush::Kind::Gradient: encoding_.encode_gradient(brush.gradient, alpha); break;
+    case Brush::Kind::Image: encoding_.encode_image(brush.image, alpha); break;
+    }
+}
+
+void Scene::fill(Fill style, const Affine &transform, const Brush &brush, const std::optional<Affine> &brush_transform,
+                 const kurbo::BezPath &shape) {
+    Transform t = Transform::from_kurbo(transform);
+    encoding_.encode_transform(t);
+    encoding_.encode_fill_style(style);
+    if (encoding_.encode_path_elements(shape, true)) {
+        if (brush_transform && encoding_.encode_transform(Transform::from_kurbo(transform * *brush_transform))) {
+            encoding_.swap_last_path_tags();
+        }
+        encode_brush(brush, 1.0f);
+    }
+}
+
+bool Scene::stroke(const kurbo::Stroke &style, const Affine &transform, const Brush &brush, const std::optional<Affine> &brush_transform,
+                   const kurbo::BezPath &shape) {
+    if (style.width == 0.) return true;
+    if (!style.dash_pattern.empty()) return false;
+    if (stroke_gpu_inner(style, transform, shape)) {
+        if (brush_transform && encoding_.encode_transform(Transform::from_kurbo(transform * *brush_transform))) {
+            encoding_.swap_last_path_tags();
+        }
+        encode_brush(brush, 1.0f);
+    }
+    return true;
+}
+
+void Scene::draw_blurred_rounded_rect(const Affine &transform, const kurbo::Rect &rect, const Color &brush, double radius,
+                                      double std_dev) {
+    // the gaussian's support is cut off at 2.5 sigma (scene.rs:264-269)
+    double k = 2.5 * std_dev;
+    kurbo::Rect shape{rect.x0 - k, rect.y0 - k, rect.x1 + k, rect.y1 + k};
+    draw_blurred_rounded_rect_in(kurbo::path_elements(shape, 0.1), transform, rect, brush, radius, std_dev);
+}
+
+void Scene::draw_blurred_rounded_rect_in(const kurbo::BezPath &shape, const Affine &transform, const kurbo::Rect &rect,
+                                         const Color &brush, double radius, double std_dev) {
+    Transform t = Transform::from_kurbo(transform);
+    encoding_.encode_transform(t);
+    encoding_.encode_fill_style(Fill::NonZero);
+    if (encoding_.encode_path_elements(shape, true)) {
+        Affine center = Affine::translate(0.5 * (rect.x0 + rect.x1), 0.5 * (rect.y0 + rect.y1));
+        if (encoding_.encode_transform(Transform::from_kurbo(transform * center))) encoding_.swap_last_path_tags();
+        encoding_.encode_blurred_rounded_rect(brush.premul_rgba8(), (float)(rect.x1 - rect.x0), (float)(rect.y1 - rect.y0), (float)radius,
+                                              (float)std_dev);
+    }
+}
+
+void Scene::draw_image(const vello_encoding::ImageBrush &image, const Affine &transform) {
+    kurbo::Rect rect{0.0, 0.0, (double)image.image.width, (double)image.image.height};
+    fill(Fill::NonZero, transform, Brush(image), std::nullopt, kurbo::path_elements(rect, 0.1));
+}
+
 bool Scene::stroke_gpu_inner(const kurbo::Stroke &style, const Affine &transform, const kurbo::BezPath &shape) {
     Transform t = Transform::from_kurbo(transform);
     encoding_.encode_transform(t);

@@ -1,6 +1,7 @@
 // Mirror of vello::Scene (vello/src/scene.rs:45-470): the API surface a vello user drives.
-// Only what produces the packed stream for the hot path is restated (fills, GPU strokes,
-// clip/blend layers, append); glyphs, images and gradients stay out of scope.
+// What produces the packed stream for the hot path is restated: fills and GPU strokes with solid, gradient
+// and image brushes, blurred rounded rects, clip/blend layers, append.  Glyph runs stay out of scope
+// (they reach the GPU as ordinary paths).
 #pragma once
 #include <optional>
 
@@ -19,6 +20,18 @@ struct BlendMode {
     uint32_t compose = 3;  // Compose::SrcOver
 };
 
+// peniko::BrushRef
+struct Brush {
+    enum class Kind { Solid, Gradient, Image } kind = Kind::Solid;
+    Color color{0.f, 0.f, 0.f, 1.f};
+    vello_encoding::Gradient gradient;
+    vello_encoding::ImageBrush image;
+    Brush() = default;
+    Brush(const Color &c) : kind(Kind::Solid), color(c) {}
+    Brush(const vello_encoding::Gradient &g) : kind(Kind::Gradient), gradient(g) {}
+    Brush(const vello_encoding::ImageBrush &i) : kind(Kind::Image), image(i) {}
+};
+
 class Scene {
   public:
     void reset() { encoding_.reset(); }
@@ -27,6 +40,16 @@ class Scene {
 
     // scene.rs:316-340
     void fill(Fill style, const Affine &transform, const Color &brush, const kurbo::BezPath &shape);
+    void fill(Fill style, const Affine &transform, const Brush &brush, const std::optional<Affine> &brush_transform,
+              const kurbo::BezPath &shape);
+    bool stroke(const kurbo::Stroke &style, const Affine &transform, const Brush &brush, const std::optional<Affine> &brush_transform,
+                const kurbo::BezPath &shape);
+    // scene.rs:256-309
+    void draw_blurred_rounded_rect(const Affine &transform, const kurbo::Rect &rect, const Color &brush, double radius, double std_dev);
+    void draw_blurred_rounded_rect_in(const kurbo::BezPath &shape, const Affine &transform, const kurbo::Rect &rect, const Color &brush,
+                                      double radius, double std_dev);
+    // scene.rs:443-452
+    void draw_image(const vello_encoding::ImageBrush &image, const Affine &transform);
     // scene.rs:347-440 (GPU_STROKES = true; dashing is expanded on the CPU by kurbo::dash upstream
     // and is not restated here: a non-empty dash_pattern is rejected)
     bool stroke(const kurbo::Stroke &style, const Affine &transform, const Color &brush, const kurbo::BezPath &shape);
@@ -41,6 +64,7 @@ class Scene {
   private:
     void push_layer_inner(const vello_encoding::DrawBeginClip &params, Fill clip_style, const Affine &transform,
                           const kurbo::BezPath &clip);
+    void encode_brush(const Brush &brush, float alpha);  // encoding.rs:286-345
     bool stroke_gpu_inner(const kurbo::Stroke &style, const Affine &transform, const kurbo::BezPath &shape);
     Encoding encoding_;
 };

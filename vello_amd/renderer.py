@@ -117,10 +117,31 @@ class Engine:
         bc = base_color.premul_rgba8() if isinstance(base_color, Color) else int(base_color)
         return RenderParamsStruct(width, height, bc, int(aa))
 
-    def upload_scene(self, packed, layout):
+    def upload_scene(self, packed, layout, ramps=None):
+        """Command::Upload of the packed scene (+ the gradient ramp texture: n_ramps x 512 RGBA8 texels as uint32)."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         lay = LayoutStruct(*layout)
-        self._check(self._lib.vello_hip_upload_scene(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), None, 0), "upload_scene")
+        rp, nr = None, 0
+        if ramps is not None and len(ramps):
+            ramps = np.ascontiguousarray(ramps, dtype=np.uint32)
+            rp, nr = ramps.ctypes.data, ramps.size // 512
+        self._check(self._lib.vello_hip_upload_scene(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), rp, nr), "upload_scene")
+
+    def resize_image_atlas(self, width, height):
+        self._check(self._lib.vello_hip_resize_image_atlas(self._h, width, height), "resize_image_atlas")
+
+    def write_image(self, x, y, pixels):
+        pixels = np.ascontiguousarray(pixels, dtype=np.uint8)
+        h, w = pixels.shape[:2]
+        self._check(self._lib.vello_hip_write_image(self._h, x, y, w, h, pixels.ctypes.data, w * 4), "write_image")
+
+    def upload_resolved(self, resolved):
+        """Everything a Resolver result carries: atlas (re)creation + image writes, ramps, packed scene."""
+        if resolved.atlas_size:
+            self.resize_image_atlas(resolved.atlas_size, resolved.atlas_size)
+            for x, y, px in resolved.uploads:
+                self.write_image(x, y, px)
+        self.upload_scene(resolved.packed, resolved.layout, resolved.ramps)
 
     def render_resident(self, width, height, base_color, aa, out=None):
         p = self._params(width, height, base_color, aa)
@@ -131,14 +152,18 @@ class Engine:
             stride = width * 4
         self._check(self._lib.vello_hip_render_resident(self._h, ctypes.byref(p), ptr, stride), "render_resident")
 
-    def render(self, packed, layout, width, height, base_color, aa):
+    def render(self, packed, layout, width, height, base_color, aa, ramps=None):
         """One blocking frame; returns (HxWx4 uint8 image, bump dict)."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         lay = LayoutStruct(*layout)
         p = self._params(width, height, base_color, aa)
         out = np.zeros((height, width, 4), dtype=np.uint8)
         b = Bump()
-        r = self._lib.vello_hip_render(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), ctypes.byref(p), None, 0,
+        rp, nr = None, 0
+        if ramps is not None and len(ramps):
+            ramps = np.ascontiguousarray(ramps, dtype=np.uint32)
+            rp, nr = ramps.ctypes.data, ramps.size // 512
+        r = self._lib.vello_hip_render(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), ctypes.byref(p), rp, nr,
                                        out.ctypes.data, width * 4, 0, ctypes.byref(b))
         if r != 0 and r != E_CAPACITY:
             self._check(r, "render")

@@ -237,3 +237,69 @@ def random_test_scene(seed, n_paths=200, size=512.0, strokes=True, clips=False):
     for _ in range(open_layers):
         s.pop_layer()
     return s
+
+
+def _test_image(w, h, seed, premultiplied=False):
+    """Deterministic RGBA8 test pattern with varying alpha (checker + gradient + noise)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), dtype=np.uint8)
+    img[..., 0] = (x * 255 // max(w - 1, 1))
+    img[..., 1] = (y * 255 // max(h - 1, 1))
+    img[..., 2] = (((x // 4) + (y // 4)) % 2) * 200 + rng.integers(0, 56, (h, w))
+    img[..., 3] = np.clip(64 + 3 * ((x + y) % 64), 0, 255)
+    if premultiplied:
+        a = img[..., 3:4].astype(np.uint16)
+        img[..., :3] = (img[..., :3].astype(np.uint16) * a // 255).astype(np.uint8)
+    return img
+
+
+def brushes_scene(size=256.0):
+    """Gradient, image and blurred-rounded-rect brushes: every gradient kind x extend mode, brush
+    transforms, ramps with alpha in both interpolation spaces, images at the three qualities with all extend modes,
+    BGRA / premultiplied sources, and blurred rounded rects under rotation."""
+    from vello_amd import (Gradient, Extend, InterpolationAlphaSpace, ImageData, ImageBrush, ImageFormat, ImageAlphaType,
+                           ImageQuality, RoundedRect)
+    s = Scene()
+    cs = [Color.from_rgb8(255, 0, 0), Color.from_rgb8(0, 255, 0), Color.from_rgb8(0, 0, 255)]
+    ca = [Color.from_rgba8(255, 200, 0, 255), Color.from_rgba8(0, 100, 255, 40), Color.from_rgba8(255, 255, 255, 200)]
+    q = size / 4
+    # row 0: linear gradients, three extend modes + a brush transform
+    for i, ext in enumerate([Extend.Pad, Extend.Repeat, Extend.Reflect]):
+        g = Gradient.new_linear((i * q + 10, 10), (i * q + 30, 30)).with_stops(cs).with_extend(ext)
+        s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(i * q + 2, 2, (i + 1) * q - 2, q - 2))
+    g = Gradient.new_linear((0, 0), (20, 0)).with_stops([(0.0, ca[0]), (0.3, ca[1]), (1.0, ca[2])]).with_extend(Extend.Reflect)
+    s.fill(Fill.NonZero, Affine.translate(3 * q, 0), g, Affine.rotate(0.6), Circle((q / 2, q / 2), q / 2 - 3))
+    # row 1: radial gradients: circular, two-point (cone), focal-on-circle, strip (equal radii)
+    g = Gradient.new_radial((q / 2, 1.5 * q), q / 2.5).with_stops(cs).with_extend(Extend.Repeat)
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(2, q + 2, q - 2, 2 * q - 2))
+    g = Gradient.new_two_point_radial((1.3 * q, 1.4 * q), 4.0, (1.6 * q, 1.6 * q), q / 3).with_stops(ca).with_extend(Extend.Pad)
+    g = g.with_interpolation_alpha_space(InterpolationAlphaSpace.Unpremultiplied)
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(q + 2, q + 2, 2 * q - 2, 2 * q - 2))
+    g = Gradient.new_two_point_radial((2.5 * q - 10, 1.5 * q), 0.0, (2.5 * q, 1.5 * q), 10.0).with_stops(cs).with_extend(Extend.Reflect)
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(2 * q + 2, q + 2, 3 * q - 2, 2 * q - 2))
+    g = Gradient.new_two_point_radial((3.3 * q, 1.3 * q), 12.0, (3.7 * q, 1.7 * q), 12.0).with_stops(cs).with_extend(Extend.Pad)
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(3 * q + 2, q + 2, 4 * q - 2, 2 * q - 2))
+    # row 2: sweep gradients + a stroked gradient; one- and zero-stop gradients fall back to colours
+    g = Gradient.new_sweep((q / 2, 2.5 * q), 0.0, 2 * math.pi).with_stops(cs + [cs[0]])
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Circle((q / 2, 2.5 * q), q / 2 - 3))
+    g = Gradient.new_sweep((1.5 * q, 2.5 * q), 0.5, 2.5).with_stops(ca).with_extend(Extend.Repeat)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, g, None, Rect(q + 2, 2 * q + 2, 2 * q - 2, 3 * q - 2))
+    g = Gradient.new_linear((2 * q, 2 * q), (3 * q, 3 * q)).with_stops(cs)
+    s.stroke(Stroke(6.0), Affine.IDENTITY, g, None, Circle((2.5 * q, 2.5 * q), q / 2 - 8))
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_linear((0, 0), (1, 1)).with_stops([cs[1]]), None, Rect(3 * q + 2, 2 * q + 2, 3.5 * q, 3 * q - 2))
+    s.fill(Fill.NonZero, Affine.IDENTITY, Gradient.new_linear((0, 0), (1, 1)).with_stops([]), None, Rect(3.5 * q, 2 * q + 2, 4 * q - 2, 3 * q - 2))
+    # row 3: images (three qualities, extend modes, BGRA, premultiplied, alpha) and blurred rounded rects
+    im_a = ImageData(_test_image(24, 16, 1))
+    im_b = ImageData(_test_image(13, 9, 2), ImageFormat.Bgra8)
+    im_c = ImageData(_test_image(32, 32, 3, premultiplied=True), ImageFormat.Rgba8, ImageAlphaType.AlphaPremultiplied)
+    s.draw_image(ImageBrush(im_a, quality=ImageQuality.Low), Affine.translate(4, 3 * q + 4) * Affine.scale(2.0))
+    s.fill(Fill.NonZero, Affine.IDENTITY, ImageBrush(im_b, Extend.Repeat, Extend.Reflect, ImageQuality.Medium, 0.8),
+           Affine.translate(q, 3 * q) * Affine.rotate(0.3) * Affine.scale(1.7), Rect(q + 2, 3 * q + 2, 2 * q - 2, 4 * q - 2))
+    s.fill(Fill.NonZero, Affine.IDENTITY, ImageBrush(im_c, Extend.Reflect, Extend.Repeat, ImageQuality.High),
+           Affine.translate(2 * q + 5, 3 * q + 5) * Affine.scale_non_uniform(0.7, 1.3), Circle((2.5 * q, 3.5 * q), q / 2 - 2))
+    s.draw_image(ImageBrush(im_a, quality=ImageQuality.High, alpha=0.5), Affine.translate(2 * q + 8, 3 * q + 30) * Affine.rotate(-0.2))
+    s.draw_blurred_rounded_rect(Affine.IDENTITY, (3 * q + 12, 3 * q + 12, 4 * q - 12, 4 * q - 20), Color.from_rgba8(20, 20, 20, 220), 6.0, 3.0)
+    s.draw_blurred_rounded_rect(Affine.rotate(0.2), (3 * q + 40, 2 * q - 20, 4 * q + 10, 2 * q + 10), Color.from_rgb8(200, 30, 90), 2.0, 1.2)
+    s.draw_blurred_rounded_rect_in(Circle((q / 2, q / 2), q / 3), Affine.IDENTITY, (4, 4, q - 4, q - 4), Color.from_rgba8(0, 0, 0, 160), 0.0, 5.0)
+    return s
