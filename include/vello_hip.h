@@ -22,6 +22,8 @@
  *   vello_hip_sync             queue.submit + device.poll                vello/src/wgpu_engine.rs:757
  *   vello_hip_set_frames_in_flight  back-to-back queue.submit without waiting  vello/src/wgpu_engine.rs:757
  *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
+ *   vello_hip_grow_pools /     "TODO: apply logic to determine whether   vello/src/lib.rs:762-764,
+ *   vello_hip_set_auto_grow    we need to rerun coarse" + pool sizes     vello_encoding/src/config.rs:398-408
  *   vello_hip_run_stages /     CpuShaderType::Present per-stage seam     vello/src/wgpu_engine.rs:57-61, :541-553,
  *   vello_hip_{read,write}_buffer  (CpuBinding byte buffers)             vello_shaders/src/cpu.rs:58-62
  *   vello_hip_set_profiling /  wgpu-profiler per-dispatch GPU timestamps vello/src/wgpu_engine.rs:570-588
@@ -151,6 +153,16 @@ int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params 
 int vello_hip_resize_image_atlas(vello_hip_ctx *ctx, uint32_t width, uint32_t height);
 int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const uint8_t *rgba8,
                           size_t stride /* bytes per source row; 0 = width*4 */);
+
+/* Robust dynamic memory.  vello_hip_grow_pools re-sizes every pool whose counter in `demand`
+ * (from vello_hip_get_bump / bump_out after VELLO_HIP_E_CAPACITY) exceeds it, with 25 % headroom, on all in-flight
+ * buffer sets; the caller then renders the frame again.  A stage that overflows stops the later stages
+ * (shared/bump.wgsl:5-9), so one frame may need several rounds.  Returns VELLO_HIP_E_INVALID when nothing had to
+ * grow.  With vello_hip_set_auto_grow(ctx, 1) the blocking vello_hip_render does these rounds itself and only
+ * reports VELLO_HIP_E_CAPACITY if the demand cannot be met. */
+int vello_hip_get_capacities(vello_hip_ctx *ctx, vello_hip_capacities *out);
+int vello_hip_grow_pools(vello_hip_ctx *ctx, const vello_hip_bump *demand, vello_hip_capacities *new_caps /* nullable */);
+int vello_hip_set_auto_grow(vello_hip_ctx *ctx, int enabled);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting
  * (wgpu_engine.rs:757); with n > 1 consecutive vello_hip_render_resident calls rotate over n private buffer

@@ -103,3 +103,40 @@ def test_emu_gradient_image_blur_brushes(emu_engine, aa):
     assert r.ramps is not None and r.atlas_size == 1024 and len(r.uploads) == 3
     compare_frame(emu_engine, r.packed, r.layout, 256, 256, WHITE, aa, f"emu_brushes_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
                   resolved=r)
+
+
+def test_emu_auto_grow_reruns_until_the_frame_fits(built):
+    # pools start far too small; robust mode grows lines -> seg_counts/segments -> ... round by round
+    # (a failed stage hides the demand of the later ones) and the final frame equals the oracle's
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        tiny = {"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 256, "bin_data": 512, "ptcl": 64 * 256 + 512, "blend_spill": 16}
+        eng = vello_amd.Engine(capacities=tiny)
+        packed, layout = workloads.clip_blend_scene().resolve()
+        img, bump = eng.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)
+        assert bump["failed"] != 0 and eng.sync() == -4
+        # manual protocol: get_bump -> grow_pools -> render again
+        rounds = 0
+        while bump["failed"] != 0:
+            assert eng.grow_pools(bump), bump
+            img, bump = eng.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)
+            rounds += 1
+            assert rounds < 8
+        assert rounds >= 2
+        o = Oracle()
+        o.set_scene(packed, layout, 256, 256, WHITE, int(AaConfig.Msaa8))
+        assert np.array_equal(img, o.render())
+        caps = eng.capacities()
+        assert caps["lines"] >= bump["lines"] and caps["segments"] >= caps["seg_counts"] >= bump["seg_counts"]
+        assert not eng.grow_pools(bump)          # nothing left to grow
+        # automatic: one blocking call
+        eng2 = vello_amd.Engine(capacities=tiny)
+        eng2.set_auto_grow(True)
+        img2, bump2 = eng2.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)
+        assert bump2["failed"] == 0 and np.array_equal(img2, img)
+    finally:
+        L._use_library(None)

@@ -171,6 +171,30 @@ def test_config_c4_mmark_reduced(gpu_engine):
     compare_frame(gpu_engine, packed, layout, 2048, 2048, WHITE, AaConfig.Msaa16, "gpu_mmark5k")
 
 
+def test_config_c4_mmark_50k_full_size(gpu_engine):
+    # BASELINE config C4 at full size: 50 000 mmark elements, 2048x2048, MSAA16 (64 bins)
+    packed, layout = workloads.mmark_scene().resolve()
+    img, ref, bump = compare_frame(gpu_engine, packed, layout, 2048, 2048, WHITE, AaConfig.Msaa16, "gpu_mmark50k")
+    assert bump["failed"] == 0
+
+
+def test_auto_grow_beyond_reference_pools(built):
+    # a scene that overflows the reference's fixed 2^21-line pool renders after the robust rounds
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    packed, layout = workloads.paris_like_scene(seed=0x5EED0011, n_paths=42000).resolve()
+    eng = vello_amd.Engine()
+    img, bump = eng.render(packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16)
+    assert bump["failed"] != 0 and bump["lines"] > (1 << 21)
+    eng.set_auto_grow(True)
+    img, bump = eng.render(packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16)
+    assert bump["failed"] == 0 and eng.capacities()["lines"] > (1 << 21)
+    o = Oracle(capacity_scale=2)
+    o.set_scene(packed, layout, 1600, 1600, WHITE, int(AaConfig.Msaa16))
+    assert np.array_equal(img, o.render())
+
+
 def test_frames_in_flight_match_oracle(built):
     # three frames of one resident scene in flight on three lanes, each with its own target and its own
     # params (size / base colour / AA): every one must equal the oracle's frame for those params

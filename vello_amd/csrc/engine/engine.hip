@@ -60,6 +60,7 @@ struct vello_hip_ctx {
     uint32_t n_ramps = 0;
     bool scene_resident = false;
     bool scene_brushes = false;
+    bool auto_grow = false;
     vello_hip_layout layout{};
     size_t scene_len = 0;
     uint32_t n_tag_words = 0, n_pathtag_parts = 0, n_draw_parts = 0;
@@ -597,15 +598,82 @@ int vello_hip_sync(vello_hip_ctx *c) {
 
 void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
 
+int vello_hip_get_capacities(vello_hip_ctx *c, vello_hip_capacities *out) {
+    if (!c || !out) return VELLO_HIP_E_INVALID;
+    *out = c->caps;
+    return VELLO_HIP_OK;
+}
+
+// The step the reference leaves as a TODO (lib.rs:753-764, "apply logic to determine whether we need to rerun
+// coarse"): size every pool whose counter exceeded it for the reported demand.  A stage that overflows stops the
+// stages behind it (bump.failed, shared/bump.wgsl:5-9), so a frame may need one call per overflowing stage.
+int vello_hip_grow_pools(vello_hip_ctx *c, const vello_hip_bump *demand, vello_hip_capacities *new_caps) {
+    if (!c || !demand) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    vello_hip_capacities d = c->caps;
+    bool grew = false;
+    // 25 % headroom, rounded up to 64 Ki elements; counters are u32, so is every pool
+    auto want = [&](uint32_t &cap, uint64_t need) {
+        if (need <= cap) return;
+        uint64_t n = need + need / 4u;
+        n = (n + 0xffffu) & ~(uint64_t)0xffffu;
+        if (n > 0xffff0000ull) n = 0xffff0000ull;
+        if (n > cap) {
+            cap = (uint32_t)n;
+            grew = true;
+        }
+    };
+    want(d.lines, demand->lines);
+    want(d.bin_data, (uint64_t)demand->binning + c->layout.bin_data_start);
+    want(d.tiles, demand->tile);
+    want(d.seg_counts, demand->seg_counts);
+    want(d.segments, demand->segments);
+    want(d.blend_spill, demand->blend);
+    if (c->have_cfg) {
+        uint64_t dyn_start = (uint64_t)c->cfg.width_in_tiles * c->cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
+        want(d.ptcl, dyn_start + demand->ptcl + PTCL_INCREMENT);
+    }
+    if (d.segments < d.seg_counts) {
+        d.segments = d.seg_counts;
+        grew = true;
+    }
+    if (new_caps) *new_caps = d;
+    if (!grew) {
+        c->last_error = "grow_pools: no counter exceeds its pool";
+        return VELLO_HIP_E_INVALID;
+    }
+    int r = sync_all(c);
+    if (r) return r;
+    c->caps = d;
+    for (auto &l : c->lanes)
+        if ((r = alloc_lane_pools(c, l))) return r;
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_set_auto_grow(vello_hip_ctx *c, int enabled) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    c->auto_grow = enabled != 0;
+    return VELLO_HIP_OK;
+}
+
 int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                      const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_rgba8, size_t out_stride,
                      int out_is_device, vello_hip_bump *bump_out) {
     if (!c || !params) return VELLO_HIP_E_INVALID;
     int r = vello_hip_upload_scene(c, scene, scene_len, layout, ramps, n_ramps);
     if (r) return r;
-    r = vello_hip_render_resident(c, params, out_is_device ? out_rgba8 : nullptr, out_stride);
-    if (r) return r;
-    int sync_r = vello_hip_sync(c);
+    int sync_r = VELLO_HIP_OK;
+    // robust mode: re-run with grown pools until the frame fits (each overflowing stage hides the demand of
+    // the stages behind it, so a handful of rounds at most)
+    for (int attempt = 0; attempt < 8; attempt++) {
+        r = vello_hip_render_resident(c, params, out_is_device ? out_rgba8 : nullptr, out_stride);
+        if (r) return r;
+        sync_r = vello_hip_sync(c);
+        if (sync_r != VELLO_HIP_E_CAPACITY || !c->auto_grow) break;
+        vello_hip_bump b;
+        if ((r = vello_hip_get_bump(c, &b))) return r;
+        if (vello_hip_grow_pools(c, &b, nullptr) != VELLO_HIP_OK) break;
+    }
     if (bump_out) {
         int br = vello_hip_get_bump(c, bump_out);
         if (br) return br;

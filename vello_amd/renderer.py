@@ -169,6 +169,19 @@ class Engine:
             self._check(r, "render")
         return out, b.as_dict()
 
+    def capacities(self):
+        c = Capacities()
+        self._check(self._lib.vello_hip_get_capacities(self._h, ctypes.byref(c)), "get_capacities")
+        return {k: getattr(c, k) for k, _ in Capacities._fields_}
+
+    def grow_pools(self, bump):
+        """vello_hip_grow_pools with a bump dict; returns True if any pool grew."""
+        b = Bump(*[bump[k] for k, _ in Bump._fields_])
+        return self._lib.vello_hip_grow_pools(self._h, ctypes.byref(b), None) == 0
+
+    def set_auto_grow(self, enabled=True):
+        self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
+
     def set_frames_in_flight(self, n):
         self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
 
