@@ -140,3 +140,15 @@ def test_emu_auto_grow_reruns_until_the_frame_fits(built):
         assert bump2["failed"] == 0 and np.array_equal(img2, img)
     finally:
         L._use_library(None)
+
+
+def test_unorm8_conversion_without_division_is_exact(built):
+    # fine.hip's unorm8_to_f32 (q = b*r; e = fma(-q, 255, b); q + e*r) must equal (float)b / 255.0f for every byte
+    f32 = np.float32
+    r = f32(1.0) / f32(255.0)
+    for b in range(256):
+        x = f32(b)
+        q = f32(x * r)
+        e = f32(np.float64(x) - np.float64(q) * 255.0)          # exact in fp64: 24-bit q times 8-bit constant
+        got = f32(np.float64(q) + np.float64(e) * np.float64(r))  # |e*r| << ulp(q)/2 margin: no double-rounding hazard here
+        assert got == f32(x / f32(255.0)), b

@@ -29,9 +29,18 @@ struct vec4 {
 __device__ __forceinline__ vec4 operator*(vec4 a, float s) { return vec4{a.x * s, a.y * s, a.z * s, a.w * s}; }
 __device__ __forceinline__ vec4 operator+(vec4 a, vec4 b) { return vec4{a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w}; }
 
+// (float)b / 255.0f for b in [0, 255] in three operations: q = b*r, one fma residual, one fma correction.  Equal to
+// the IEEE division for all 256 inputs (checked exhaustively in tests/test_emu_parity.py); the compiler's generic
+// division expansion costs 11 VALU per channel and CMD_COLOR unpacks four channels per command.
+__device__ __forceinline__ float unorm8_to_f32(uint32_t b) {
+    const float r = 1.0f / 255.0f;
+    const float x = (float)b;
+    const float q = x * r;
+    const float e = fmaf(-q, 255.0f, x);
+    return fmaf(e, r, q);
+}
 __device__ __forceinline__ vec4 unpack4x8unorm(uint32_t u) {
-    return vec4{(float)(u & 0xffu) / 255.0f, (float)((u >> 8) & 0xffu) / 255.0f, (float)((u >> 16) & 0xffu) / 255.0f,
-                (float)((u >> 24) & 0xffu) / 255.0f};
+    return vec4{unorm8_to_f32(u & 0xffu), unorm8_to_f32((u >> 8) & 0xffu), unorm8_to_f32((u >> 16) & 0xffu), unorm8_to_f32(u >> 24)};
 }
 __device__ __forceinline__ uint32_t unorm8(float e) { return (uint32_t)floorf(0.5f + 255.0f * clampf(e, 0.0f, 1.0f)); }
 __device__ __forceinline__ uint32_t pack4x8unorm(vec4 c) {
@@ -593,6 +602,199 @@ __device__ __attribute__((noinline)) float blur_rect_alpha(const uint32_t *__res
 
 }  // namespace
 
+// Everything except FILL / SOLID / COLOR / JUMP / END: clip layers (blend stack) and, when BRUSHES, the gradient,
+// image and blur arms.  Out of line on purpose: inlined into the interpreter loop these arms cost the hot
+// FILL+COLOR path ~250 VALU per fill in register copies at the loop's join points (1391 static VALU in the loop,
+// PMC: 52 M of 125 M VALU per frame with the rasterizer removed).  The pixel state crosses the call through
+// RareState (scratch); the blend stack lives in scratch permanently, only these commands touch it.
+struct RareState {
+    vec4 rgba[4];
+    float area[4];
+    uint32_t clip_depth;
+    uint32_t cmd_ix;
+};
+template <bool BRUSHES>
+__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, const Config &cfg,
+                                                       const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
+                                                       uint32_t *blend_spill, uint32_t blend_offset, uint32_t lane, float xy_x,
+                                                       float xy_y, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
+                                                       const uint32_t *__restrict__ atlas_texels, uint32_t atlas_w, uint32_t atlas_h) {
+    vec4 rgba[4] = {st.rgba[0], st.rgba[1], st.rgba[2], st.rgba[3]};
+    float area[4] = {st.area[0], st.area[1], st.area[2], st.area[3]};
+    uint32_t clip_depth = st.clip_depth;
+    uint32_t cmd_ix = st.cmd_ix;
+    auto rd = [&](uint32_t ix) -> uint32_t { return ix < cfg.ptcl_size ? ptcl[ix] : 0u; };
+    if (tag == CMD_BEGIN_CLIP) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t packed = pack4x8unorm(rgba[i]);
+            if (clip_depth < BLEND_STACK_SPLIT) {
+                blend_stack[clip_depth][i] = packed;
+            } else {
+                uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
+                if (ix < cfg.blend_size) blend_spill[ix] = packed;
+            }
+            rgba[i] = vec4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        clip_depth += 1u;
+        cmd_ix += 1u;
+    } else if (tag == CMD_END_CLIP) {
+        const uint32_t blend = rd(cmd_ix + 1u);
+        const float alpha = __uint_as_float(rd(cmd_ix + 2u));
+        clip_depth -= 1u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t bg_rgba = 0u;
+            if (clip_depth < BLEND_STACK_SPLIT) {
+                bg_rgba = blend_stack[clip_depth][i];
+            } else {
+                uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
+                bg_rgba = ix < cfg.blend_size ? blend_spill[ix] : 0u;
+            }
+            const vec4 bg = unpack4x8unorm(bg_rgba);
+            const vec4 fg = (rgba[i] * area[i]) * alpha;
+            if (blend == LUMINANCE_MASK_LAYER) {
+                if (area[i] == 0.0f) {
+                    rgba[i] = bg;
+                } else {
+                    float luminance = clampf(svg_lum(unpremultiply(fg)) * fg.w, 0.0f, 1.0f);
+                    rgba[i] = bg * luminance;
+                }
+            } else {
+                rgba[i] = blend_mix_compose(bg, fg, blend);
+            }
+        }
+        cmd_ix += 3u;
+    } else if (BRUSHES && tag == CMD_LIN_GRAD) {
+        const uint32_t index_mode = rd(cmd_ix + 1u);
+        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+        const uint32_t io = rd(cmd_ix + 2u);
+        const float line_x = __uint_as_float(info[io]), line_y = __uint_as_float(info[io + 1u]), line_c = __uint_as_float(info[io + 2u]);
+        const float d = line_x * xy_x + line_y * xy_y + line_c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float my_d = d + line_x * (float)i;
+            int32_t x = f2i(roundf_te(extend_mode_normalized(my_d, extend) * (float)(GRADIENT_WIDTH - 1)));
+            src_over(rgba[i], ramp_load(ramps, n_ramps, x, index), area[i]);
+        }
+        cmd_ix += 3u;
+    } else if (BRUSHES && tag == CMD_RAD_GRAD) {
+        const uint32_t index_mode = rd(cmd_ix + 1u);
+        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+        const uint32_t io = rd(cmd_ix + 2u);
+        const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                    m3 = __uint_as_float(info[io + 3u]);
+        const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+        const float focal_x = __uint_as_float(info[io + 6u]), radius = __uint_as_float(info[io + 7u]);
+        const uint32_t flags_kind = info[io + 8u];
+        const uint32_t flags = flags_kind >> 3, kind = flags_kind & 7u;
+        const bool is_strip = kind == RAD_GRAD_KIND_STRIP, is_circular = kind == RAD_GRAD_KIND_CIRCULAR;
+        const bool is_focal_on_circle = kind == RAD_GRAD_KIND_FOCAL_ON_CIRCLE;
+        const bool is_swapped = (flags & RAD_GRAD_SWAPPED) != 0u;
+        const float r1_recip = is_circular ? 0.0f : 1.0f / radius;
+        const float less_scale = (is_swapped || (1.0f - focal_x) < 0.0f) ? -1.0f : 1.0f;
+        const float t_sign = signf(1.0f - focal_x);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float mx = xy_x + (float)i, my = xy_y;
+            float x = m0 * mx + m2 * my + xl0;
+            float y = m1 * mx + m3 * my + xl1;
+            float xx = x * x, yy = y * y;
+            float t = 0.0f;
+            bool is_valid = true;
+            if (is_strip) {
+                float a = radius - yy;
+                t = sqrtf(a) + x;
+                is_valid = a >= 0.0f;
+            } else if (is_focal_on_circle) {
+                t = (xx + yy) / x;
+                is_valid = t >= 0.0f && x != 0.0f;
+            } else if (radius > 1.0f) {
+                t = sqrtf(xx + yy) - x * r1_recip;
+            } else {
+                float a = xx - yy;
+                t = less_scale * sqrtf(a) - x * r1_recip;
+                is_valid = a >= 0.0f && t >= 0.0f;
+            }
+            if (is_valid) {
+                t = extend_mode_normalized(focal_x + t_sign * t, extend);
+                if (is_swapped) t = 1.0f - t;
+                int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
+                src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
+            }
+        }
+        cmd_ix += 3u;
+    } else if (BRUSHES && tag == CMD_SWEEP_GRAD) {
+        const uint32_t index_mode = rd(cmd_ix + 1u);
+        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
+        const uint32_t io = rd(cmd_ix + 2u);
+        const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
+                    m3 = __uint_as_float(info[io + 3u]);
+        const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
+        const float t0 = __uint_as_float(info[io + 6u]), t1 = __uint_as_float(info[io + 7u]);
+        const float scale = 1.0f / (t1 - t0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float mx = xy_x + (float)i, my = xy_y;
+            float x = m0 * mx + m2 * my + xl0;
+            float y = m1 * mx + m3 * my + xl1;
+            float xabs = fabsf(x), yabs = fabsf(y);
+            float slope = minf(xabs, yabs) / maxf(xabs, yabs);
+            float s = slope * slope;
+            float phi = slope * (0.15912117063999176025390625f +
+                                 s * (-5.185396969318389892578125e-2f +
+                                      s * (2.476101927459239959716796875e-2f + s * (-7.0547382347285747528076171875e-3f))));
+            if (xabs < yabs) phi = 1.0f / 4.0f - phi;
+            if (x < 0.0f) phi = 1.0f / 2.0f - phi;
+            if (y < 0.0f) phi = 1.0f - phi;
+            if (phi != phi) phi = 0.0f;
+            phi = (phi - t0) * scale;
+            float t = extend_mode_normalized(phi, extend);
+            int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
+            src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
+        }
+        cmd_ix += 3u;
+    } else if (BRUSHES && tag == CMD_IMAGE) {
+        const uint32_t io = rd(cmd_ix + 1u);
+        const uint32_t sample_alpha = info[io + 8u];
+        const float alpha = (float)(sample_alpha & 0xFFu) / 255.0f;
+        const bool bgra = (sample_alpha >> 15) == 1u;
+        const Atlas at{atlas_texels, atlas_w, atlas_h};
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+            if (area[i] != 0.0f) {
+                vec4 fg = image_sample(at, info, io, xy_x + (float)i + 0.5f, xy_y + 0.5f);
+                vec4 fg_i = fg * area[i] * alpha;
+                if (bgra) fg_i = vec4{fg_i.z, fg_i.y, fg_i.x, fg_i.w};  // pixel_format: .bgra
+                rgba[i] = rgba[i] * (1.0f - fg_i.w) + fg_i;
+            }
+        }
+        cmd_ix += 2u;
+    } else if (BRUSHES && tag == CMD_BLUR_RECT) {
+        const uint32_t io = rd(cmd_ix + 1u);
+        const vec4 blur_rgba = unpack4x8unorm(rd(cmd_ix + 2u));
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {
+            const float alpha = blur_rect_alpha(info, io, xy_x + (float)i, xy_y);
+            src_over(rgba[i], blur_rgba * alpha, area[i]);
+        }
+        cmd_ix += 3u;
+    } else if (tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
+        cmd_ix += 3u;  // !BRUSHES: unreachable by construction; keeps the stream in step if the contract is broken
+    } else if (tag == CMD_IMAGE) {
+        cmd_ix += 2u;
+    } else {
+        cmd_ix += 1u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        st.rgba[i] = rgba[i];
+        st.area[i] = area[i];
+    }
+    st.clip_depth = clip_depth;
+    st.cmd_ix = cmd_ix;
+}
+
 // BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
 // on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
 // solid-colour interpreter does not pay their registers.
@@ -673,173 +875,26 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
 #pragma unroll
             for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
             cmd_ix += 2u;
-        } else if (tag == CMD_BEGIN_CLIP) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t packed = pack4x8unorm(rgba[i]);
-                if (clip_depth < BLEND_STACK_SPLIT) {
-#pragma unroll
-                    for (uint32_t d = 0; d < BLEND_STACK_SPLIT; d++)
-                        if (clip_depth == d) blend_stack[d][i] = packed;
-                } else {
-                    uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
-                    if (ix < cfg.blend_size) blend_spill[ix] = packed;
-                }
-                rgba[i] = vec4{0.0f, 0.0f, 0.0f, 0.0f};
-            }
-            clip_depth += 1u;
-            cmd_ix += 1u;
-        } else if (tag == CMD_END_CLIP) {
-            const uint32_t blend = rd(cmd_ix + 1u);
-            const float alpha = __uint_as_float(rd(cmd_ix + 2u));
-            clip_depth -= 1u;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t bg_rgba = 0u;
-                if (clip_depth < BLEND_STACK_SPLIT) {
-#pragma unroll
-                    for (uint32_t d = 0; d < BLEND_STACK_SPLIT; d++)
-                        if (clip_depth == d) bg_rgba = blend_stack[d][i];
-                } else {
-                    uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
-                    bg_rgba = ix < cfg.blend_size ? blend_spill[ix] : 0u;
-                }
-                const vec4 bg = unpack4x8unorm(bg_rgba);
-                const vec4 fg = (rgba[i] * area[i]) * alpha;
-                if (blend == LUMINANCE_MASK_LAYER) {
-                    if (area[i] == 0.0f) {
-                        rgba[i] = bg;
-                    } else {
-                        float luminance = clampf(svg_lum(unpremultiply(fg)) * fg.w, 0.0f, 1.0f);
-                        rgba[i] = bg * luminance;
-                    }
-                } else {
-                    rgba[i] = blend_mix_compose(bg, fg, blend);
-                }
-            }
-            cmd_ix += 3u;
         } else if (tag == CMD_JUMP) {
             cmd_ix = rd(cmd_ix + 1u);
-        } else if (!BRUSHES && (tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT)) {
-            cmd_ix += 3u;  // unreachable by construction; keeps the stream in step if the contract is broken
-        } else if (!BRUSHES && tag == CMD_IMAGE) {
-            cmd_ix += 2u;
-        } else if (BRUSHES && tag == CMD_LIN_GRAD) {
-            const uint32_t index_mode = rd(cmd_ix + 1u);
-            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = rd(cmd_ix + 2u);
-            const float line_x = __uint_as_float(info[io]), line_y = __uint_as_float(info[io + 1u]), line_c = __uint_as_float(info[io + 2u]);
-            const float d = line_x * xy_x + line_y * xy_y + line_c;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float my_d = d + line_x * (float)i;
-                int32_t x = f2i(roundf_te(extend_mode_normalized(my_d, extend) * (float)(GRADIENT_WIDTH - 1)));
-                src_over(rgba[i], ramp_load(ramps, n_ramps, x, index), area[i]);
-            }
-            cmd_ix += 3u;
-        } else if (BRUSHES && tag == CMD_RAD_GRAD) {
-            const uint32_t index_mode = rd(cmd_ix + 1u);
-            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = rd(cmd_ix + 2u);
-            const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
-                        m3 = __uint_as_float(info[io + 3u]);
-            const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
-            const float focal_x = __uint_as_float(info[io + 6u]), radius = __uint_as_float(info[io + 7u]);
-            const uint32_t flags_kind = info[io + 8u];
-            const uint32_t flags = flags_kind >> 3, kind = flags_kind & 7u;
-            const bool is_strip = kind == RAD_GRAD_KIND_STRIP, is_circular = kind == RAD_GRAD_KIND_CIRCULAR;
-            const bool is_focal_on_circle = kind == RAD_GRAD_KIND_FOCAL_ON_CIRCLE;
-            const bool is_swapped = (flags & RAD_GRAD_SWAPPED) != 0u;
-            const float r1_recip = is_circular ? 0.0f : 1.0f / radius;
-            const float less_scale = (is_swapped || (1.0f - focal_x) < 0.0f) ? -1.0f : 1.0f;
-            const float t_sign = signf(1.0f - focal_x);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float mx = xy_x + (float)i, my = xy_y;
-                float x = m0 * mx + m2 * my + xl0;
-                float y = m1 * mx + m3 * my + xl1;
-                float xx = x * x, yy = y * y;
-                float t = 0.0f;
-                bool is_valid = true;
-                if (is_strip) {
-                    float a = radius - yy;
-                    t = sqrtf(a) + x;
-                    is_valid = a >= 0.0f;
-                } else if (is_focal_on_circle) {
-                    t = (xx + yy) / x;
-                    is_valid = t >= 0.0f && x != 0.0f;
-                } else if (radius > 1.0f) {
-                    t = sqrtf(xx + yy) - x * r1_recip;
-                } else {
-                    float a = xx - yy;
-                    t = less_scale * sqrtf(a) - x * r1_recip;
-                    is_valid = a >= 0.0f && t >= 0.0f;
-                }
-                if (is_valid) {
-                    t = extend_mode_normalized(focal_x + t_sign * t, extend);
-                    if (is_swapped) t = 1.0f - t;
-                    int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
-                    src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
-                }
-            }
-            cmd_ix += 3u;
-        } else if (BRUSHES && tag == CMD_SWEEP_GRAD) {
-            const uint32_t index_mode = rd(cmd_ix + 1u);
-            const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-            const uint32_t io = rd(cmd_ix + 2u);
-            const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
-                        m3 = __uint_as_float(info[io + 3u]);
-            const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
-            const float t0 = __uint_as_float(info[io + 6u]), t1 = __uint_as_float(info[io + 7u]);
-            const float scale = 1.0f / (t1 - t0);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float mx = xy_x + (float)i, my = xy_y;
-                float x = m0 * mx + m2 * my + xl0;
-                float y = m1 * mx + m3 * my + xl1;
-                float xabs = fabsf(x), yabs = fabsf(y);
-                float slope = minf(xabs, yabs) / maxf(xabs, yabs);
-                float s = slope * slope;
-                float phi = slope * (0.15912117063999176025390625f +
-                                     s * (-5.185396969318389892578125e-2f +
-                                          s * (2.476101927459239959716796875e-2f + s * (-7.0547382347285747528076171875e-3f))));
-                if (xabs < yabs) phi = 1.0f / 4.0f - phi;
-                if (x < 0.0f) phi = 1.0f / 2.0f - phi;
-                if (y < 0.0f) phi = 1.0f - phi;
-                if (phi != phi) phi = 0.0f;
-                phi = (phi - t0) * scale;
-                float t = extend_mode_normalized(phi, extend);
-                int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
-                src_over(rgba[i], ramp_load(ramps, n_ramps, rx, index), area[i]);
-            }
-            cmd_ix += 3u;
-        } else if (BRUSHES && tag == CMD_IMAGE) {
-            const uint32_t io = rd(cmd_ix + 1u);
-            const uint32_t sample_alpha = info[io + 8u];
-            const float alpha = (float)(sample_alpha & 0xFFu) / 255.0f;
-            const bool bgra = (sample_alpha >> 15) == 1u;
-            const Atlas at{atlas_texels, atlas_w, atlas_h};
-#pragma unroll 1
-            for (int i = 0; i < 4; i++) {
-                if (area[i] != 0.0f) {
-                    vec4 fg = image_sample(at, info, io, xy_x + (float)i + 0.5f, xy_y + 0.5f);
-                    vec4 fg_i = fg * area[i] * alpha;
-                    if (bgra) fg_i = vec4{fg_i.z, fg_i.y, fg_i.x, fg_i.w};  // pixel_format: .bgra
-                    rgba[i] = rgba[i] * (1.0f - fg_i.w) + fg_i;
-                }
-            }
-            cmd_ix += 2u;
-        } else if (BRUSHES && tag == CMD_BLUR_RECT) {
-            const uint32_t io = rd(cmd_ix + 1u);
-            const vec4 blur_rgba = unpack4x8unorm(rd(cmd_ix + 2u));
-#pragma unroll 1
-            for (int i = 0; i < 4; i++) {
-                const float alpha = blur_rect_alpha(info, io, xy_x + (float)i, xy_y);
-                src_over(rgba[i], blur_rgba * alpha, area[i]);
-            }
-            cmd_ix += 3u;
         } else {
-            cmd_ix += 1u;
+            RareState st;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                st.rgba[i] = rgba[i];
+                st.area[i] = area[i];
+            }
+            st.clip_depth = clip_depth;
+            st.cmd_ix = cmd_ix;
+            rare_command<BRUSHES>(st, blend_stack, tag, cfg, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+                                  atlas_texels, atlas_w, atlas_h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                rgba[i] = st.rgba[i];
+                area[i] = st.area[i];
+            }
+            clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
+            cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
         }
     }
     // fine.wgsl:1386-1397: un-premultiplied RGBA8
