@@ -152,3 +152,11 @@ def test_unorm8_conversion_without_division_is_exact(built):
         e = f32(np.float64(x) - np.float64(q) * 255.0)          # exact in fp64: 24-bit q times 8-bit constant
         got = f32(np.float64(q) + np.float64(e) * np.float64(r))  # |e*r| << ulp(q)/2 margin: no double-rounding hazard here
         assert got == f32(x / f32(255.0)), b
+
+
+def test_emu_flatten_staging_overflow(emu_engine):
+    # one flatten workgroup producing more lines than its LDS staging area (3072): the overflow pieces are written
+    # straight to the soup; counts, multiset of lines and the image must not change
+    packed, layout = workloads.heavy_strokes_scene().resolve()
+    img, ref, bump = compare_frame(emu_engine, packed, layout, 1024, 1024, BLACK, AaConfig.Msaa8, "emu_heavy_strokes")
+    assert bump["lines"] > 3072

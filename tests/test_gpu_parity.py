@@ -249,3 +249,10 @@ def test_brushes_at_scale(gpu_engine):
     s.append(base, Affine.translate(60, -40) * Affine.rotate(0.15) * Affine.scale(3.0))
     r = vello_amd.Resolver().resolve(s)
     compare_frame(gpu_engine, r.packed, r.layout, 800, 800, BLACK, AaConfig.Msaa16, "gpu_brushes_zoom", resolved=r)
+
+
+def test_flatten_staging_overflow(gpu_engine):
+    # k_flatten's LDS staging area holds 3072 lines per workgroup; this scene puts 3728 into one workgroup
+    packed, layout = workloads.heavy_strokes_scene().resolve()
+    img, ref, bump = compare_frame(gpu_engine, packed, layout, 1024, 1024, BLACK, AaConfig.Msaa16, "gpu_heavy_strokes")
+    assert bump["lines"] > 3072

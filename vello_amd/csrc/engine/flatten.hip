@@ -4,12 +4,12 @@
 //
 // gfx950 design.  The reference bumps `bump.lines` with one global atomic per emitted line; on
 // MI355X same-address device-scope atomics retire at ~12 ns each (MI355X_MICROARCH.md "dequeue"
-// row), i.e. ~18 ms for a paris-class frame.  Here each workgroup (256 threads x 4 tags) runs the
-// flattener twice over its 1024 tags: a COUNT pass (no stores, no position math), a wave64 shuffle
-// scan of the per-thread counts, ONE atomicAdd for the whole workgroup, then the EMIT pass writes
-// every thread's lines into its own contiguous slice.  Line order is therefore deterministic
-// inside a workgroup; across workgroups it follows atomic order exactly as in the reference
-// (the line soup is an unordered set, flatten.wgsl:775-798).
+// row), i.e. ~18 ms for a paris-class frame.  Here each workgroup (256 threads x 4 tags) flattens its
+// 1024 tags ONCE into an LDS staging area (one LDS atomic per curve piece reserves its slots), then
+// issues ONE atomicAdd for the whole workgroup and copies the staged lines out coalesced.  Pieces
+// that do not fit the 3072-line staging area go to the soup directly (one global atomic per piece).
+// Line order inside a workgroup follows LDS atomic order, across workgroups global atomic order, as
+// in the reference (the line soup is an unordered set, flatten.wgsl:775-798).
 #include "engine.h"
 
 namespace vk {
@@ -36,35 +36,54 @@ __device__ __forceinline__ vec2 xf_apply(const Xform &t, vec2 p) {
     return v2(px, py);
 }
 
+// Lines are staged in LDS and leave the workgroup in one coalesced copy (see k_flatten).  `alloc` reserves the n
+// slots of one curve piece with ONE LDS atomic; a piece that does not fit the staging area any more goes straight
+// to the soup with one global atomic for the piece (bit 31 of the index marks "global").
+constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
+constexpr uint32_t LINE_IX_GLOBAL = 0x80000000u;
+struct FlattenShared {
+    uint32_t path_ix[FLATTEN_LDS_LINES];
+    float p0x[FLATTEN_LDS_LINES], p0y[FLATTEN_LDS_LINES], p1x[FLATTEN_LDS_LINES], p1y[FLATTEN_LDS_LINES];
+    uint32_t count;    // slots handed out (may run past the capacity)
+    uint32_t lds_end;  // first slot of the first piece that did not fit (dense prefix [0, lds_end) is staged)
+    uint32_t base;
+};
+
 template <bool EMIT>
 struct Emitter {
-    uint32_t next;      // next line index of this thread's slice (EMIT) / running count (COUNT)
     float bx0, by0, bx1, by1;
     LineSoup *lines;
     uint32_t lines_size;
+    Bump *bump;
+    FlattenShared *sh;
 
     __device__ __forceinline__ uint32_t alloc(uint32_t n) {
-        uint32_t r = next;
-        next += n;
-        return r;
+        uint32_t slot = atomicAdd(&sh->count, n);
+        if (slot + n <= FLATTEN_LDS_LINES) return slot;
+        atomicMin(&sh->lds_end, slot);
+        return atomicAdd(&bump->lines, n) | LINE_IX_GLOBAL;
     }
     // flatten.wgsl:766-773
     __device__ __forceinline__ void write(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1) {
-        if constexpr (EMIT) {
-            bx0 = minf(bx0, minf(p0.x, p1.x));
-            by0 = minf(by0, minf(p0.y, p1.y));
-            bx1 = maxf(bx1, maxf(p0.x, p1.x));
-            by1 = maxf(by1, maxf(p0.y, p1.y));
+        bx0 = minf(bx0, minf(p0.x, p1.x));
+        by0 = minf(by0, minf(p0.y, p1.y));
+        bx1 = maxf(bx1, maxf(p0.x, p1.x));
+        by1 = maxf(by1, maxf(p0.y, p1.y));
+        if (ix & LINE_IX_GLOBAL) {
+            ix &= ~LINE_IX_GLOBAL;
             if (ix < lines_size) {
                 LineSoup l;
                 l.path_ix = path_ix; l.pad = 0u;
                 l.p0x = p0.x; l.p0y = p0.y; l.p1x = p1.x; l.p1y = p1.y;
                 lines[ix] = l;
             }
+        } else {
+            sh->path_ix[ix] = path_ix;
+            sh->p0x[ix] = p0.x; sh->p0y[ix] = p0.y; sh->p1x[ix] = p1.x; sh->p1y[ix] = p1.y;
         }
     }
     __device__ __forceinline__ void write_xf(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1, const Xform &t) {
-        if constexpr (EMIT) write(ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
+        write(ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
     }
 };
 
@@ -736,48 +755,27 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 __global__ void __launch_bounds__(256, 2) k_flatten(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                     const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes, Bump *bump,
                                                     LineSoup *lines) {
-    __shared__ uint32_t sh_scan[4];
-    __shared__ uint32_t sh_base;
+    __shared__ FlattenShared sh;
     const uint32_t tid = threadIdx.x;
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
     // a path are of one kind, so waves stay convergent and segment reads coalesce.  (Giving each thread 4
     // consecutive tags instead measured 1.7x slower on MI355X.)
     const uint32_t tag0 = blockIdx.x * FLATTEN_BLOCK_TAGS + tid;
-
-    // COUNT pass
-    uint32_t cnt[FLATTEN_TAGS_PER_THREAD];
-#pragma unroll 1
-    for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
-        Emitter<false> c;
-        c.next = 0u;
-        c.lines = nullptr;
-        c.lines_size = 0u;
-        uint32_t ix = tag0 + j * 256u;
-        if (ix < n_tags) flatten_tag<false>(c, cfg, scene, tag_monoids, path_bboxes, ix);
-        cnt[j] = c.next;
+    if (tid == 0u) {
+        sh.count = 0u;
+        sh.lds_end = 0xffffffffu;
     }
-    // Offsets in TAG order (tag index = j * 256 + tid inside the workgroup): the workgroup's lines land in
-    // the soup in path order, which is what gives path_count's tile atomics their run locality.
-    uint32_t start[FLATTEN_TAGS_PER_THREAD];
-    uint32_t running = 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
-        uint32_t total_j;
-        uint32_t incl = block256_incl_scan_u32(cnt[j], sh_scan, &total_j);
-        start[j] = running + (incl - cnt[j]);
-        running += total_j;
-    }
-    if (tid == 0u) sh_base = running ? atomicAdd(&bump->lines, running) : 0u;
     __syncthreads();
-    const uint32_t base = sh_base;
 
-    // EMIT pass
+    // ONE pass over the tags (the first version ran the flattener twice, COUNT then EMIT, to learn the slice
+    // sizes before writing; the fp64-heavy subdivision was paid twice): lines go to the LDS staging area.
 #pragma unroll 1
     for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
         Emitter<true> em;
-        em.next = base + start[j];
         em.lines = lines;
         em.lines_size = cfg.lines_size;
+        em.bump = bump;
+        em.sh = &sh;
         uint32_t ix = tag0 + j * 256u;
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
@@ -789,6 +787,22 @@ __global__ void __launch_bounds__(256, 2) k_flatten(Config cfg, uint32_t n_tags,
             }
         }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)(tid & 63u));
+    }
+    __syncthreads();
+    // ONE atomicAdd(bump.lines) for the staged lines of the workgroup (the reference issues one per line), then a
+    // coalesced copy: thread i writes the 24-byte record i.
+    const uint32_t n_lds = minu(sh.count, sh.lds_end);
+    if (tid == 0u) sh.base = n_lds ? atomicAdd(&bump->lines, n_lds) : 0u;
+    __syncthreads();
+    const uint32_t base = sh.base;
+    for (uint32_t i = tid; i < n_lds; i += 256u) {
+        uint32_t o = base + i;
+        if (o < cfg.lines_size) {
+            LineSoup l;
+            l.path_ix = sh.path_ix[i]; l.pad = 0u;
+            l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
+            lines[o] = l;
+        }
     }
 }
 

@@ -8,5 +8,5 @@ concrete, seeded, synthetic inputs.  Harness code, not a product feature.
   C5  8 x C3 with seeds 0x5EED0001..8, one per GPU (bench.py --gpus 8)
 """
 from .scenes import (circle_scene, smoke_circle_scene, smoke_square_scene, paris_like_scene, mmark_scene,
-                     random_test_scene, clip_blend_scene, stroke_styles_scene, brushes_scene)
+                     random_test_scene, clip_blend_scene, stroke_styles_scene, brushes_scene, heavy_strokes_scene)
 from .pico_svg import load_svg, tiger_scene

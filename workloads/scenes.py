@@ -303,3 +303,13 @@ def brushes_scene(size=256.0):
     s.draw_blurred_rounded_rect(Affine.rotate(0.2), (3 * q + 40, 2 * q - 20, 4 * q + 10, 2 * q + 10), Color.from_rgb8(200, 30, 90), 2.0, 1.2)
     s.draw_blurred_rounded_rect_in(Circle((q / 2, q / 2), q / 3), Affine.IDENTITY, (4, 4, q - 4, q - 4), Color.from_rgba8(0, 0, 0, 160), 0.0, 5.0)
     return s
+
+
+def heavy_strokes_scene():
+    """169 path tags (ONE flatten workgroup) that expand to 3728 lines: wide round strokes of large circles.  Exceeds the
+    3072-line LDS staging area of k_flatten, so the tail pieces take the direct-to-soup route."""
+    s = Scene()
+    for i in range(24):
+        s.stroke(Stroke(40.0 + i), Affine.IDENTITY, Color.from_rgba8(20 * i % 255, 100, 200, 200), None,
+                 Circle((512 + 3 * i, 512 - 2 * i), 100 + 15 * i))
+    return s
