@@ -119,158 +119,178 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
 }
 
 // ---------------- MSAA (fine.wgsl:146-709) ----------------
+// The reference rasterizes one fill at a time: count pixel crossings per segment, prefix-sum, one thread per crossing
+// ("item") computes a sample mask and bumps packed winding counters in workgroup memory, then every thread resolves
+// its 4 pixels.  On the paris-like scene a tile holds ~13 fills of ~8 segments / ~30 items, so a wave64 runs the
+// 275-instruction item pass at <50 % lane use 13 times, each time behind the same chain of dependent latencies
+// (segment load -> count -> scan -> search -> LUT load -> LDS atomics -> resolve).  Here the arithmetic of fine.wgsl
+// is split into three pure pieces -- ms_item (crossing -> 28-bit record), ms_apply (record -> counter atomics),
+// ms_resolve -- and up to MS_BATCH_FILLS consecutive fills of the command list are batched: one segment load,
+// one count/scan, one dense item pass writing records to LDS; each FILL command then only replays its records
+// (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
+constexpr uint32_t MS_BATCH_FILLS = 8u;     // fills per batch (their segments must fit one 64-lane load)
+constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
+constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
+
+struct FineBatch {
+    uint32_t item[MS_ITEM_CAP];
+    uint32_t seg_slot[64];                     // fill slot of each staged segment
+    uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
+    uint32_t item_end[MS_BATCH_FILLS + 1u];    // item range of slot k = [item_end[k], item_end[k + 1])
+    uint32_t rule_backdrop[MS_BATCH_FILLS][2];
+};
+
+// One pixel crossing of segment `sg` (fine.wgsl:222-330): which pixel, the 8/16-bit sample mask from the LUT, and the
+// flags the accumulation needs.  Pure function of its arguments.
 template <int AA>
-__device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
-                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4], const Segment &first) {
+__device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, bool last_pixel, bool even_odd,
+                                            const uint32_t *__restrict__ mask_lut) {
     constexpr bool MSAA16 = AA == 2;
     constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
-    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
     constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
     constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
-    const uint32_t n_segs = fill.size_and_rule >> 1;
-    const uint32_t lx = lane & 3u, ly = lane >> 2;
-    __syncthreads();
-    if (!even_odd) {
-        if (lane < 4u) sh.winding_y[lane] = 0x80808080u;
-        sh.winding[lane] = 0x80808080u;
-#pragma unroll
-        for (uint32_t i = 0; i < PIXELS_PER_THREAD * SWPP; i++) sh_samples[i * 64u + lane] = 0x80808080u;
+    // line setup, fine.wgsl:236-261
+    const bool is_down = sg.p1y >= sg.p0y;
+    const vec2 xy0 = is_down ? v2(sg.p0x, sg.p0y) : v2(sg.p1x, sg.p1y);
+    const vec2 xy1 = is_down ? v2(sg.p1x, sg.p1y) : v2(sg.p0x, sg.p0y);
+    const float dx = fabsf(xy1.x - xy0.x);
+    const float dy = xy1.y - xy0.y;
+    const float idxdy = 1.0f / (dx + dy);
+    float a = dx * idxdy;
+    const bool is_positive_slope = xy1.x >= xy0.x;
+    const float x_sign = is_positive_slope ? 1.0f : -1.0f;
+    const float xt0 = floorf(xy0.x * x_sign);
+    const float c = xy0.x * x_sign - xt0;
+    const float y0i = floorf(xy0.y);
+    const float ytop = y0i + 1.0f;
+    const float b = minf((dy * c + dx * (ytop - xy0.y)) * idxdy, ONE_MINUS_ULP);
+    const uint32_t count_x = span(xy0.x, xy1.x) - 1u;
+    const uint32_t cnt = count_x + span(xy0.y, xy1.y);
+    const float robust_err = floorf(a * ((float)cnt - 1.0f) + b) - (float)count_x;
+    if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
+    const int32_t x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+    const float zf = a * (float)sub_ix + b;
+    const float z = floorf(zf);
+    const int32_t x = x0i + f2i(x_sign * z);
+    const int32_t y = f2i(y0i) + (int32_t)sub_ix - f2i(z);
+    bool is_delta, is_bump;
+    const float zp = floorf(a * (float)(sub_ix - 1u) + b);
+    if (sub_ix == 0u) {
+        is_delta = y0i == xy0.y;
+        is_bump = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
     } else {
-        if (lane == 0u) sh.winding_y[0] = 0u;
-        if (lane < 16u) sh.winding[lane] = 0u;
+        is_delta = z == zp;
+        is_bump = is_positive_slope && !is_delta;
+    }
+    const uint32_t pix_ix = (uint32_t)y * TILE_WIDTH + (uint32_t)x;
+    const bool delta_ok = (uint32_t)x < TILE_WIDTH - 1u && (uint32_t)y < TILE_HEIGHT && is_delta;
+    const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
+    const float half_height = (float)(MASK_HEIGHT / 2u);
+    const float mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
+    const float mask_col = floorf((zf - z) * (float)MASK_WIDTH);
+    const uint32_t mask_ix = mask_block + f2u(mask_row + mask_col);
+    uint32_t mask;
+    if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
+    else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
+    if (sub_ix == 0u && !is_bump) {
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy0.y - (float)y)));
+        mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
+    }
+    if (last_pixel && xy1.x != 0.0f) {
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy1.y - (float)y)));
+        mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
+    }
+    // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
+    return (pix_ix & 0xffu) | ((mask & FULL) << 8) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) |
+           (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
+}
+
+// The counter updates of one crossing (fine.wgsl:262-270, :331-360).
+template <int AA>
+__device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *winding, uint32_t *sh_samples) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const uint32_t pix_ix = rec & 0xffu;
+    const bool is_down = (rec & REC_IS_DOWN) != 0u, is_bump = (rec & REC_IS_BUMP) != 0u;
+    if (rec & REC_DELTA_OK) {
+        if (!even_odd) {
+            uint32_t delta_pix = pix_ix + 1u;
+            uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
+            atomicAdd(&winding[delta_pix >> 2], d);
+        } else {
+            atomicXor(&winding[pix_ix >> 4], 2u << (pix_ix & 15u));
+        }
+    }
+    if (!(rec & REC_PIX_VALID)) return;
+    uint32_t mask = (rec >> 8) & FULL;
+    // sample words are stored transposed: logical word w of pixel p lives at ((p & 3) * SWPP + w) * 64 + (p >> 2),
+    // so that the words of a pixel and of its x-neighbours land in different banks
+    if (even_odd) {
+        if (is_bump) mask ^= FULL;
+        atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
+        return;
+    }
+    const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
+    constexpr uint32_t NH = MSAA16 ? 2u : 1u;
 #pragma unroll
+    for (uint32_t h = 0; h < NH; h++) {
+        uint32_t m8 = (mask >> (8u * h)) & 0xffu;
+        uint32_t m_a = m8 ^ (m8 << 7);
+        uint32_t m_b = m_a ^ (m_a << 14);
+        uint32_t e0 = m_b & 0x1010101u;
+        uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
+        uint32_t e1 = (m_b >> 4) & 0x1010101u;
+        uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
+        if (is_bump) {
+            s0 += bump_delta;
+            s1 += bump_delta;
+        }
+        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
+        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
+    }
+}
+
+// Per-segment part of the counting stage (fine.wgsl:186-215): crossing count and the row winding bump.
+__device__ __forceinline__ uint32_t ms_segment(const Segment &sg, bool even_odd, uint32_t *winding_y) {
+    uint32_t count = 0u;
+    float y_edge_f = (float)TILE_HEIGHT;
+    uint32_t delta = (sg.p1x <= sg.p0x) ? 1u : 0xffffffffu;
+    if (sg.p0x == 0.0f) y_edge_f = sg.p0y;
+    else if (sg.p1x == 0.0f) y_edge_f = sg.p1y;
+    if (!(sg.p0y == sg.p1y && sg.p0y == floorf(sg.p0y))) count = span(sg.p0x, sg.p1x) + span(sg.p0y, sg.p1y) - 1u;
+    uint32_t y_edge = f2u(ceilf(y_edge_f));
+    if (y_edge < TILE_HEIGHT) {
+        if (!even_odd) atomicAdd(&winding_y[y_edge >> 2], delta << ((y_edge & 3u) << 3));
+        else atomicXor(&winding_y[0], 1u << y_edge);
+    }
+    return count;
+}
+
+__device__ __forceinline__ void ms_clear(FineShared &sh, uint32_t *sh_samples, bool even_odd, uint32_t lane, uint32_t swpp) {
+    if (!even_odd) {
+        sh.winding[lane] = 0x80808080u;
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD * swpp; i++) sh_samples[i * 64u + lane] = 0x80808080u;
+    } else {
+        if (lane < 16u) sh.winding[lane] = 0u;
         for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) sh_samples[i * 64u + lane] = 0u;
     }
-    __syncthreads();
-    const uint32_t n_batch = (n_segs + 63u) / 64u;
-    for (uint32_t batch = 0; batch < n_batch; batch++) {
-        const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
-        uint32_t count = 0u;
-        if (lane < slice_size) {
-            Segment sg = batch == 0u ? first : segments[fill.seg_data + batch * 64u + lane];
-            sh.seg[lane] = sg;
-            float y_edge_f = (float)TILE_HEIGHT;
-            uint32_t delta = (sg.p1x <= sg.p0x) ? 1u : 0xffffffffu;
-            if (sg.p0x == 0.0f) y_edge_f = sg.p0y;
-            else if (sg.p1x == 0.0f) y_edge_f = sg.p1y;
-            if (!(sg.p0y == sg.p1y && sg.p0y == floorf(sg.p0y))) count = span(sg.p0x, sg.p1x) + span(sg.p0y, sg.p1y) - 1u;
-            uint32_t y_edge = f2u(ceilf(y_edge_f));
-            if (y_edge < TILE_HEIGHT) {
-                if (!even_odd) atomicAdd(&sh.winding_y[y_edge >> 2], delta << ((y_edge & 3u) << 3));
-                else atomicXor(&sh.winding_y[0], 1u << y_edge);
-            }
-        }
-        uint32_t incl = wave_incl_scan_u32(count, (int)lane);
-        sh.count[lane] = incl;
-        uint32_t total = __shfl(incl, 63);
-        __syncthreads();
-        for (uint32_t i = lane; i < total; i += 64u) {
-            uint32_t lo = 0u, hi = slice_size;
-            while (hi > lo + 1u) {
-                uint32_t mid = (lo + hi) >> 1;
-                if (i >= sh.count[mid - 1u]) lo = mid; else hi = mid;
-            }
-            const uint32_t el_ix = lo;
-            const bool last_pixel = i + 1u == sh.count[el_ix];
-            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-            Segment sg = sh.seg[el_ix];
-            // line setup, fine.wgsl:236-261
-            const bool is_down = sg.p1y >= sg.p0y;
-            const vec2 xy0 = is_down ? v2(sg.p0x, sg.p0y) : v2(sg.p1x, sg.p1y);
-            const vec2 xy1 = is_down ? v2(sg.p1x, sg.p1y) : v2(sg.p0x, sg.p0y);
-            const float dx = fabsf(xy1.x - xy0.x);
-            const float dy = xy1.y - xy0.y;
-            const float idxdy = 1.0f / (dx + dy);
-            float a = dx * idxdy;
-            const bool is_positive_slope = xy1.x >= xy0.x;
-            const float x_sign = is_positive_slope ? 1.0f : -1.0f;
-            const float xt0 = floorf(xy0.x * x_sign);
-            const float c = xy0.x * x_sign - xt0;
-            const float y0i = floorf(xy0.y);
-            const float ytop = y0i + 1.0f;
-            const float b = minf((dy * c + dx * (ytop - xy0.y)) * idxdy, ONE_MINUS_ULP);
-            const uint32_t count_x = span(xy0.x, xy1.x) - 1u;
-            const uint32_t cnt = count_x + span(xy0.y, xy1.y);
-            const float robust_err = floorf(a * ((float)cnt - 1.0f) + b) - (float)count_x;
-            if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
-            const int32_t x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
-            const float zf = a * (float)sub_ix + b;
-            const float z = floorf(zf);
-            const int32_t x = x0i + f2i(x_sign * z);
-            const int32_t y = f2i(y0i) + (int32_t)sub_ix - f2i(z);
-            bool is_delta, is_bump;
-            const float zp = floorf(a * (float)(sub_ix - 1u) + b);
-            if (sub_ix == 0u) {
-                is_delta = y0i == xy0.y;
-                is_bump = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
-            } else {
-                is_delta = z == zp;
-                is_bump = is_positive_slope && !is_delta;
-            }
-            const uint32_t pix_ix = (uint32_t)y * TILE_WIDTH + (uint32_t)x;
-            if ((uint32_t)x < TILE_WIDTH - 1u && (uint32_t)y < TILE_HEIGHT && is_delta) {
-                if (!even_odd) {
-                    uint32_t delta_pix = pix_ix + 1u;
-                    uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
-                    atomicAdd(&sh.winding[delta_pix >> 2], d);
-                } else {
-                    atomicXor(&sh.winding[y], 2u << (uint32_t)x);
-                }
-            }
-            const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
-            const float half_height = (float)(MASK_HEIGHT / 2u);
-            const float mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
-            const float mask_col = floorf((zf - z) * (float)MASK_WIDTH);
-            const uint32_t mask_ix = mask_block + f2u(mask_row + mask_col);
-            uint32_t mask;
-            if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
-            else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
-            if (sub_ix == 0u && !is_bump) {
-                uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy0.y - (float)y)));
-                mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
-            }
-            if (last_pixel && xy1.x != 0.0f) {
-                uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy1.y - (float)y)));
-                mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
-            }
-            if (pix_ix >= 256u) continue;  // memory safety only; tile-clipped segments never get here
-            // sample words are stored transposed ([word][pixel-of-lane group]) so that the 4 words of
-            // a pixel land in different banks: index = word * 64 + (pix >> 2) ... see sample_index()
-            if (even_odd) {
-                if (is_bump) mask ^= FULL;
-                atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
-                continue;
-            }
-            const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
-            constexpr uint32_t NH = MSAA16 ? 2u : 1u;
-#pragma unroll
-            for (uint32_t h = 0; h < NH; h++) {
-                uint32_t m8 = (mask >> (8u * h)) & 0xffu;
-                uint32_t m_a = m8 ^ (m8 << 7);
-                uint32_t m_b = m_a ^ (m_a << 14);
-                uint32_t e0 = m_b & 0x1010101u;
-                uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
-                uint32_t e1 = (m_b >> 4) & 0x1010101u;
-                uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
-                if (is_bump) {
-                    s0 += bump_delta;
-                    s1 += bump_delta;
-                }
-                // logical word w of pixel p lives at ((p & 3) * SWPP + w) * 64 + (p >> 2)
-                atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
-                atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
-            }
-        }
-        __syncthreads();
-    }
-    // resolve
+}
+
+// Resolve (fine.wgsl:365-466): prefix sums of the packed counters, then per pixel the number of covered samples.
+template <int AA>
+__device__ __forceinline__ void ms_resolve(FineShared &sh, uint32_t *sh_samples, const uint32_t *winding_y, bool even_odd,
+                                           int32_t backdrop, uint32_t lane, float (&area)[4]) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
     if (even_odd) {
         uint32_t scan_x = sh.winding[ly];
         scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
-        uint32_t scan_y = sh.winding_y[0];
+        uint32_t scan_y = winding_y[0];
         scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
-        uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)fill.backdrop;
+        uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
 #pragma unroll
         for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
             uint32_t pix_ix = lane * PIXELS_PER_THREAD + i;
@@ -284,7 +304,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
     uint32_t packed_w = sh.winding[lane];
     packed_w += (packed_w - 0x808080u) << 8;
     packed_w += (packed_w - 0x8080u) << 16;
-    uint32_t packed_y = sh.winding_y[ly >> 2];
+    uint32_t packed_y = winding_y[ly >> 2];
     packed_y += (packed_y - 0x808080u) << 8;
     packed_y += (packed_y - 0x8080u) << 16;
     uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
@@ -296,7 +316,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
     for (uint32_t i = 0; i < (ly >> 2); i++) wind_y += sh.winding_y_prefix[i];
 #pragma unroll
     for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
-        uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)fill.backdrop;
+        uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
         if (expected_zero >= 256u) {
             area[i] = 1.0f;
         } else if (!MSAA16) {
@@ -332,6 +352,169 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
             area[i] = (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
         }
     }
+}
+
+// Index of the segment that owns item i: largest el with count[el - 1] <= i (count = inclusive scan in LDS).
+__device__ __forceinline__ uint32_t ms_find_segment(const uint32_t *count, uint32_t n, uint32_t i) {
+    uint32_t lo = 0u, hi = n;
+    while (hi > lo + 1u) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (i >= count[mid - 1u]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One fill on its own, any number of segments: the reference's loop over batches of 64 segments.  Used for fills that
+// do not fit a batch.
+template <int AA>
+__device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
+                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4]) {
+    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
+    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
+    const uint32_t n_segs = fill.size_and_rule >> 1;
+    __syncthreads();
+    if (lane < 4u) sh.winding_y[lane] = even_odd ? 0u : 0x80808080u;
+    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
+    __syncthreads();
+    const uint32_t n_batch = (n_segs + 63u) / 64u;
+    for (uint32_t batch = 0; batch < n_batch; batch++) {
+        const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
+        uint32_t count = 0u;
+        if (lane < slice_size) {
+            Segment sg = segments[fill.seg_data + batch * 64u + lane];
+            sh.seg[lane] = sg;
+            count = ms_segment(sg, even_odd, sh.winding_y);
+        }
+        uint32_t incl = wave_incl_scan_u32(count, (int)lane);
+        sh.count[lane] = incl;
+        uint32_t total = __shfl(incl, 63);
+        __syncthreads();
+        for (uint32_t i = lane; i < total; i += 64u) {
+            const uint32_t el_ix = ms_find_segment(sh.count, slice_size, i);
+            const bool last_pixel = i + 1u == sh.count[el_ix];
+            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+            Segment sg = sh.seg[el_ix];
+            ms_apply<AA>(ms_item<AA>(sg, sub_ix, last_pixel, even_odd, mask_lut), even_odd, sh.winding, sh_samples);
+        }
+        __syncthreads();
+    }
+    ms_resolve<AA>(sh, sh_samples, sh.winding_y, even_odd, fill.backdrop, lane, area);
+}
+
+// Stage a batch: starting at the FILL command at cmd_ix, collect the following FILL commands visible in the command
+// window (any other commands in between are skipped over: coverage does not depend on them), load all their segments
+// with one instruction, count, scan, and write one record per crossing.  Returns the number of fills staged (0 when
+// the first fill alone does not fit: > 64 segments or > MS_ITEM_CAP crossings).
+template <int AA>
+__device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
+                                   const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
+                                   uint32_t lane) {
+    auto rd = [&](uint32_t ix) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
+    };
+    // scalar scan over the window; lane k keeps the parameters of fill slot k
+    uint32_t n = 0u, tot_segs = 0u;
+    uint32_t my_seg_data = 0u, my_seg_start = 0u, my_rule_n = 0u, my_backdrop = 0u;
+    uint32_t ix = cmd_ix;
+    const uint32_t win_end = win_base + 64u;
+    while (n < MS_BATCH_FILLS && ix + 4u <= win_end) {
+        const uint32_t tag = rd(ix);
+        if (tag == CMD_FILL) {
+            const uint32_t size_and_rule = rd(ix + 1u);
+            const uint32_t n_segs = size_and_rule >> 1;
+            if (tot_segs + n_segs > 64u) break;
+            const uint32_t seg_data_w = rd(ix + 2u), backdrop_w = rd(ix + 3u);
+            if (lane == n) {
+                my_seg_data = seg_data_w;
+                my_backdrop = backdrop_w;
+                my_rule_n = size_and_rule;
+                my_seg_start = tot_segs;
+            }
+            tot_segs += n_segs;
+            n += 1u;
+            ix += 4u;
+        } else if (tag == CMD_COLOR || tag == CMD_IMAGE) {
+            ix += 2u;
+        } else if (tag == CMD_SOLID || tag == CMD_BEGIN_CLIP) {
+            ix += 1u;
+        } else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
+            ix += 3u;
+        } else {
+            break;  // END, JUMP: the list continues elsewhere
+        }
+    }
+    if (n == 0u) return 0u;
+    __syncthreads();
+    if (lane < n) {
+        const bool eo = (my_rule_n & 1u) != 0u;
+        bt.rule_backdrop[lane][0] = my_rule_n;
+        bt.rule_backdrop[lane][1] = my_backdrop;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
+    }
+    // which slot does staged segment `lane` belong to
+    uint32_t slot = 0u, seg_data = 0u, seg_start = 0u, rule = 0u;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_start, (int)k);
+        const uint32_t sd_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_data, (int)k);
+        const uint32_t rl_k = (uint32_t)__builtin_amdgcn_readlane((int)my_rule_n, (int)k);
+        if (lane >= st_k) {
+            slot = k;
+            seg_data = sd_k;
+            seg_start = st_k;
+            rule = rl_k;
+        }
+    }
+    __syncthreads();
+    uint32_t count = 0u;
+    if (lane < tot_segs) {
+        Segment sg = segments[seg_data + (lane - seg_start)];
+        sh.seg[lane] = sg;
+        bt.seg_slot[lane] = slot;
+        count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
+    }
+    uint32_t incl = wave_incl_scan_u32(count, (int)lane);
+    sh.count[lane] = incl;
+    // item range ends per slot: the inclusive count at the slot's last segment (or the previous end for empty fills)
+    {
+        const uint32_t last_seg = my_seg_start + (my_rule_n >> 1);  // one past the slot's last staged segment (0 for lanes >= n)
+        const uint32_t end = (uint32_t)__shfl(incl, (int)(last_seg ? last_seg - 1u : 0u));
+        if (lane < n) bt.item_end[lane + 1u] = last_seg ? end : 0u;
+        if (lane == 0u) bt.item_end[0] = 0u;
+    }
+    __syncthreads();
+    // keep only the fills whose records fit
+    uint32_t n_fit = 0u;
+    for (uint32_t k = 0; k < n; k++)
+        if (bt.item_end[k + 1u] <= MS_ITEM_CAP) n_fit = k + 1u;
+    if (n_fit == 0u) return 0u;
+    const uint32_t total = bt.item_end[n_fit];
+    const uint32_t n_staged = tot_segs;
+    for (uint32_t i = lane; i < total; i += 64u) {
+        const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
+        const bool last_pixel = i + 1u == sh.count[el_ix];
+        const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+        Segment sg = sh.seg[el_ix];
+        const bool eo = (bt.rule_backdrop[bt.seg_slot[el_ix]][0] & 1u) != 0u;
+        bt.item[i] = ms_item<AA>(sg, sub_ix, last_pixel, eo, mask_lut);
+    }
+    __syncthreads();
+    return n_fit;
+}
+
+// A FILL command whose crossings were staged by ms_build_batch: replay its records and resolve.
+template <int AA>
+__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4]) {
+    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
+    const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
+    const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
+    const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
+    __syncthreads();
+    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
+    __syncthreads();
+    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], even_odd, sh.winding, sh_samples);
+    __syncthreads();
+    ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, lane, area);
 }
 
 // ---------------- blend (shared/blend.wgsl) ----------------
@@ -806,6 +989,7 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
                                              uint32_t atlas_w, uint32_t atlas_h) {
     __shared__ FineShared sh;
     __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
+    __shared__ FineBatch bt;
     if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 3u, ly = lane >> 2;
@@ -841,30 +1025,54 @@ __global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__res
     Segment pre;
     pre.p0x = 0.0f; pre.p0y = 0.0f; pre.p1x = 0.0f; pre.p1y = 0.0f; pre.y_edge = 0.0f; pre.pad = 0u;
     uint32_t pre_seg_data = ~0u;
+    uint32_t batch_n = 0u, batch_pos = 0u;  // MSAA: fills staged by ms_build_batch / already consumed
     for (;;) {
         ensure(cmd_ix, 4u);
         const uint32_t tag = rd(cmd_ix);
         if (tag == CMD_END) break;
         if (tag == CMD_FILL) {
-            CmdFill fill;
-            fill.size_and_rule = rd(cmd_ix + 1u);
-            fill.seg_data = rd(cmd_ix + 2u);
-            fill.backdrop = (int32_t)rd(cmd_ix + 3u);
-            Segment first = pre;
-            if (pre_seg_data != fill.seg_data) {
-                if (lane < minu(fill.size_and_rule >> 1, 64u)) first = segments[fill.seg_data + lane];
+            if constexpr (AA == 0) {
+                CmdFill fill;
+                fill.size_and_rule = rd(cmd_ix + 1u);
+                fill.seg_data = rd(cmd_ix + 2u);
+                fill.backdrop = (int32_t)rd(cmd_ix + 3u);
+                Segment first = pre;
+                if (pre_seg_data != fill.seg_data) {
+                    if (lane < minu(fill.size_and_rule >> 1, 64u)) first = segments[fill.seg_data + lane];
+                }
+                // look ahead: [COLOR] FILL -> prefetch its first segment batch into registers
+                pre_seg_data = ~0u;
+                uint32_t nx = cmd_ix + 4u;
+                if (nx + 2u <= win_base + 64u && rd(nx) == CMD_COLOR) nx += 2u;
+                if (nx + 4u <= win_base + 64u && rd(nx) == CMD_FILL) {
+                    uint32_t n2 = rd(nx + 1u) >> 1;
+                    pre_seg_data = rd(nx + 2u);
+                    if (lane < minu(n2, 64u)) pre = segments[pre_seg_data + lane];
+                }
+                fill_path_area(sh, segments, fill, lane, area, first);
+            } else {
+                if (batch_pos == batch_n) {
+                    // the scan wants to see as far ahead as possible: restart the window at this command
+                    if (cmd_ix != win_base) {
+                        win_base = cmd_ix;
+                        uint32_t a = win_base + lane;
+                        win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+                    }
+                    batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
+                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane));
+                    batch_pos = 0u;
+                }
+                if (batch_n != 0u) {
+                    ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area);
+                    batch_pos += 1u;
+                } else {
+                    CmdFill fill;
+                    fill.size_and_rule = rd(cmd_ix + 1u);
+                    fill.seg_data = rd(cmd_ix + 2u);
+                    fill.backdrop = (int32_t)rd(cmd_ix + 3u);
+                    fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area);
+                }
             }
-            // look ahead: [COLOR] FILL -> prefetch its first segment batch into registers
-            pre_seg_data = ~0u;
-            uint32_t nx = cmd_ix + 4u;
-            if (nx + 2u <= win_base + 64u && rd(nx) == CMD_COLOR) nx += 2u;
-            if (nx + 4u <= win_base + 64u && rd(nx) == CMD_FILL) {
-                uint32_t n2 = rd(nx + 1u) >> 1;
-                pre_seg_data = rd(nx + 2u);
-                if (lane < minu(n2, 64u)) pre = segments[pre_seg_data + lane];
-            }
-            if constexpr (AA == 0) fill_path_area(sh, segments, fill, lane, area, first);
-            else fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area, first);
             cmd_ix += 4u;
         } else if (tag == CMD_SOLID) {
 #pragma unroll
