@@ -27,7 +27,8 @@ struct Control {
     Bump bump;              // must be first: VELLO_HIP_BUF_BUMP aliases it
     uint32_t ticket_pathtag;
     uint32_t ticket_draw;
-    uint32_t pad[6];
+    uint32_t heavy_count;   // flatten: tags queued for k_flatten_heavy
+    uint32_t pad[5];
 };
 static_assert(sizeof(Control) == 64, "Control");
 
@@ -38,6 +39,7 @@ struct Frame {
     // device pointers
     const uint32_t *scene;
     Control *control;
+    uint32_t *heavy_list;   // flatten: tag indices that need the Euler-spiral / stroker path
     unsigned long long *pathtag_state;  // [n_pathtag_parts][2][5]
     unsigned long long *draw_state;     // [n_draw_parts][2][4]
     TagMonoid *tag_monoids;

@@ -39,6 +39,7 @@ struct Lane {
     DevBuf buf[VELLO_HIP_BUF_COUNT];  // SCENE / CONFIG entries unused (shared, see ctx)
     DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
     DevBuf clip_stack;
+    DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -145,6 +146,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
+    if ((r = ensure(c, l.heavy_list, (size_t)(c->n_tag_words + 1u) * 16u))) return r;
     return 0;
 }
 
@@ -226,6 +228,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.ptcl = (uint32_t *)l.buf[VELLO_HIP_BUF_PTCL].ptr;
     f.blend_spill = (uint32_t *)l.buf[VELLO_HIP_BUF_BLEND_SPILL].ptr;
     f.clip_stack = (uint32_t *)l.clip_stack.ptr;
+    f.heavy_list = (uint32_t *)l.heavy_list.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
         f.out_stride = out_stride ? out_stride : (size_t)p->width * 4u;
@@ -418,6 +421,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
             if (l.buf[i].ptr && i != VELLO_HIP_BUF_BUMP) (void)hipFree(l.buf[i].ptr);
         if (l.zero_region.ptr) (void)hipFree(l.zero_region.ptr);
         if (l.clip_stack.ptr) (void)hipFree(l.clip_stack.ptr);
+        if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);

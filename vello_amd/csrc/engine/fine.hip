@@ -982,7 +982,7 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
 // on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
 // solid-colour interpreter does not pay their registers.
 template <int AA, bool BRUSHES>
-__global__ void __launch_bounds__(64, 3) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+__global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
                                              const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,

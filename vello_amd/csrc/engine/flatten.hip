@@ -39,11 +39,11 @@ __device__ __forceinline__ vec2 xf_apply(const Xform &t, vec2 p) {
 // Lines are staged in LDS and leave the workgroup in one coalesced copy (see k_flatten).  `alloc` reserves the n
 // slots of one curve piece with ONE LDS atomic; a piece that does not fit the staging area any more goes straight
 // to the soup with one global atomic for the piece (bit 31 of the index marks "global").
-constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
 constexpr uint32_t LINE_IX_GLOBAL = 0x80000000u;
+template <uint32_t CAP>
 struct FlattenShared {
-    uint32_t path_ix[FLATTEN_LDS_LINES];
-    float p0x[FLATTEN_LDS_LINES], p0y[FLATTEN_LDS_LINES], p1x[FLATTEN_LDS_LINES], p1y[FLATTEN_LDS_LINES];
+    uint32_t path_ix[CAP];
+    float p0x[CAP], p0y[CAP], p1x[CAP], p1y[CAP];
     uint32_t count;    // slots handed out (may run past the capacity)
     uint32_t lds_end;  // first slot of the first piece that did not fit (dense prefix [0, lds_end) is staged)
     uint32_t base;
@@ -55,12 +55,23 @@ struct Emitter {
     LineSoup *lines;
     uint32_t lines_size;
     Bump *bump;
-    FlattenShared *sh;
+    uint32_t cap;
+    uint32_t *s_path_ix;
+    float *s_p0x, *s_p0y, *s_p1x, *s_p1y;
+    uint32_t *s_count, *s_lds_end;
 
+    template <uint32_t CAP>
+    __device__ __forceinline__ void bind(FlattenShared<CAP> &sh) {
+        cap = CAP;
+        s_path_ix = sh.path_ix;
+        s_p0x = sh.p0x; s_p0y = sh.p0y; s_p1x = sh.p1x; s_p1y = sh.p1y;
+        s_count = &sh.count;
+        s_lds_end = &sh.lds_end;
+    }
     __device__ __forceinline__ uint32_t alloc(uint32_t n) {
-        uint32_t slot = atomicAdd(&sh->count, n);
-        if (slot + n <= FLATTEN_LDS_LINES) return slot;
-        atomicMin(&sh->lds_end, slot);
+        uint32_t slot = atomicAdd(s_count, n);
+        if (slot + n <= cap) return slot;
+        atomicMin(s_lds_end, slot);
         return atomicAdd(&bump->lines, n) | LINE_IX_GLOBAL;
     }
     // flatten.wgsl:766-773
@@ -78,14 +89,53 @@ struct Emitter {
                 lines[ix] = l;
             }
         } else {
-            sh->path_ix[ix] = path_ix;
-            sh->p0x[ix] = p0.x; sh->p0y[ix] = p0.y; sh->p1x[ix] = p1.x; sh->p1y[ix] = p1.y;
+            s_path_ix[ix] = path_ix;
+            s_p0x[ix] = p0.x; s_p0y[ix] = p0.y; s_p1x[ix] = p1.x; s_p1y[ix] = p1.y;
         }
     }
     __device__ __forceinline__ void write_xf(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1, const Xform &t) {
         write(ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
     }
 };
+
+// ONE atomicAdd(bump.lines) for the staged lines of the workgroup (the reference issues one per line), then a
+// coalesced copy: thread i writes the 24-byte record i.  Resets the staging area for the next round.
+template <uint32_t CAP>
+__device__ __forceinline__ void flush_staged_lines(FlattenShared<CAP> &sh, Bump *bump, LineSoup *lines, uint32_t lines_size, uint32_t tid) {
+    __syncthreads();
+    const uint32_t n_lds = minu(sh.count, sh.lds_end);
+    if (tid == 0u) sh.base = n_lds ? atomicAdd(&bump->lines, n_lds) : 0u;
+    __syncthreads();
+    const uint32_t base = sh.base;
+    for (uint32_t i = tid; i < n_lds; i += 256u) {
+        uint32_t o = base + i;
+        if (o < lines_size) {
+            LineSoup l;
+            l.path_ix = sh.path_ix[i]; l.pad = 0u;
+            l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
+            lines[o] = l;
+        }
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        sh.count = 0u;
+        sh.lds_end = 0xffffffffu;
+    }
+    __syncthreads();
+}
+
+// The straight-segment test of flatten_euler (see there), shared with the light kernel.
+__device__ __forceinline__ bool cubic_is_straight(vec2 p0, vec2 p1, vec2 p2, vec2 p3, float scale, float offset) {
+    vec2 q0 = p1 - p0, q1 = p3 - p2, chd = p3 - p0;
+    float c2 = dot(chd, chd), a0 = dot(q0, q0), a1 = dot(q1, q1);
+    float h0x = dot(q0, chd), h0y = q0.y * chd.x - q0.x * chd.y;
+    float h1x = dot(q1, chd), h1y = q1.x * chd.y - q1.y * chd.x;
+    float clen = sqrtf(c2);
+    float S = scale * clen;
+    float ay0 = fabsf(h0y), ay1 = fabsf(h1y), aoff = fabsf(offset);
+    return c2 >= 4e-12f && a0 >= 4e-12f && a1 >= 4e-12f && a0 <= c2 && a1 <= c2 && h0x > 0.0f && h1x > 0.0f && ay0 * S <= 0.02f * h0x &&
+           ay1 * S <= 0.02f * h1x && aoff * ay0 <= 2.5e-3f * h0x * clen && aoff * ay1 <= 2.5e-3f * h1x * clen;
+}
 
 // flatten.wgsl:94-133
 __device__ CubicParams cubic_from_points_derivs(vec2 p0, vec2 p1, vec2 q0, vec2 q1, float dt) {
@@ -328,16 +378,7 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
         // the parallel-curve branch); theta*S <= 0.02 keeps both decisions 2-6x inside their thresholds, far
         // beyond f32 rounding, so "accept, n = 1" is what the loop would compute.  Polylines (most of a
         // map-like scene) then cost ~40 flops per pass instead of six fp64 transcendentals.
-        vec2 q0 = p1 - p0, q1 = p3 - p2, chd = p3 - p0;
-        float c2 = dot(chd, chd), a0 = dot(q0, q0), a1 = dot(q1, q1);
-        float h0x = dot(q0, chd), h0y = q0.y * chd.x - q0.x * chd.y;
-        float h1x = dot(q1, chd), h1y = q1.x * chd.y - q1.y * chd.x;
-        float clen = sqrtf(c2);
-        float S = scale * clen;
-        float ay0 = fabsf(h0y), ay1 = fabsf(h1y), aoff = fabsf(offset);
-        bool straight = c2 >= 4e-12f && a0 >= 4e-12f && a1 >= 4e-12f && a0 <= c2 && a1 <= c2 && h0x > 0.0f && h1x > 0.0f &&
-                        ay0 * S <= 0.02f * h0x && ay1 * S <= 0.02f * h1x && aoff * ay0 <= 2.5e-3f * h0x * clen &&
-                        aoff * ay1 <= 2.5e-3f * h1x * clen;
+        const bool straight = cubic_is_straight(p0, p1, p2, p3, scale, offset);
         if (straight) {
             uint32_t line_ix = em.alloc((uint32_t)n_sides);
             if constexpr (EMIT) {
@@ -752,57 +793,131 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 
 }  // namespace
 
-__global__ void __launch_bounds__(256, 2) k_flatten(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
-                                                    const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes, Bump *bump,
-                                                    LineSoup *lines) {
-    __shared__ FlattenShared sh;
+// ---- light kernel -------------------------------------------------------------------------------------------
+// Most tags of a map-like scene are fill segments that pass the straight-segment test: one transform, one test, one
+// line.  Inlined next to the Euler-spiral / stroker code they inherit its 256 VGPRs (2 waves per SIMD), and the
+// kernel is bound by the chain of dependent loads tag -> monoid -> style / transform / points with nothing to hide
+// it behind.  This kernel handles exactly those tags (and the PATH markers) with a small register budget; every
+// other segment tag is appended to `heavy_list` for k_flatten_heavy.  Returns true when the tag needs the heavy path.
+__device__ __forceinline__ bool flatten_tag_light(Emitter<true> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+                                                  PathBbox *path_bboxes, uint32_t ix, uint32_t &path_ix_out) {
+    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
+    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
+    bool is_path = (tag.tag_byte & PATH_TAG_PATH) != 0u;
+    uint32_t path_ix = tag.monoid.path_ix;
+    path_ix_out = path_ix;
+    em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+    if (!is_path && seg_type == 0u) return false;
+    uint32_t style_ix = tag.monoid.style_ix;
+    uint32_t trans_ix = tag.monoid.trans_ix;
+    uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
+    if (is_path) {
+        path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
+        path_bboxes[path_ix].trans_ix = trans_ix;
+    }
+    if (seg_type == 0u) return false;
+    if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return true;  // strokes: joins, caps, offset curves
+    const uint32_t *pd = scene + cfg.layout.path_data_base;
+    Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
+    CubicPoints pts = read_path_segment(pd, tag, false);
+    // flatten_euler with offset == 0 (flatten.wgsl:340-352): points to device space, degenerate cubics emit nothing
+    vec2 p0 = xf_apply(transform, pts.p0), p1 = xf_apply(transform, pts.p1), p2 = xf_apply(transform, pts.p2),
+         p3 = xf_apply(transform, pts.p3);
+    if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return false;
+    if (!cubic_is_straight(p0, p1, p2, p3, 1.0f, 0.0f)) return true;
+    const Xform identity{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    uint32_t line_ix = em.alloc(1u);
+    em.write_xf(line_ix, path_ix, p0, p3, identity);  // the reference applies the (identity) transform here too
+    return false;
+}
+
+__global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                          Control *control, LineSoup *lines, uint32_t *heavy_list) {
+    __shared__ FlattenShared<FLATTEN_BLOCK_TAGS> sh;  // at most one line per tag: never overflows
+    __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];
+    __shared__ uint32_t sh_n_heavy, sh_heavy_base;
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
-    // a path are of one kind, so waves stay convergent and segment reads coalesce.  (Giving each thread 4
-    // consecutive tags instead measured 1.7x slower on MI355X.)
+    // a path are of one kind, so waves stay convergent and segment reads coalesce.
     const uint32_t tag0 = blockIdx.x * FLATTEN_BLOCK_TAGS + tid;
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
+        sh_n_heavy = 0u;
     }
     __syncthreads();
-
-    // ONE pass over the tags (the first version ran the flattener twice, COUNT then EMIT, to learn the slice
-    // sizes before writing; the fp64-heavy subdivision was paid twice): lines go to the LDS staging area.
+    Bump *bump = &control->bump;
 #pragma unroll 1
     for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
         Emitter<true> em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
         em.bump = bump;
-        em.sh = &sh;
+        em.bind(sh);
         uint32_t ix = tag0 + j * 256u;
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
+        bool heavy = false;
         if (ix < n_tags) {
-            key = flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, ix);
+            heavy = flatten_tag_light(em, cfg, scene, tag_monoids, path_bboxes, ix, key);
             // a tag contributes only if it produced an extent (flatten.wgsl:915)
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
         }
-        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)(tid & 63u));
+        // wave-aggregated append to the workgroup's heavy list (tag order is kept inside a wave)
+        const unsigned long long hm = __ballot(heavy);
+        if (hm != 0ull) {
+            uint32_t wbase = 0u;
+            if (lane == (uint32_t)(__ffsll((long long)hm) - 1)) wbase = atomicAdd(&sh_n_heavy, (uint32_t)__popcll(hm));
+            wbase = (uint32_t)__shfl((int)wbase, __ffsll((long long)hm) - 1);
+            if (heavy) sh_heavy[wbase + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = ix;
+        }
+        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
+    }
+    flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
+    const uint32_t n_heavy = sh_n_heavy;
+    if (tid == 0u) sh_heavy_base = n_heavy ? atomicAdd(&control->heavy_count, n_heavy) : 0u;
+    __syncthreads();
+    for (uint32_t i = tid; i < n_heavy; i += 256u) heavy_list[sh_heavy_base + i] = sh_heavy[i];
+}
+
+// ---- heavy kernel: curves that need subdivision and everything stroked ----------------------------------------
+constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
+__global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, const uint32_t *__restrict__ scene,
+                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list) {
+    __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_heavy = control->heavy_count;  // final: written by the previous kernel on this stream
+    if (blockIdx.x * 256u >= n_heavy) return;
+    if (tid == 0u) {
+        sh.count = 0u;
+        sh.lds_end = 0xffffffffu;
     }
     __syncthreads();
-    // ONE atomicAdd(bump.lines) for the staged lines of the workgroup (the reference issues one per line), then a
-    // coalesced copy: thread i writes the 24-byte record i.
-    const uint32_t n_lds = minu(sh.count, sh.lds_end);
-    if (tid == 0u) sh.base = n_lds ? atomicAdd(&bump->lines, n_lds) : 0u;
-    __syncthreads();
-    const uint32_t base = sh.base;
-    for (uint32_t i = tid; i < n_lds; i += 256u) {
-        uint32_t o = base + i;
-        if (o < cfg.lines_size) {
-            LineSoup l;
-            l.path_ix = sh.path_ix[i]; l.pad = 0u;
-            l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
-            lines[o] = l;
+    Bump *bump = &control->bump;
+    // no indirect dispatch in HIP: a fixed grid strides over the list
+#pragma unroll 1
+    for (uint32_t base = blockIdx.x * 256u; base < n_heavy; base += gridDim.x * 256u) {
+        Emitter<true> em;
+        em.lines = lines;
+        em.lines_size = cfg.lines_size;
+        em.bump = bump;
+        em.bind(sh);
+        uint32_t key = 0xffffffffu;
+        float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
+        if (base + tid < n_heavy) {
+            key = flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, heavy_list[base + tid]);
+            if (em.bx1 > em.bx0 || em.by1 > em.by0) {
+                x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
+            }
         }
+        // list entries of one source workgroup keep tag order, so equal path keys still come in runs
+        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)(tid & 63u));
+        flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     }
 }
 
@@ -810,8 +925,12 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     uint32_t n_tags = f.n_tag_words * 4u;
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
     if (grid == 0) return;
-    hipLaunchKernelGGL(k_flatten, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.bump(),
-                       f.lines);
+    hipLaunchKernelGGL(k_flatten_light, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                       f.lines, f.heavy_list);
+    uint32_t grid_heavy = (n_tags + 255u) / 256u;
+    if (grid_heavy > 2048u) grid_heavy = 2048u;
+    hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                       f.lines, f.heavy_list);
 }
 
 }  // namespace vk
