@@ -27,8 +27,8 @@ struct Control {
     Bump bump;              // must be first: VELLO_HIP_BUF_BUMP aliases it
     uint32_t ticket_pathtag;
     uint32_t ticket_draw;
-    uint32_t heavy_count;   // flatten: tags queued for k_flatten_heavy
-    uint32_t pad[5];
+    uint32_t heavy_count[2];  // flatten: tags queued for k_flatten_heavy: [0] fill curves, [1] strokes
+    uint32_t pad[4];
 };
 static_assert(sizeof(Control) == 64, "Control");
 

@@ -146,7 +146,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
-    if ((r = ensure(c, l.heavy_list, (size_t)(c->n_tag_words + 1u) * 16u))) return r;
+    if ((r = ensure(c, l.heavy_list, (size_t)(c->n_tag_words + 1u) * 32u))) return r;  // 2 lists x 4 tags per word x u32
     return 0;
 }
 

@@ -798,8 +798,11 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 // line.  Inlined next to the Euler-spiral / stroker code they inherit its 256 VGPRs (2 waves per SIMD), and the
 // kernel is bound by the chain of dependent loads tag -> monoid -> style / transform / points with nothing to hide
 // it behind.  This kernel handles exactly those tags (and the PATH markers) with a small register budget; every
-// other segment tag is appended to `heavy_list` for k_flatten_heavy.  Returns true when the tag needs the heavy path.
-__device__ __forceinline__ bool flatten_tag_light(Emitter<true> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+// other segment tag is queued for k_flatten_heavy, curves and strokes on separate lists so that its waves are
+// homogeneous (a wave mixing 8 cubics with 56 stroked lines runs the subdivision loop at 1/8 lane use).
+// Returns 0 = done, HEAVY_CURVE or HEAVY_STROKE.
+constexpr uint32_t HEAVY_CURVE = 1u, HEAVY_STROKE = 2u;
+__device__ __forceinline__ uint32_t flatten_tag_light(Emitter<true> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                                   PathBbox *path_bboxes, uint32_t ix, uint32_t &path_ix_out) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
@@ -807,7 +810,7 @@ __device__ __forceinline__ bool flatten_tag_light(Emitter<true> &em, const Confi
     uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
-    if (!is_path && seg_type == 0u) return false;
+    if (!is_path && seg_type == 0u) return 0u;
     uint32_t style_ix = tag.monoid.style_ix;
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
@@ -815,28 +818,28 @@ __device__ __forceinline__ bool flatten_tag_light(Emitter<true> &em, const Confi
         path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
         path_bboxes[path_ix].trans_ix = trans_ix;
     }
-    if (seg_type == 0u) return false;
-    if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return true;  // strokes: joins, caps, offset curves
+    if (seg_type == 0u) return 0u;
+    if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return HEAVY_STROKE;  // joins, caps, offset curves
     const uint32_t *pd = scene + cfg.layout.path_data_base;
     Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
     CubicPoints pts = read_path_segment(pd, tag, false);
     // flatten_euler with offset == 0 (flatten.wgsl:340-352): points to device space, degenerate cubics emit nothing
     vec2 p0 = xf_apply(transform, pts.p0), p1 = xf_apply(transform, pts.p1), p2 = xf_apply(transform, pts.p2),
          p3 = xf_apply(transform, pts.p3);
-    if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return false;
-    if (!cubic_is_straight(p0, p1, p2, p3, 1.0f, 0.0f)) return true;
+    if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return 0u;
+    if (!cubic_is_straight(p0, p1, p2, p3, 1.0f, 0.0f)) return HEAVY_CURVE;
     const Xform identity{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
     uint32_t line_ix = em.alloc(1u);
     em.write_xf(line_ix, path_ix, p0, p3, identity);  // the reference applies the (identity) transform here too
-    return false;
+    return 0u;
 }
 
 __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                           Control *control, LineSoup *lines, uint32_t *heavy_list) {
     __shared__ FlattenShared<FLATTEN_BLOCK_TAGS> sh;  // at most one line per tag: never overflows
-    __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];
-    __shared__ uint32_t sh_n_heavy, sh_heavy_base;
+    __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];  // curves from the front, strokes from the back
+    __shared__ uint32_t sh_n_heavy[2], sh_heavy_base[2];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
@@ -845,7 +848,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
-        sh_n_heavy = 0u;
+        sh_n_heavy[0] = sh_n_heavy[1] = 0u;
     }
     __syncthreads();
     Bump *bump = &control->bump;
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
         uint32_t ix = tag0 + j * 256u;
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
-        bool heavy = false;
+        uint32_t heavy = 0u;
         if (ix < n_tags) {
             heavy = flatten_tag_light(em, cfg, scene, tag_monoids, path_bboxes, ix, key);
             // a tag contributes only if it produced an extent (flatten.wgsl:915)
@@ -867,31 +870,40 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
         }
-        // wave-aggregated append to the workgroup's heavy list (tag order is kept inside a wave)
-        const unsigned long long hm = __ballot(heavy);
-        if (hm != 0ull) {
-            uint32_t wbase = 0u;
-            if (lane == (uint32_t)(__ffsll((long long)hm) - 1)) wbase = atomicAdd(&sh_n_heavy, (uint32_t)__popcll(hm));
-            wbase = (uint32_t)__shfl((int)wbase, __ffsll((long long)hm) - 1);
-            if (heavy) sh_heavy[wbase + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = ix;
+        // wave-aggregated appends to the workgroup's two heavy lists (tag order is kept inside a wave)
+#pragma unroll
+        for (uint32_t kind = 0; kind < 2u; kind++) {
+            const unsigned long long hm = __ballot(heavy == kind + 1u);
+            if (hm != 0ull) {
+                const int leader = __ffsll((long long)hm) - 1;
+                uint32_t wbase = 0u;
+                if ((int)lane == leader) wbase = atomicAdd(&sh_n_heavy[kind], (uint32_t)__popcll(hm));
+                wbase = (uint32_t)__shfl((int)wbase, leader);
+                if (heavy == kind + 1u) {
+                    uint32_t pos = wbase + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+                    sh_heavy[kind == 0u ? pos : FLATTEN_BLOCK_TAGS - 1u - pos] = ix;
+                }
+            }
         }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
     }
     flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
-    const uint32_t n_heavy = sh_n_heavy;
-    if (tid == 0u) sh_heavy_base = n_heavy ? atomicAdd(&control->heavy_count, n_heavy) : 0u;
+    if (tid < 2u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
     __syncthreads();
-    for (uint32_t i = tid; i < n_heavy; i += 256u) heavy_list[sh_heavy_base + i] = sh_heavy[i];
+    // curves fill heavy_list[0, n_tags), strokes heavy_list[n_tags, 2 n_tags)
+    for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
+    for (uint32_t i = tid; i < sh_n_heavy[1]; i += 256u) heavy_list[n_tags + sh_heavy_base[1] + i] = sh_heavy[FLATTEN_BLOCK_TAGS - 1u - i];
 }
 
 // ---- heavy kernel: curves that need subdivision and everything stroked ----------------------------------------
 constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
-__global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, const uint32_t *__restrict__ scene,
+__global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                           Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
     const uint32_t tid = threadIdx.x;
-    const uint32_t n_heavy = control->heavy_count;  // final: written by the previous kernel on this stream
+    // final counts: written by the previous kernel on this stream
+    const uint32_t n_curves = control->heavy_count[0], n_heavy = n_curves + control->heavy_count[1];
     if (blockIdx.x * 256u >= n_heavy) return;
     if (tid == 0u) {
         sh.count = 0u;
@@ -910,7 +922,9 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, const uint
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
         if (base + tid < n_heavy) {
-            key = flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, heavy_list[base + tid]);
+            const uint32_t e = base + tid;
+            const uint32_t tag_ix = e < n_curves ? heavy_list[e] : heavy_list[n_tags + (e - n_curves)];
+            key = flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
@@ -929,7 +943,7 @@ void launch_flatten(const Frame &f, hipStream_t s) {
                        f.lines, f.heavy_list);
     uint32_t grid_heavy = (n_tags + 255u) / 256u;
     if (grid_heavy > 2048u) grid_heavy = 2048u;
-    hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+    hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
 }
 
