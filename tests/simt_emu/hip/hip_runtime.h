@@ -23,6 +23,7 @@
 #include <functional>
 #include <vector>
 
+#define VELLO_SIMT_EMU 1
 #define __global__
 #define __device__
 #define __host__

@@ -160,6 +160,21 @@ __device__ __forceinline__ Xform read_transform(const uint32_t *scene, uint32_t 
 // ---------------- wave64 / workgroup primitives ----------------
 constexpr int WAVE = 64;
 
+// For workgroups of exactly ONE wave64 (k_fine): the LDS operations of a wave are issued and performed in program
+// order, so lanes can exchange data through LDS without s_barrier and, above all, without the s_waitcnt that a
+// __syncthreads() puts in front of it (it would also wait for the global loads in flight).  Only the compiler has
+// to keep the order.  The CPU emulator runs lanes as fibers and needs the real rendezvous.
+#ifdef VELLO_SIMT_EMU
+#define wave_lds_sync() __syncthreads()
+#else
+#define wave_lds_sync()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+    } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {

@@ -14,7 +14,7 @@ constexpr uint32_t PATHTAG_PART_WORDS = 1024;  // 256 threads x 4 tag words (= 4
 constexpr uint32_t DRAW_PART = 256;            // draw objects per partition
 constexpr uint32_t FLATTEN_TAGS_PER_THREAD = 4;
 constexpr uint32_t FLATTEN_BLOCK_TAGS = 256 * FLATTEN_TAGS_PER_THREAD;
-constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = 8;
+constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = 4;
 constexpr uint32_t PATH_COUNT_CHUNK = 256 * PATH_COUNT_LINES_PER_THREAD;
 // Spin bound for look-back waits: a predecessor always holds a smaller ticket, so it is resident
 // or finished; the bound only turns a driver-level hang into a reported failure.

@@ -72,9 +72,9 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
     for (int k = 0; k < 4; k++) area[k] = backdrop_f;
     for (uint32_t base = 0; base < n_segs; base += 64u) {
         uint32_t slice = minu(n_segs - base, 64u);
-        __syncthreads();
+        wave_lds_sync();
         if (lane < slice) sh.seg[lane] = base == 0u ? first : segments[fill.seg_data + base + lane];
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t i = 0; i < slice; i++) {
             Segment sg = sh.seg[i];
             float y = sg.p0y - xy_y;
@@ -308,12 +308,18 @@ __device__ __forceinline__ void ms_resolve(FineShared &sh, uint32_t *sh_samples,
     packed_y += (packed_y - 0x808080u) << 8;
     packed_y += (packed_y - 0x8080u) << 16;
     uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
-    if ((ly & 3u) == 3u && lx == 0u) sh.winding_y_prefix[ly >> 2] = wind_y;
+    // fine.wgsl publishes both prefixes through workgroup memory (sh_winding, sh_winding_y_prefix) and re-reads
+    // them after a barrier; one wave does it with shuffles.  Integer adds: the order of the terms is irrelevant.
     const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
-    sh.winding[lane] = prefix_x;
-    __syncthreads();
-    for (uint32_t i = (lane & ~3u); i < lane; i++) packed_w += sh.winding[i];
-    for (uint32_t i = 0; i < (ly >> 2); i++) wind_y += sh.winding_y_prefix[i];
+    const uint32_t px1 = __shfl_up(prefix_x, 1), px2 = __shfl_up(prefix_x, 2), px3 = __shfl_up(prefix_x, 3);
+    if (lx >= 1u) packed_w += px1;
+    if (lx >= 2u) packed_w += px2;
+    if (lx >= 3u) packed_w += px3;
+    // wind_y of rows 3, 7, 11 (any lane of the row holds it)
+    const uint32_t wy3 = __shfl(wind_y, 12), wy7 = __shfl(wind_y, 28), wy11 = __shfl(wind_y, 44);
+    if (ly >= 4u) wind_y += wy3;
+    if (ly >= 8u) wind_y += wy7;
+    if (ly >= 12u) wind_y += wy11;
 #pragma unroll
     for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
         uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
@@ -372,10 +378,10 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
     constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
     const bool even_odd = (fill.size_and_rule & 1u) != 0u;
     const uint32_t n_segs = fill.size_and_rule >> 1;
-    __syncthreads();
+    wave_lds_sync();
     if (lane < 4u) sh.winding_y[lane] = even_odd ? 0u : 0x80808080u;
     ms_clear(sh, sh_samples, even_odd, lane, SWPP);
-    __syncthreads();
+    wave_lds_sync();
     const uint32_t n_batch = (n_segs + 63u) / 64u;
     for (uint32_t batch = 0; batch < n_batch; batch++) {
         const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
@@ -388,7 +394,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
         uint32_t incl = wave_incl_scan_u32(count, (int)lane);
         sh.count[lane] = incl;
         uint32_t total = __shfl(incl, 63);
-        __syncthreads();
+        wave_lds_sync();
         for (uint32_t i = lane; i < total; i += 64u) {
             const uint32_t el_ix = ms_find_segment(sh.count, slice_size, i);
             const bool last_pixel = i + 1u == sh.count[el_ix];
@@ -396,7 +402,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
             Segment sg = sh.seg[el_ix];
             ms_apply<AA>(ms_item<AA>(sg, sub_ix, last_pixel, even_odd, mask_lut), even_odd, sh.winding, sh_samples);
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     ms_resolve<AA>(sh, sh_samples, sh.winding_y, even_odd, fill.backdrop, lane, area);
 }
@@ -444,7 +450,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         }
     }
     if (n == 0u) return 0u;
-    __syncthreads();
+    wave_lds_sync();
     if (lane < n) {
         const bool eo = (my_rule_n & 1u) != 0u;
         bt.rule_backdrop[lane][0] = my_rule_n;
@@ -465,7 +471,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
             rule = rl_k;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     uint32_t count = 0u;
     if (lane < tot_segs) {
         Segment sg = segments[seg_data + (lane - seg_start)];
@@ -482,7 +488,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         if (lane < n) bt.item_end[lane + 1u] = last_seg ? end : 0u;
         if (lane == 0u) bt.item_end[0] = 0u;
     }
-    __syncthreads();
+    wave_lds_sync();
     // keep only the fills whose records fit
     uint32_t n_fit = 0u;
     for (uint32_t k = 0; k < n; k++)
@@ -498,7 +504,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         const bool eo = (bt.rule_backdrop[bt.seg_slot[el_ix]][0] & 1u) != 0u;
         bt.item[i] = ms_item<AA>(sg, sub_ix, last_pixel, eo, mask_lut);
     }
-    __syncthreads();
+    wave_lds_sync();
     return n_fit;
 }
 
@@ -509,11 +515,11 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
     const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
     const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
-    __syncthreads();
+    wave_lds_sync();
     ms_clear(sh, sh_samples, even_odd, lane, SWPP);
-    __syncthreads();
+    wave_lds_sync();
     for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], even_odd, sh.winding, sh_samples);
-    __syncthreads();
+    wave_lds_sync();
     ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, lane, area);
 }
 
