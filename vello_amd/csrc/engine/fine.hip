@@ -803,7 +803,8 @@ struct RareState {
     uint32_t cmd_ix;
 };
 template <bool BRUSHES>
-__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, const Config &cfg,
+__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, uint32_t ptcl_size,
+                                                       uint32_t blend_size,
                                                        const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
                                                        uint32_t *blend_spill, uint32_t blend_offset, uint32_t lane, float xy_x,
                                                        float xy_y, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
@@ -812,7 +813,7 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
     float area[4] = {st.area[0], st.area[1], st.area[2], st.area[3]};
     uint32_t clip_depth = st.clip_depth;
     uint32_t cmd_ix = st.cmd_ix;
-    auto rd = [&](uint32_t ix) -> uint32_t { return ix < cfg.ptcl_size ? ptcl[ix] : 0u; };
+    auto rd = [&](uint32_t ix) -> uint32_t { return ix < ptcl_size ? ptcl[ix] : 0u; };
     if (tag == CMD_BEGIN_CLIP) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -821,7 +822,7 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
                 blend_stack[clip_depth][i] = packed;
             } else {
                 uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
-                if (ix < cfg.blend_size) blend_spill[ix] = packed;
+                if (ix < blend_size) blend_spill[ix] = packed;
             }
             rgba[i] = vec4{0.0f, 0.0f, 0.0f, 0.0f};
         }
@@ -838,7 +839,7 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
                 bg_rgba = blend_stack[clip_depth][i];
             } else {
                 uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + lane * 4u + (uint32_t)i;
-                bg_rgba = ix < cfg.blend_size ? blend_spill[ix] : 0u;
+                bg_rgba = ix < blend_size ? blend_spill[ix] : 0u;
             }
             const vec4 bg = unpack4x8unorm(bg_rgba);
             const vec4 fg = (rgba[i] * area[i]) * alpha;
@@ -1100,7 +1101,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             }
             st.clip_depth = clip_depth;
             st.cmd_ix = cmd_ix;
-            rare_command<BRUSHES>(st, blend_stack, tag, cfg, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+            rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
                                   atlas_texels, atlas_w, atlas_h);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
