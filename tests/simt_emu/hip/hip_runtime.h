@@ -161,6 +161,8 @@ static inline unsigned atomicAdd(unsigned *p, int v) { unsigned o = *p; *p = o +
 static inline int atomicAdd(int *p, unsigned v) { int o = *p; *p = (int)((unsigned)o + v); return o; }
 template <class T>
 static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T>
+static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 template <class T>
 static inline T atomicXor(T *p, T v) { T o = *p; *p = o ^ v; return o; }
 template <class T>
