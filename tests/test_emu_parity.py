@@ -160,3 +160,11 @@ def test_emu_flatten_staging_overflow(emu_engine):
     packed, layout = workloads.heavy_strokes_scene().resolve()
     img, ref, bump = compare_frame(emu_engine, packed, layout, 1024, 1024, BLACK, AaConfig.Msaa8, "emu_heavy_strokes")
     assert bump["lines"] > 3072
+
+
+@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths"])
+def test_emu_reference_test_scenes(emu_engine, which):
+    # scenes of the reference's own catalogue (examples/scenes/src/test_scenes.rs:513-770, :1610-1691)
+    scene, w, h = getattr(workloads, which + "_scene")()
+    packed, layout = scene.resolve()
+    compare_frame(emu_engine, packed, layout, w, h, BLACK, AaConfig.Msaa16, "emu_" + which)

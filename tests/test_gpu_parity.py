@@ -256,3 +256,35 @@ def test_flatten_staging_overflow(gpu_engine):
     packed, layout = workloads.heavy_strokes_scene().resolve()
     img, ref, bump = compare_frame(gpu_engine, packed, layout, 1024, 1024, BLACK, AaConfig.Msaa16, "gpu_heavy_strokes")
     assert bump["lines"] > 3072
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
+@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths"])
+def test_reference_test_scenes(gpu_engine, which, aa):
+    # examples/scenes/src/test_scenes.rs: cusps / 180-degree turns / degenerate cubics under the stroker (:513-697),
+    # self-intersections under both fill rules (:699-770), edges exactly on tile boundaries (:1610-1691)
+    scene, w, h = getattr(workloads, which + "_scene")()
+    packed, layout = scene.resolve()
+    compare_frame(gpu_engine, packed, layout, w, h, BLACK, aa, f"gpu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+
+
+def test_tricky_strokes_round_joins_and_caps(gpu_engine):
+    # the same cubics with round joins and caps: every arc goes through the fp64 sin / cos / acos / atan2 paths
+    from vello_amd import Cap, Join
+
+    scene, w, h = workloads.tricky_strokes_scene(join=Join.Round, cap=Cap.Round)
+    packed, layout = scene.resolve()
+    compare_frame(gpu_engine, packed, layout, w, h, WHITE, AaConfig.Msaa8, "gpu_tricky_round")
+
+
+def test_config_c5_all_eight_seeds(gpu_engine):
+    # BASELINE config C5: the eight per-GPU scenes (seeds 0x5EED0001..8), images against the oracle (tile-parallel)
+    from oracle.oracle import Oracle
+
+    o = Oracle()
+    o.set_threads(32)
+    for k in range(1, 8):  # seed ...0001 is test_config_c3_paris_like_full_size
+        packed, layout = workloads.paris_like_scene(0x5EED0001 + k).resolve()
+        img, ref, bump = compare_frame(gpu_engine, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, f"gpu_paris_seed{k}",
+                                       check_stages=False, oracle=o)
+        assert bump["failed"] == 0

@@ -1,0 +1,148 @@
+"""Scenes restated from the reference's own test-scene catalogue (examples/scenes/src/test_scenes.rs): the inputs the
+upstream snapshot tests render.  The geometry tables are the reference's test vectors; everything is rebuilt on this
+repo's Scene API.  Used for oracle-relative parity (the upstream snapshots themselves are Git-LFS stubs)."""
+import numpy as np
+
+from vello_amd import Affine, BezPath, Cap, Color, Fill, Join, Rect, Scene, Stroke
+
+# test_scenes.rs:549-576 (tricky_strokes): cusps, near-cusps, 180-degree turns, degenerate and flat cubics
+TRICKY_CUBICS = [
+    [(122., 737.), (348., 553.), (403., 761.), (400., 760.)],
+    [(244., 520.), (244., 518.), (1141., 634.), (394., 688.)],
+    [(550., 194.), (138., 130.), (1035., 246.), (288., 300.)],
+    [(226., 733.), (556., 779.), (-43., 471.), (348., 683.)],
+    [(268., 204.), (492., 304.), (352., 23.), (433., 412.)],
+    [(172., 480.), (396., 580.), (256., 299.), (338., 677.)],
+    [(731., 340.), (318., 252.), (1026., -64.), (367., 265.)],
+    [(475., 708.), (62., 620.), (770., 304.), (220., 659.)],
+    [(0., 0.), (128., 128.), (128., 0.), (0., 128.)],
+    [(0., 0.01), (128., 127.999), (128., 0.01), (0., 127.99)],
+    [(0., -0.01), (128., 128.001), (128., -0.01), (0., 128.001)],
+    [(0., 0.), (0., -10.), (0., -10.), (0., 10.)],
+    [(10., 0.), (0., 0.), (20., 0.), (10., 0.)],
+    [(39., -39.), (40., -40.), (40., -40.), (0., 0.)],
+    [(40., 40.), (0., 0.), (200., 200.), (0., 0.)],
+    [(0., 0.), (1e-2, 0.), (-1e-2, 0.), (0., 0.)],
+    [(400.75, 100.05), (400.75, 100.05), (100.05, 300.95), (100.05, 300.95)],
+    [(0.5, 0.), (0., 0.), (20., 0.), (10., 0.)],
+    [(10., 0.), (0., 0.), (10., 0.), (10., 0.)],
+]
+# test_scenes.rs:579-582, :621-638: flat quads with cusps (the 1.5-weight conic lowered to quads)
+FLAT_QUAD = [[(2., 1.), (1., 1.)]]
+BIGGER_FLAT_CONIC_AS_QUADS = [
+    [(8.979845, 1.0), (15.795975, 1.0)], [(22.612104, 1.0), (28.363287, 1.0)], [(34.114471, 1.0), (38.884045, 1.0)],
+    [(43.653618, 1.0), (47.510696, 1.0)], [(51.367767, 1.0), (54.368233, 1.0)], [(57.368698, 1.0), (59.556030, 1.0)],
+    [(61.743366, 1.0), (63.149269, 1.0)], [(64.555168, 1.0), (65.200005, 1.0)], [(65.844841, 1.0), (65.737961, 1.0)],
+    [(65.631073, 1.0), (64.770912, 1.0)], [(63.910763, 1.0), (62.284878, 1.0)], [(60.658997, 1.0), (58.243816, 1.0)],
+    [(55.828640, 1.0), (52.589172, 1.0)], [(49.349705, 1.0), (45.239006, 1.0)], [(41.128315, 1.0), (36.086826, 1.0)],
+    [(31.045338, 1.0), (25.000000, 1.0)],
+]
+_COLORS = [(140, 181, 236), (246, 236, 202), (201, 147, 206), (150, 195, 160)]
+
+
+def _cubic_bounds(pts, n=512):
+    t = np.linspace(0.0, 1.0, n)[:, None]
+    p = [np.array(q, dtype=np.float64) for q in pts]
+    c = ((1 - t) ** 3) * p[0] + 3 * ((1 - t) ** 2) * t * p[1] + 3 * (1 - t) * t * t * p[2] + (t ** 3) * p[3]
+    return c[:, 0].min(), c[:, 1].min(), c[:, 0].max(), c[:, 1].max()
+
+
+def _map_rect_to_rect(src, dst):
+    sw, sh = max(src[2] - src[0], 1e-9), max(src[3] - src[1], 1e-9)
+    dw, dh = dst[2] - dst[0], dst[3] - dst[1]
+    sx, sy = dw / sw, dh / sh
+    scale = min(sx, sy)
+    tx, ty = dst[0] - src[0] * scale, dst[1] - src[1] * scale
+    if sx > sy:
+        tx += 0.5 * (dw - sw * scale)
+    else:
+        ty += 0.5 * (dh - sh * scale)
+    return Affine((scale, 0.0, 0.0, scale, tx, ty)), scale
+
+
+def tricky_strokes_scene(join=Join.Miter, cap=Cap.Butt):
+    """test_scenes.rs:513-697; returns (scene, width, height).  Cell bounds come from a sampled bounding box instead of
+    kurbo's exact CubicBez::bounding_box (kurbo is not in the tree): placement differs by a fraction of a pixel."""
+    cell, sw, cols = 200.0, 30.0, 5
+    s = Scene()
+    idx = 0
+    for i, cub in enumerate(TRICKY_CUBICS):
+        x, y = (i % cols) * cell, (i // cols) * cell
+        b = _cubic_bounds(cub)
+        t, sc = _map_rect_to_rect((b[0] - sw, b[1] - sw, b[2] + sw, b[3] + sw), (x, y, x + cell, y + cell))
+        p = BezPath()
+        p.move_to(cub[0])
+        p.curve_to(cub[1], cub[2], cub[3])
+        s.stroke(Stroke(sw / sc).with_caps(cap).with_join(join), t, Color.from_rgb8(*_COLORS[i % 4]), None, p)
+        idx += 1
+    for quads in (FLAT_QUAD, BIGGER_FLAT_CONIC_AS_QUADS):
+        p = BezPath()
+        p.move_to((1.0, 1.0))
+        xs = [1.0]
+        for q in quads:
+            p.quad_to(q[0], q[1])
+            xs += [q[0][0], q[1][0]]
+        x, y = (idx % cols) * cell, (idx // cols) * cell
+        t, sc = _map_rect_to_rect((min(xs) - sw, 1.0 - sw, max(xs) + sw, 1.0 + sw), (x, y, x + cell, y + cell))
+        s.stroke(Stroke(sw / sc).with_caps(cap).with_join(join), t, Color.from_rgb8(*_COLORS[idx % 4]), None, p)
+        idx += 1
+    n = len(TRICKY_CUBICS) + 2
+    return s, int(cell * cols), int(cell * (1 + n // cols))
+
+
+def fill_types_scene():
+    """test_scenes.rs:699-770 without the text labels: self-intersecting star and overlapping arcs under both fill rules,
+    then the same with rotated translucent copies.  1400 x 700."""
+    s = Scene()
+    rect = Rect(0.0, 0.0, 500.0, 500.0)
+    star = BezPath()
+    star.move_to((250., 0.)); star.line_to((105., 450.)); star.line_to((490., 175.)); star.line_to((10., 175.))
+    star.line_to((395., 450.)); star.close_path()
+    arcs = BezPath()
+    arcs.move_to((0., 480.)); arcs.curve_to((500., 480.), (500., -10.), (0., -10.)); arcs.close_path()
+    arcs.move_to((500., -10.)); arcs.curve_to((0., -10.), (0., 480.), (500., 480.)); arcs.close_path()
+    gray, yellow = Color.from_rgb8(128, 128, 128), Color.from_rgb8(255, 255, 0)
+    rules = [(Fill.NonZero, star), (Fill.EvenOdd, star), (Fill.NonZero, arcs), (Fill.EvenOdd, arcs)]
+    scale = Affine.scale(0.6)
+    t0 = Affine.translate(10., 25.)
+    for blends in (False, True):
+        tb = Affine.translate(700., 0.) * t0 if blends else t0
+        for i, (rule, path) in enumerate(rules):
+            t = Affine.translate((i % 2) * 306., (i // 2) * 340.) * tb
+            t = Affine.translate(0., 5.) * t * scale
+            s.fill(Fill.NonZero, t, gray, None, rect)
+            s.fill(rule, Affine.translate(0., 10.) * t, yellow, None, path)
+            if blends:
+                s.fill(rule, Affine.translate(0., 10.) * t * Affine.rotate(0.06), Color(0., 1., 0.7, 0.6), None, path)
+                s.fill(rule, Affine.translate(0., 10.) * t * Affine.rotate(-0.06), Color(0.9, 0.7, 0.5, 0.6), None, path)
+    return s, 1400, 700
+
+
+def robust_paths_scene():
+    """test_scenes.rs:1610-1691: axis-aligned and tile-boundary-aligned polygons (edges exactly on multiples of 16),
+    the cases the ROBUST_EPSILON / ONE_MINUS_ULP handling exists for.  600 x 160."""
+    p = BezPath()
+    polys = [
+        [(16, 16), (32, 16), (32, 32), (16, 32)],
+        [(48, 18), (64, 23), (64, 33), (48, 38)],
+        [(80, 18), (82, 16), (94, 16), (96, 18), (96, 30), (94, 32), (82, 32), (80, 30)],
+        [(112, 16), (128, 16), (128, 32)],
+        [(144, 16), (160, 32), (144, 32)],
+        [(168, 8), (184, 8), (184, 24)],
+        [(200, 8), (216, 24), (200, 24)],
+        [(241, 17.5), (255, 17.5), (255, 19.5), (241, 19.5)],
+        [(241, 22.5), (256, 22.5), (256, 24.5), (241, 24.5)],
+    ]
+    for poly in polys:
+        p.move_to(poly[0])
+        for q in poly[1:]:
+            p.line_to(q)
+        p.close_path()
+    s = Scene()
+    yellow, lime = Color.from_rgb8(255, 255, 0), Color.from_rgb8(0, 255, 0)
+    s.fill(Fill.NonZero, Affine.IDENTITY, yellow, None, p)
+    s.fill(Fill.EvenOdd, Affine.translate(300.0, 0.0), lime, None, p)
+    p.move_to((8.0, 4.0)); p.line_to((8.0, 40.0)); p.line_to((260.0, 40.0)); p.line_to((260.0, 4.0)); p.close_path()
+    s.fill(Fill.NonZero, Affine.translate(0.0, 100.0), yellow, None, p)
+    s.fill(Fill.EvenOdd, Affine.translate(300.0, 100.0), lime, None, p)
+    return s, 600, 160
