@@ -89,6 +89,11 @@ def test_emu_frames_in_flight_rotate_lanes(built):
         assert eng.sync() == 0
         with pytest.raises(Exception):
             eng.sync_frame(3)
+        eng.set_frames_in_flight(1)                # shrink: back to one frame at a time
+        with pytest.raises(Exception):
+            eng.sync_frame(1)
+        eng.render_resident(96, 96, BLACK, AaConfig.Area)
+        assert eng.sync() == 0
     finally:
         L._use_library(None)
 

@@ -57,6 +57,7 @@ struct vello_hip_ctx {
     DevBuf atlas;  // persistent image atlas (render.rs:160-176), shared by all lanes
     uint32_t atlas_w = 0, atlas_h = 0;
     std::vector<Lane> lanes;
+    uint32_t n_active = 1;  // lanes in the rotation (<= lanes.size(): shrinking keeps the buffers)
     uint32_t next_lane = 0, last_lane = 0;
     uint32_t n_ramps = 0;
     bool scene_resident = false;
@@ -436,13 +437,16 @@ int vello_hip_set_frames_in_flight(vello_hip_ctx *c, uint32_t n) {
     int r = sync_all(c);
     if (r) return r;
     size_t old = c->lanes.size();
-    if (n < old) return VELLO_HIP_OK;  // lanes are kept; only the rotation shrinks
-    c->lanes.resize(n);
-    for (size_t i = old; i < n; i++) {
-        if ((r = alloc_lane_pools(c, c->lanes[i]))) return r;
-        if (c->scene_resident && (r = alloc_lane_scene(c, c->lanes[i]))) return r;
+    if (n > old) {
+        c->lanes.resize(n);
+        for (size_t i = old; i < n; i++) {
+            if ((r = alloc_lane_pools(c, c->lanes[i]))) return r;
+            if (c->scene_resident && (r = alloc_lane_scene(c, c->lanes[i]))) return r;
+        }
     }
+    c->n_active = n;  // shrinking keeps the extra lanes' buffers; only the rotation changes
     c->next_lane = 0;
+    c->last_lane = 0;
     return VELLO_HIP_OK;
 }
 
@@ -540,8 +544,8 @@ int vello_hip_write_image(vello_hip_ctx *c, uint32_t x, uint32_t y, uint32_t wid
 int vello_hip_render_resident(vello_hip_ctx *c, const vello_hip_render_params *params, void *out_device, size_t out_stride) {
     if (!c) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    uint32_t li = c->next_lane % (uint32_t)c->lanes.size();
-    c->next_lane = (li + 1u) % (uint32_t)c->lanes.size();
+    uint32_t li = c->next_lane % c->n_active;
+    c->next_lane = (li + 1u) % c->n_active;
     c->last_lane = li;
     Frame f;
     int r = prepare_frame(c, c->lanes[li], params, out_device, out_stride, f, false);
@@ -571,9 +575,9 @@ int vello_hip_get_bump(vello_hip_ctx *c, vello_hip_bump *out) {
 }
 
 int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
-    if (!c || age >= c->lanes.size()) return VELLO_HIP_E_INVALID;
+    if (!c || age >= c->n_active) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    uint32_t n = (uint32_t)c->lanes.size();
+    uint32_t n = c->n_active;
     Lane &l = c->lanes[(c->last_lane + n - age) % n];
     HIP_TRY(c, hipStreamSynchronize(l.stream));
     return VELLO_HIP_OK;
