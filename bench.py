@@ -183,7 +183,10 @@ def main():
     all_ms = engine.stage_ms()
     engine.set_profiling([])
 
-    # PCIe-inclusive rate (never `value`): host scene bytes -> H2D -> full frame, one frame in flight
+    # PCIe-inclusive rates (never `value`): the packed scene starts in host memory every frame.
+    #  (a) serial: upload, render, wait -- what a blocking render_to_texture does;
+    #  (b) pipelined: vello_hip_render_frame puts each frame's scene into the next in-flight slot, so the H2D copy of
+    #      frame i+1 overlaps the kernels of the frames before it (animation form).
     n_pcie = 0 if args.timed_only else 20
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -191,7 +194,17 @@ def main():
         engine.upload_scene(packed, layout)
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
         engine.sync()
-    pcie_fps = n_pcie / (time.perf_counter() - t1)
+    pcie_fps = n_pcie / max(time.perf_counter() - t1, 1e-9)
+    n_pipe = 0 if args.timed_only else 60
+    for i in range(min(n_pipe, nif)):  # warm the private scene slots (first use allocates)
+        engine.render_frame(packed, layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
+    engine.sync()
+    t1 = time.perf_counter()
+    for i in range(n_pipe):
+        engine.render_frame(packed, layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
+    engine.sync()
+    pcie_pipelined_fps = n_pipe / max(time.perf_counter() - t1, 1e-9)
+    engine.upload_scene(packed, layout)  # back to the shared resident scene
     if args.timed_only:
         all_ms = {k: (0.0, 0) for k in vello_amd.renderer.STAGES}
         all_ms[dominant] = (dom_ms, dom_n)
@@ -243,6 +256,7 @@ def main():
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
             "serial_frame_latency_ms": round(serial_ms, 4),
             "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
+            "pcie_inclusive_pipelined_frames_per_s": round(pcie_pipelined_fps, 2),
         },
         "roofline": {
             "bound": "hbm",

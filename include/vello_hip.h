@@ -14,6 +14,7 @@
  *   vello_hip_render           Renderer::render_to_texture               vello/src/lib.rs:474-515
  *                              = render_full + WgpuEngine::run_recording vello/src/render.rs:84-112,
  *                                                                        vello/src/wgpu_engine.rs:380-777
+ *   vello_hip_render_frame     render_to_texture without the wait        vello/src/lib.rs:474-515, wgpu_engine.rs:757
  *   vello_hip_upload_scene     Command::Upload("vello.scene") +          vello/src/render.rs:229-232,
  *                              Command::UploadUniform("vello.config")    vello/src/recording.rs:124-140
  *   vello_hip_render_resident  the Dispatch/DispatchIndirect chain       vello/src/render.rs:250-502, :560-629
@@ -145,6 +146,16 @@ int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scen
 /* ... then each call enqueues one full frame (all stages) on the context's stream and returns
  * without waiting.  `out_device` may be NULL (render into the internal target only). */
 int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
+/* Animation form (every frame has its own scene): vello_hip_upload_scene + vello_hip_render_resident in one call
+ * that does NOT wait for the frame.  The scene is copied into the private slot of the next in-flight buffer set
+ * (only that set's previous frame is waited for), so with vello_hip_set_frames_in_flight(n > 1) the upload of frame
+ * i+1 overlaps the rendering of frames i, i-1, ...  `scene` / `ramps` may be reused when the call returns; the target
+ * is complete after vello_hip_sync_frame(0) / vello_hip_sync.  Replaces, per frame, the same reference calls as
+ * vello_hip_render (vello/src/lib.rs:474-515) under wgpu's submit-without-wait (vello/src/wgpu_engine.rs:757). */
+int vello_hip_render_frame(vello_hip_ctx *ctx, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                           const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_device,
+                           size_t out_stride);
+
 /* The image atlas: one RGBA8 texture that persists across frames (render.rs:160-176).  The Resolver owns
  * the packing: it patches every DrawImage's atlas xy (resolve.rs:300-316) and lists the images to (re)write.
  * resize discards the contents (zero-filled), as creating a new ImageProxy does.  Texel bytes are stored

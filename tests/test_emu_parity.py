@@ -173,3 +173,37 @@ def test_emu_reference_test_scenes(emu_engine, which):
     scene, w, h = getattr(workloads, which + "_scene")()
     packed, layout = scene.resolve()
     compare_frame(emu_engine, packed, layout, w, h, BLACK, AaConfig.Msaa16, "emu_" + which)
+
+
+def test_emu_render_frame_keeps_a_scene_per_lane(built):
+    # vello_hip_render_frame: every in-flight frame has its OWN scene (animation form); lanes must not see each other's
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        eng = vello_amd.Engine()
+        eng.set_frames_in_flight(3)
+        scenes = [workloads.stroke_styles_scene(), workloads.clip_blend_scene(), workloads.smoke_circle_scene(),
+                  workloads.random_test_scene(3, n_paths=60, size=128.0)]
+        o = Oracle()
+        for rep in range(2):
+            for k, sc in enumerate(scenes):
+                packed, layout = sc.resolve()
+                w, h, aa = (128, 128, AaConfig.Msaa8) if k != 2 else (20, 20, AaConfig.Msaa16)
+                eng.render_frame(packed, layout, w, h, BLACK, aa)
+                eng.sync_frame(0)
+                img = eng.read_buffer("output", np.uint8, w * h * 4).reshape(h, w, 4)
+                o.set_scene(packed, layout, w, h, BLACK, int(aa))
+                assert np.array_equal(img, o.render()), (rep, k)
+        assert eng.sync() == 0
+        # the shared-scene form takes over again
+        packed, layout = scenes[0].resolve()
+        eng.upload_scene(packed, layout)
+        eng.render_resident(128, 128, WHITE, AaConfig.Msaa8)
+        eng.sync_frame(0)
+        o.set_scene(packed, layout, 128, 128, WHITE, int(AaConfig.Msaa8))
+        assert np.array_equal(eng.read_buffer("output", np.uint8, 128 * 128 * 4).reshape(128, 128, 4), o.render())
+    finally:
+        L._use_library(None)

@@ -288,3 +288,23 @@ def test_config_c5_all_eight_seeds(gpu_engine):
         img, ref, bump = compare_frame(gpu_engine, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, f"gpu_paris_seed{k}",
                                        check_stages=False, oracle=o)
         assert bump["failed"] == 0
+
+
+def test_render_frame_pipelines_scenes(built):
+    # animation form: a different scene per frame, 3 frames in flight, targets checked after the whole burst
+    import torch
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    eng = vello_amd.Engine()
+    eng.set_frames_in_flight(3)
+    scenes = [workloads.random_test_scene(10 + k, n_paths=300, size=320.0, strokes=True, clips=(k % 2 == 1)).resolve() for k in range(3)]
+    targets = [torch.zeros((320, 320, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+    for rep in range(3):
+        for k in range(3):
+            eng.render_frame(scenes[k][0], scenes[k][1], 320, 320, BLACK, AaConfig.Msaa16, out=targets[k])
+    assert eng.sync() == 0
+    o = Oracle()
+    for k in range(3):
+        o.set_scene(scenes[k][0], scenes[k][1], 320, 320, BLACK, int(AaConfig.Msaa16))
+        assert np.array_equal(o.render(), targets[k].cpu().numpy()), k

@@ -73,6 +73,7 @@ def load_library():
     sig("vello_hip_destroy", None, [vp])
     sig("vello_hip_render", i32, [vp, vp, sz, c.POINTER(LayoutStruct), c.POINTER(RenderParamsStruct), vp, u32, vp, sz, i32, c.POINTER(Bump)])
     sig("vello_hip_upload_scene", i32, [vp, vp, sz, c.POINTER(LayoutStruct), vp, u32])
+    sig("vello_hip_render_frame", i32, [vp, vp, sz, c.POINTER(LayoutStruct), c.POINTER(RenderParamsStruct), vp, u32, vp, sz])
     sig("vello_hip_render_resident", i32, [vp, c.POINTER(RenderParamsStruct), vp, sz])
     sig("vello_hip_set_frames_in_flight", i32, [vp, u32])
     sig("vello_hip_resize_image_atlas", i32, [vp, u32, u32])

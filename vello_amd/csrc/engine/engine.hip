@@ -34,8 +34,21 @@ uint32_t align_up(uint32_t len, uint32_t alignment) { return len + ((0u - len) &
 // ramps and mask LUTs are shared read-only.  wgpu queues recordings without waiting (wgpu_engine.rs:757); here
 // consecutive frames additionally overlap on the GPU (coarse launches only one workgroup per bin, fine and
 // flatten are latency-bound, so a second frame fills the idle CUs): vello_hip_set_frames_in_flight.
+// A packed scene made resident: the bytes, the ramp texture and everything the host derives from the Layout.
+struct SceneSlot {
+    DevBuf scene, ramps;
+    vello_hip_layout layout{};
+    size_t scene_len = 0;
+    uint32_t n_tag_words = 0, n_pathtag_parts = 0, n_draw_parts = 0, n_ramps = 0;
+    size_t zero_bytes = 0;
+    bool brushes = false;   // gradient / image / blurred-rect draw objects present (selects fine's specialisation)
+    bool resident = false;
+};
+
 struct Lane {
     hipStream_t stream = nullptr;
+    SceneSlot own;          // vello_hip_render_frame: the scene of the frame this lane is rendering
+    bool use_own = false;   // else the context's shared scene (vello_hip_upload_scene)
     DevBuf buf[VELLO_HIP_BUF_COUNT];  // SCENE / CONFIG entries unused (shared, see ctx)
     DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
     DevBuf clip_stack;
@@ -52,21 +65,15 @@ struct vello_hip_ctx {
     int device = 0;
     uint32_t aa_mask = 0;
     vello_hip_capacities caps{};
-    DevBuf scene, config;
-    DevBuf ramps, mask8, mask16;
+    DevBuf config;
+    DevBuf mask8, mask16;
+    SceneSlot shared;  // vello_hip_upload_scene: one scene for every lane
     DevBuf atlas;  // persistent image atlas (render.rs:160-176), shared by all lanes
     uint32_t atlas_w = 0, atlas_h = 0;
     std::vector<Lane> lanes;
     uint32_t n_active = 1;  // lanes in the rotation (<= lanes.size(): shrinking keeps the buffers)
     uint32_t next_lane = 0, last_lane = 0;
-    uint32_t n_ramps = 0;
-    bool scene_resident = false;
-    bool scene_brushes = false;
     bool auto_grow = false;
-    vello_hip_layout layout{};
-    size_t scene_len = 0;
-    uint32_t n_tag_words = 0, n_pathtag_parts = 0, n_draw_parts = 0;
-    size_t zero_bytes = 0;
     // last frame
     Config cfg{};
     bool have_cfg = false;
@@ -132,14 +139,16 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     return 0;
 }
 
+SceneSlot &slot_of(vello_hip_ctx *c, Lane &l) { return l.use_own ? l.own : c->shared; }
+
 // scene-dependent buffers of one lane
-int alloc_lane_scene(vello_hip_ctx *c, Lane &l) {
-    const vello_hip_layout &L = c->layout;
+int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
+    const vello_hip_layout &L = sc.layout;
     int r;
-    if ((r = ensure(c, l.zero_region, c->zero_bytes))) return r;
+    if ((r = ensure(c, l.zero_region, sc.zero_bytes))) return r;
     l.buf[VELLO_HIP_BUF_BUMP].ptr = l.zero_region.ptr;
     l.buf[VELLO_HIP_BUF_BUMP].size = sizeof(Bump);
-    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(c->n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
+    if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(sc.n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATH_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(PathBbox)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_MONOIDS], (size_t)(L.n_draw_objects + 1u) * sizeof(DrawMonoid)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_CLIP_INP], (size_t)(L.n_clips + 1u) * sizeof(Clip)))) return r;
@@ -147,12 +156,12 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
-    if ((r = ensure(c, l.heavy_list, (size_t)(c->n_tag_words + 1u) * 32u))) return r;  // 2 lists x 4 tags per word x u32
+    if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 32u))) return r;  // 2 lists x 4 tags per word x u32
     return 0;
 }
 
 // RenderConfig::new + BufferSizes::new, vello_encoding/src/config.rs:168-196, :363-435
-int configure(vello_hip_ctx *c, const vello_hip_render_params *p, Config &cfg) {
+int configure(vello_hip_ctx *c, const SceneSlot &sc, const vello_hip_render_params *p, Config &cfg) {
     if (!p || p->width == 0 || p->height == 0 || p->aa > VELLO_HIP_AA_MSAA16) {
         c->last_error = "invalid render params";
         return VELLO_HIP_E_INVALID;
@@ -168,14 +177,14 @@ int configure(vello_hip_ctx *c, const vello_hip_render_params *p, Config &cfg) {
     cfg.target_width = p->width;
     cfg.target_height = p->height;
     cfg.base_color = p->base_color;
-    std::memcpy(&cfg.layout, &c->layout, sizeof(Layout));
+    std::memcpy(&cfg.layout, &sc.layout, sizeof(Layout));
     uint32_t bin_data = c->caps.bin_data;
-    if (bin_data <= c->layout.bin_data_start) {
+    if (bin_data <= sc.layout.bin_data_start) {
         c->last_error = "bin_data capacity smaller than the scene's info words";
         return VELLO_HIP_E_INVALID;
     }
     cfg.lines_size = c->caps.lines;
-    cfg.binning_size = bin_data - c->layout.bin_data_start;
+    cfg.binning_size = bin_data - sc.layout.bin_data_start;
     cfg.tiles_size = c->caps.tiles;
     cfg.seg_counts_size = c->caps.seg_counts;
     cfg.segments_size = c->caps.segments;
@@ -191,28 +200,29 @@ int configure(vello_hip_ctx *c, const vello_hip_render_params *p, Config &cfg) {
 
 int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, void *out_device, size_t out_stride, Frame &f,
                   bool upload_cfg) {
-    if (!c->scene_resident) {
+    const SceneSlot &sc = slot_of(c, l);
+    if (!sc.resident) {
         c->last_error = "no scene uploaded";
         return VELLO_HIP_E_INVALID;
     }
-    int r = configure(c, p, f.cfg);
+    int r = configure(c, sc, p, f.cfg);
     if (r) return r;
     c->cfg = f.cfg;
     c->have_cfg = true;
     // size-dependent buffers
     uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
     uint32_t aligned_n_bins = align_up(wb * hb, 256u);
-    uint32_t binning_wgs = (c->layout.n_draw_objects + 255u) / 256u;
+    uint32_t binning_wgs = (sc.layout.n_draw_objects + 255u) / 256u;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
     if (!out_device && (r = ensure(c, l.buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
     // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
     if (upload_cfg) HIP_TRY(c, hipMemcpy(c->config.ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
-    f.n_tag_words = c->n_tag_words;
+    f.n_tag_words = sc.n_tag_words;
     f.aa = p->aa;
-    f.scene = (const uint32_t *)c->scene.ptr;
+    f.scene = (const uint32_t *)sc.scene.ptr;
     f.control = (Control *)l.zero_region.ptr;
     f.pathtag_state = (unsigned long long *)((char *)l.zero_region.ptr + sizeof(Control));
-    f.draw_state = f.pathtag_state + (size_t)c->n_pathtag_parts * 10u;
+    f.draw_state = f.pathtag_state + (size_t)sc.n_pathtag_parts * 10u;
     f.tag_monoids = (TagMonoid *)l.buf[VELLO_HIP_BUF_TAG_MONOIDS].ptr;
     f.path_bboxes = (PathBbox *)l.buf[VELLO_HIP_BUF_PATH_BBOXES].ptr;
     f.lines = (LineSoup *)l.buf[VELLO_HIP_BUF_LINES].ptr;
@@ -237,9 +247,9 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
         f.output = (uint8_t *)l.buf[VELLO_HIP_BUF_OUTPUT].ptr;
         f.out_stride = (size_t)p->width * 4u;
     }
-    f.ramps = c->n_ramps ? (const uint32_t *)c->ramps.ptr : nullptr;
-    f.n_ramps = c->n_ramps;
-    f.brushes = c->scene_brushes;
+    f.ramps = sc.n_ramps ? (const uint32_t *)sc.ramps.ptr : nullptr;
+    f.n_ramps = sc.n_ramps;
+    f.brushes = sc.brushes;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
     f.atlas_w = c->atlas_w;
     f.atlas_h = c->atlas_h;
@@ -262,7 +272,7 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f, int first, int la
         switch (s) {
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
-            HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, c->zero_bytes, st));
+            HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, slot_of(c, l).zero_bytes, st));
             launch_pathtag_scan(f, st);
             break;
         case VELLO_HIP_STAGE_FLATTEN: launch_flatten(f, st); break;
@@ -303,7 +313,7 @@ int drain_events(vello_hip_ctx *c) {
 }
 
 DevBuf *find_buf(vello_hip_ctx *c, int id) {
-    if (id == VELLO_HIP_BUF_SCENE) return &c->scene;
+    if (id == VELLO_HIP_BUF_SCENE) return &slot_of(c, c->lanes[c->last_lane]).scene;
     if (id == VELLO_HIP_BUF_CONFIG) return &c->config;
     return &c->lanes[c->last_lane].buf[id];
 }
@@ -426,7 +436,10 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf *b : {&c->scene, &c->config, &c->ramps, &c->mask8, &c->mask16, &c->atlas})
+    for (auto &l : c->lanes)
+        for (DevBuf *b : {&l.own.scene, &l.own.ramps})
+            if (b->ptr) (void)hipFree(b->ptr);
+    for (DevBuf *b : {&c->shared.scene, &c->shared.ramps, &c->config, &c->mask8, &c->mask16, &c->atlas})
         if (b->ptr) (void)hipFree(b->ptr);
     delete c;
 }
@@ -441,7 +454,7 @@ int vello_hip_set_frames_in_flight(vello_hip_ctx *c, uint32_t n) {
         c->lanes.resize(n);
         for (size_t i = old; i < n; i++) {
             if ((r = alloc_lane_pools(c, c->lanes[i]))) return r;
-            if (c->scene_resident && (r = alloc_lane_scene(c, c->lanes[i]))) return r;
+            if (c->shared.resident && (r = alloc_lane_scene(c, c->lanes[i], c->shared))) return r;
         }
     }
     c->n_active = n;  // shrinking keeps the extra lanes' buffers; only the rotation changes
@@ -450,10 +463,11 @@ int vello_hip_set_frames_in_flight(vello_hip_ctx *c, uint32_t n) {
     return VELLO_HIP_OK;
 }
 
-int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
-                           const uint32_t *ramps, uint32_t n_ramps) {
-    if (!c || (!scene && scene_len) || !layout || (scene_len & 3u)) return VELLO_HIP_E_INVALID;
-    HIP_TRY(c, hipSetDevice(c->device));
+// Validates the layout, sizes the slot and copies scene + ramps on `st`; returns once the source buffers may be
+// reused (they are caller-owned only for the duration of the call, recording.rs:124-129).
+static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint8_t *scene, size_t scene_len,
+                     const vello_hip_layout *layout, const uint32_t *ramps, uint32_t n_ramps) {
+    if ((!scene && scene_len) || !layout || (scene_len & 3u)) return VELLO_HIP_E_INVALID;
     const vello_hip_layout &L = *layout;
     size_t words = scene_len / 4u;
     if (L.path_tag_base > L.path_data_base || L.path_data_base > L.draw_tag_base || L.draw_tag_base > L.draw_data_base ||
@@ -467,46 +481,77 @@ int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_
         return VELLO_HIP_E_INVALID;
     }
     int r;
-    // frames still in flight read the old scene
-    if ((r = sync_all(c))) return r;
     // 64 B of slack: flatten reads tag ix+1 and the (wrapped) style word of pre-style tags speculatively
-    if ((r = ensure(c, c->scene, scene_len + 64))) return r;
-    c->layout = L;
-    c->scene_len = scene_len;
+    if ((r = ensure(c, sc.scene, scene_len + 64))) return r;
+    sc.layout = L;
+    sc.scene_len = scene_len;
     uint32_t n_path_tags = (L.path_data_base - L.path_tag_base) * 4u;
-    c->n_tag_words = align_up(n_path_tags, 1024u) / 4u;
-    c->n_pathtag_parts = (c->n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
-    if (c->n_pathtag_parts == 0) c->n_pathtag_parts = 1;
-    c->n_draw_parts = (L.n_draw_objects + DRAW_PART - 1u) / DRAW_PART;
-    c->zero_bytes = sizeof(Control) + ((size_t)c->n_pathtag_parts * 10u + (size_t)c->n_draw_parts * 8u) * 8u;
-    for (auto &l : c->lanes)
-        if ((r = alloc_lane_scene(c, l))) return r;
+    sc.n_tag_words = align_up(n_path_tags, 1024u) / 4u;
+    sc.n_pathtag_parts = (sc.n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
+    if (sc.n_pathtag_parts == 0) sc.n_pathtag_parts = 1;
+    sc.n_draw_parts = (L.n_draw_objects + DRAW_PART - 1u) / DRAW_PART;
+    sc.zero_bytes = sizeof(Control) + ((size_t)sc.n_pathtag_parts * 10u + (size_t)sc.n_draw_parts * 8u) * 8u;
     // Which fine specialisation the scene needs: any draw tag other than COLOR / BEGIN_CLIP / END_CLIP / NOP
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
-    c->scene_brushes = false;
+    sc.brushes = false;
     {
         const uint32_t *words_p = reinterpret_cast<const uint32_t *>(scene);
         for (uint32_t i = 0; i < L.n_draw_objects; i++) {
             uint32_t t = words_p[L.draw_tag_base + i];
             if (t != DRAWTAG_FILL_COLOR && t != DRAWTAG_BEGIN_CLIP && t != DRAWTAG_END_CLIP && t != DRAWTAG_NOP) {
-                c->scene_brushes = true;
+                sc.brushes = true;
                 break;
             }
         }
     }
-    hipStream_t st = c->lanes[0].stream;
-    if (scene_len) HIP_TRY(c, hipMemcpyAsync(c->scene.ptr, scene, scene_len, hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipMemsetAsync((char *)c->scene.ptr + scene_len, 0, 64, st));
-    c->n_ramps = 0;
+    if (scene_len) HIP_TRY(c, hipMemcpyAsync(sc.scene.ptr, scene, scene_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipMemsetAsync((char *)sc.scene.ptr + scene_len, 0, 64, st));
+    sc.n_ramps = 0;
     if (ramps && n_ramps) {
-        if ((r = ensure(c, c->ramps, (size_t)n_ramps * 512u * 4u))) return r;
-        HIP_TRY(c, hipMemcpyAsync(c->ramps.ptr, ramps, (size_t)n_ramps * 512u * 4u, hipMemcpyHostToDevice, st));
-        c->n_ramps = n_ramps;
+        if ((r = ensure(c, sc.ramps, (size_t)n_ramps * 512u * 4u))) return r;
+        HIP_TRY(c, hipMemcpyAsync(sc.ramps.ptr, ramps, (size_t)n_ramps * 512u * 4u, hipMemcpyHostToDevice, st));
+        sc.n_ramps = n_ramps;
     }
-    // the source buffers are caller-owned only for the duration of the call (recording.rs:124-129)
     HIP_TRY(c, hipStreamSynchronize(st));
-    c->scene_resident = true;
+    sc.resident = true;
     return VELLO_HIP_OK;
+}
+
+int vello_hip_upload_scene(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                           const uint32_t *ramps, uint32_t n_ramps) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r;
+    // frames still in flight read the old scene
+    if ((r = sync_all(c))) return r;
+    if ((r = load_slot(c, c->shared, c->lanes[0].stream, scene, scene_len, layout, ramps, n_ramps))) return r;
+    for (auto &l : c->lanes) {
+        l.use_own = false;
+        if ((r = alloc_lane_scene(c, l, c->shared))) return r;
+    }
+    return VELLO_HIP_OK;
+}
+
+// The pipelined form of vello_hip_render for animations: every frame brings its own scene.  The scene goes into
+// the private slot of the next lane of the rotation (only THAT lane's previous frame is waited for), the frame is
+// enqueued, and the call returns; other lanes keep rendering while the next scene crosses PCIe.
+int vello_hip_render_frame(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                           const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_device,
+                           size_t out_stride) {
+    if (!c || !params) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t li = c->next_lane % c->n_active;
+    Lane &l = c->lanes[li];
+    HIP_TRY(c, hipStreamSynchronize(l.stream));
+    int r = load_slot(c, l.own, l.stream, scene, scene_len, layout, ramps, n_ramps);
+    if (r) return r;
+    l.use_own = true;
+    if ((r = alloc_lane_scene(c, l, l.own))) return r;
+    c->next_lane = (li + 1u) % c->n_active;
+    c->last_lane = li;
+    Frame f;
+    if ((r = prepare_frame(c, l, params, out_device, out_stride, f, false))) return r;
+    return run_stage_range(c, l, f, 0, VELLO_HIP_STAGE_FINE);
 }
 
 int vello_hip_resize_image_atlas(vello_hip_ctx *c, uint32_t width, uint32_t height) {
@@ -632,7 +677,7 @@ int vello_hip_grow_pools(vello_hip_ctx *c, const vello_hip_bump *demand, vello_h
         }
     };
     want(d.lines, demand->lines);
-    want(d.bin_data, (uint64_t)demand->binning + c->layout.bin_data_start);
+    want(d.bin_data, (uint64_t)demand->binning + slot_of(c, c->lanes[c->last_lane]).layout.bin_data_start);
     want(d.tiles, demand->tile);
     want(d.seg_counts, demand->seg_counts);
     want(d.segments, demand->segments);

@@ -143,6 +143,23 @@ class Engine:
                 self.write_image(x, y, px)
         self.upload_scene(resolved.packed, resolved.layout, resolved.ramps)
 
+    def render_frame(self, packed, layout, width, height, base_color, aa, out=None, ramps=None):
+        """vello_hip_render_frame: upload this frame's scene into the next in-flight slot and enqueue the frame."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        lay = LayoutStruct(*layout)
+        p = self._params(width, height, base_color, aa)
+        ptr, stride = None, 0
+        if out is not None:
+            ptr, is_dev = _data_ptr(out)
+            assert is_dev, "render_frame writes to device memory"
+            stride = width * 4
+        rp, nr = None, 0
+        if ramps is not None and len(ramps):
+            ramps = np.ascontiguousarray(ramps, dtype=np.uint32)
+            rp, nr = ramps.ctypes.data, ramps.size // 512
+        self._check(self._lib.vello_hip_render_frame(self._h, packed.ctypes.data, packed.nbytes, ctypes.byref(lay), ctypes.byref(p),
+                                                     rp, nr, ptr, stride), "render_frame")
+
     def render_resident(self, width, height, base_color, aa, out=None):
         p = self._params(width, height, base_color, aa)
         ptr, stride = None, 0
