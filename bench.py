@@ -263,6 +263,7 @@ def main():
             "kernel": f"k_{dominant}",
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
+            "peak_measured": 6290.0,  # float4 copy on this part (MI355X_MICROARCH.md), for reference
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,

@@ -308,3 +308,30 @@ def test_render_frame_pipelines_scenes(built):
     for k in range(3):
         o.set_scene(scenes[k][0], scenes[k][1], 320, 320, BLACK, int(AaConfig.Msaa16))
         assert np.array_equal(o.render(), targets[k].cpu().numpy()), k
+
+
+def test_pure_c_client_of_the_abi(built, tmp_path):
+    # a C program (gcc, no Python / C++ in the process) drives include/vello_hip.h: one-shot render and the animation form
+    import struct
+    import subprocess
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(vello_amd.library_path())
+    exe = str(tmp_path / "render_blob")
+    subprocess.run(["gcc", "-O1", "-std=c11", "-o", exe, os.path.join(root, "tests", "c_abi", "render_blob.c"), "-L" + lib_dir,
+                    "-lvello_hip", "-Wl,-rpath," + lib_dir], check=True)
+    r = vello_amd.Resolver().resolve(workloads.brushes_scene())
+    w, h, aa = 256, 256, int(AaConfig.Msaa16)
+    blob = struct.pack("<10I", *r.layout) + struct.pack("<5I", w, h, WHITE, aa, r.ramps.size // 512) + struct.pack("<Q", r.packed.nbytes)
+    blob += r.packed.tobytes() + r.ramps.tobytes()
+    (tmp_path / "scene.bin").write_bytes(blob)
+    out_path = tmp_path / "out.rgba"
+    p = subprocess.run([exe, str(tmp_path / "scene.bin"), str(out_path)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    img = np.frombuffer(out_path.read_bytes(), dtype=np.uint8).reshape(h, w, 4)
+    o = Oracle()
+    o.set_scene(r.packed, r.layout, w, h, WHITE, aa)
+    o.set_ramps(r.ramps)            # no image atlas in the C client: image brushes sample transparent black on both sides
+    assert np.array_equal(img, o.render())
