@@ -51,7 +51,7 @@ def stage_bytes(layout, bump, n_tag_words, scene_len, width, height, ptcl_words)
     path_data = (layout.draw_tag_base - layout.path_data_base) * 4
     return {
         "pathtag_scan": 4 * Tw + 20 * Tw + 16 * P,
-        "flatten": 2 * (4 * Tw + 20 * Tw + path_data) + 24 * L + 24 * P,   # count + emit pass read the inputs twice
+        "flatten": (4 * Tw + 20 * Tw + path_data) + 24 * L + 24 * P,   # single pass: tags, monoids, path data read once
         "draw_scan": 4 * D + 24 * D + 16 * D + 4 * D,
         "clip": 8 * K + 24 * K + 16 * K + 16 * K,
         "binning": 16 * D + 24 * D + 16 * D + 4 * Bd,

@@ -690,7 +690,7 @@ __device__ CubicPoints read_path_segment(const uint32_t *pd, const PathTagData &
     return CubicPoints{p0, p1, p2, p3};
 }
 
-// One tag: flatten.wgsl:831-923 (body of main).  COUNT mode touches no memory but the scene.
+// One tag: flatten.wgsl:831-923 (body of main).
 // Returns the path index of the tag; the per-tag bbox is left in `em` (invalid = no lines) for the caller.
 template <bool EMIT>
 __device__ uint32_t flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
