@@ -49,7 +49,6 @@ struct FlattenShared {
     uint32_t base;
 };
 
-template <bool EMIT>
 struct Emitter {
     float bx0, by0, bx1, by1;
     LineSoup *lines;
@@ -343,8 +342,7 @@ enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 
 // re-derive the identical subdivision of the centre-line cubic; here one walk of the subdivision feeds both
 // offset curves (`two_sided`), which halves the Euler-spiral fitting work of the stroker.  Per side the
 // arithmetic is unchanged, only the order in which lines are appended differs (the soup is unordered).
-template <bool EMIT>
-__device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
+__device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
                               float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n) {
     vec2 p0, p1, p2, p3;
     float scale;
@@ -381,7 +379,7 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
         const bool straight = cubic_is_straight(p0, p1, p2, p3, scale, offset);
         if (straight) {
             uint32_t line_ix = em.alloc((uint32_t)n_sides);
-            if constexpr (EMIT) {
+            {
                 for (int side = 0; side < n_sides; side++) {
                     const float off = side ? -offset : offset;
                     vec2 l0 = off >= 0.0f ? t_start[side] : t_end[side];
@@ -453,7 +451,7 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
                 float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
                 uint32_t n_u = f2u(n);
                 uint32_t line_ix = em.alloc(n_u);
-                if constexpr (EMIT) {
+                {
                     vec2 lp = lp0[side];
                     for (uint32_t i = 0; i < n_u; i++) {
                         vec2 lp1;
@@ -494,8 +492,7 @@ __device__ void flatten_euler(Emitter<EMIT> &em, const CubicPoints &cubic, uint3
 }
 
 // flatten.wgsl:494-521
-template <bool EMIT>
-__device__ void flatten_arc(Emitter<EMIT> &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float angle,
+__device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float angle,
                             const Xform &transform) {
     vec2 p0 = xf_apply(transform, begin);
     vec2 r = begin - center;
@@ -505,7 +502,7 @@ __device__ void flatten_arc(Emitter<EMIT> &em, uint32_t path_ix, vec2 begin, vec
     float theta = maxf(MIN_THETA, 2.0f * acos_cr(1.0f - tol / radius));
     uint32_t n_lines = maxu(1u, f2u(ceilf(angle / theta)));
     uint32_t line_ix = em.alloc(n_lines);
-    if constexpr (EMIT) {
+    {
         float cs = cos_cr(theta);
         float sn = sin_cr(theta);
         for (uint32_t i = 0; i < n_lines - 1u; i++) {
@@ -520,11 +517,10 @@ __device__ void flatten_arc(Emitter<EMIT> &em, uint32_t path_ix, vec2 begin, vec
 }
 
 // flatten.wgsl:523-547
-template <bool EMIT>
-__device__ void draw_cap(Emitter<EMIT> &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
+__device__ void draw_cap(Emitter &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
                          vec2 offset_tangent, const Xform &transform) {
     if (cap_style == STYLE_FLAGS_CAP_ROUND) {
-        flatten_arc<EMIT>(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
+        flatten_arc(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
         return;
     }
     vec2 start = cap0, end = cap1;
@@ -559,8 +555,7 @@ __device__ float f16_to_f32(uint32_t bits) {
 }
 
 // flatten.wgsl:549-631
-template <bool EMIT>
-__device__ void draw_join(Emitter<EMIT> &em, uint32_t path_ix, uint32_t style_flags, vec2 p0, vec2 tan_prev, vec2 tan_next,
+__device__ void draw_join(Emitter &em, uint32_t path_ix, uint32_t style_flags, vec2 p0, vec2 tan_prev, vec2 tan_next,
                           vec2 n_prev, vec2 n_next, const Xform &transform) {
     vec2 front0 = p0 + n_prev;
     vec2 front1 = p0 + n_next;
@@ -598,7 +593,7 @@ __device__ void draw_join(Emitter<EMIT> &em, uint32_t path_ix, uint32_t style_fl
         vec2 arc0, arc1, other0, other1;
         if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
         else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
-        flatten_arc<EMIT>(em, path_ix, arc0, arc1, p0, fabsf(atan2_cr(cr, d)), transform);
+        flatten_arc(em, path_ix, arc0, arc1, p0, fabsf(atan2_cr(cr, d)), transform);
         uint32_t ix = em.alloc(1u);
         em.write_xf(ix, path_ix, other0, other1, transform);
     }
@@ -692,8 +687,7 @@ __device__ CubicPoints read_path_segment(const uint32_t *pd, const PathTagData &
 
 // One tag: flatten.wgsl:831-923 (body of main).
 // Returns the path index of the tag; the per-tag bbox is left in `em` (invalid = no lines) for the caller.
-template <bool EMIT>
-__device__ uint32_t flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+__device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                 PathBbox *path_bboxes, uint32_t ix) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
@@ -704,7 +698,7 @@ __device__ uint32_t flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint
     uint32_t style_ix = tag.monoid.style_ix;
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
-    if constexpr (EMIT) {
+    {
         if (is_path) {
             path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
             path_bboxes[path_ix].trans_ix = trans_ix;
@@ -725,7 +719,7 @@ __device__ uint32_t flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint
                 vec2 tangent = pts.p3 - pts.p0;
                 vec2 offset_tangent = normalize(tangent) * offset;
                 vec2 n = v2(-offset_tangent.y, offset_tangent.x);
-                draw_cap<EMIT>(em, path_ix, (style_flags & STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
+                draw_cap(em, path_ix, (style_flags & STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
                                -offset_tangent, transform);
             }
         } else {
@@ -750,17 +744,17 @@ __device__ uint32_t flatten_tag(Emitter<EMIT> &em, const Config &cfg, const uint
             vec2 tnn = normalize(tan_next) * offset;
             vec2 n_next = v2(-tnn.y, tnn.x);
 
-            flatten_euler<EMIT>(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev, true, pts.p0 - n_start,
+            flatten_euler(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev, true, pts.p0 - n_start,
                                 pts.p3 - n_prev);
             if (do_join) {
-                draw_join<EMIT>(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+                draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
             } else {
-                draw_cap<EMIT>(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
+                draw_cap(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
                                offset_tangent, transform);
             }
         }
     } else {
-        flatten_euler<EMIT>(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3, false, pts.p0, pts.p3);
+        flatten_euler(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3, false, pts.p0, pts.p3);
     }
     return path_ix;
 }
@@ -802,7 +796,7 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 // homogeneous (a wave mixing 8 cubics with 56 stroked lines runs the subdivision loop at 1/8 lane use).
 // Returns 0 = done, HEAVY_CURVE or HEAVY_STROKE.
 constexpr uint32_t HEAVY_CURVE = 1u, HEAVY_STROKE = 2u;
-__device__ __forceinline__ uint32_t flatten_tag_light(Emitter<true> &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+__device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                                   PathBbox *path_bboxes, uint32_t ix, uint32_t &path_ix_out) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
@@ -854,7 +848,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     Bump *bump = &control->bump;
 #pragma unroll 1
     for (uint32_t j = 0; j < FLATTEN_TAGS_PER_THREAD; j++) {
-        Emitter<true> em;
+        Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
         em.bump = bump;
@@ -914,7 +908,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     // no indirect dispatch in HIP: a fixed grid strides over the list
 #pragma unroll 1
     for (uint32_t base = blockIdx.x * 256u; base < n_heavy; base += gridDim.x * 256u) {
-        Emitter<true> em;
+        Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
         em.bump = bump;
@@ -924,7 +918,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         if (base + tid < n_heavy) {
             const uint32_t e = base + tid;
             const uint32_t tag_ix = e < n_curves ? heavy_list[e] : heavy_list[n_tags + (e - n_curves)];
-            key = flatten_tag<true>(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
+            key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
