@@ -207,3 +207,14 @@ def test_emu_render_frame_keeps_a_scene_per_lane(built):
         assert np.array_equal(eng.read_buffer("output", np.uint8, 128 * 128 * 4).reshape(128, 128, 4), o.render())
     finally:
         L._use_library(None)
+
+
+@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips"])
+def test_emu_reference_brush_and_layer_scenes(emu_engine, which):
+    # test_scenes.rs:978-1043, :1213-1304, :1398-1436: gradient extend modes, the 16 mix modes over gradients, blend
+    # stack spill, 600 clip layers
+    import vello_amd
+
+    scene, w, h = getattr(workloads, which + "_scene")()
+    r = vello_amd.Resolver().resolve(scene)
+    compare_frame(emu_engine, r.packed, r.layout, w, h, BLACK, AaConfig.Msaa8, "emu_" + which, resolved=r)

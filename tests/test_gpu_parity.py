@@ -335,3 +335,16 @@ def test_pure_c_client_of_the_abi(built, tmp_path):
     o.set_scene(r.packed, r.layout, w, h, WHITE, aa)
     o.set_ramps(r.ramps)            # no image atlas in the C client: image brushes sample transparent black on both sides
     assert np.array_equal(img, o.render())
+
+
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
+@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips"])
+def test_reference_brush_and_layer_scenes(gpu_engine, which, aa):
+    # test_scenes.rs:978-1043 (gradient kinds x extend modes), :1213-1239 + :1398-1436 (16 mix modes over gradients in
+    # nested layers), :1241-1276 (blend stack deeper than 4), :1278-1304 (600 clip layers)
+    import vello_amd
+
+    scene, w, h = getattr(workloads, which + "_scene")()
+    r = vello_amd.Resolver().resolve(scene)
+    compare_frame(gpu_engine, r.packed, r.layout, w, h, WHITE, aa, f"gpu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                  resolved=r)

@@ -146,3 +146,96 @@ def robust_paths_scene():
     s.fill(Fill.NonZero, Affine.translate(0.0, 100.0), yellow, None, p)
     s.fill(Fill.EvenOdd, Affine.translate(300.0, 100.0), lime, None, p)
     return s, 600, 160
+
+
+def gradient_extend_scene():
+    """test_scenes.rs:978-1043 without the labels: linear / two-point radial / sweep gradients under the three extend
+    modes.  1200 x 1200."""
+    from vello_amd import Extend, Gradient
+    s = Scene()
+    colors = [Color.from_rgb8(255, 0, 0), Color.from_rgb8(0, 255, 0), Color.from_rgb8(0, 0, 255)]
+    w = h = 300.0
+    for x, ext in enumerate([Extend.Pad, Extend.Repeat, Extend.Reflect]):
+        for y in range(3):
+            if y == 0:
+                g = Gradient.new_linear((w * 0.35, h * 0.5), (w * 0.65, h * 0.5))
+            elif y == 1:
+                radius = float(np.float32(w * 0.25))
+                g = Gradient.new_two_point_radial((w * 0.5, h * 0.5), radius * 0.25, (w * 0.5, h * 0.5), radius)
+            else:
+                g = Gradient.new_sweep((w * 0.5, h * 0.5), float(np.radians(np.float32(30.0))), float(np.radians(np.float32(150.0))))
+            g = g.with_stops(colors).with_extend(ext)
+            s.fill(Fill.NonZero, Affine.translate(x * 350.0 + 50.0, y * 350.0 + 100.0), g, None, Rect(0.0, 0.0, w, h))
+    return s, 1200, 1200
+
+
+def blend_grid_scene():
+    """test_scenes.rs:1213-1239 + render_blend_square (:1398-1436): the 16 mix modes, each over gradient backdrops with
+    gradient-filled squashed ellipses inside nested blend layers.  900 x 900."""
+    from vello_amd import Circle, Gradient, Mix, BlendMode, Compose
+    import math
+    modes = [Mix.Normal, Mix.Multiply, Mix.Darken, Mix.Screen, Mix.Lighten, Mix.Overlay, Mix.ColorDodge, Mix.ColorBurn,
+             Mix.HardLight, Mix.SoftLight, Mix.Difference, Mix.Exclusion, Mix.Hue, Mix.Saturation, Mix.Color, Mix.Luminosity]
+    black, white = Color.from_rgb8(0, 0, 0), Color.from_rgb8(255, 255, 255)
+    rect = Rect(0.0, 0.0, 200.0, 200.0)
+
+    def blend_square(mix):
+        f = Scene()
+        t = Affine.IDENTITY
+        f.fill(Fill.NonZero, t, Gradient.new_linear((0.0, 0.0), (200.0, 0.0)).with_stops([black, white]), None, rect)
+        for x, y, c in [(150., 0., (255, 240, 64)), (175., 100., (255, 96, 240)), (125., 200., (64, 192, 255))]:
+            col = Color.from_rgb8(*c)
+            f.fill(Fill.NonZero, t, Gradient.new_radial((x, y), 100.0).with_stops([col, col.with_alpha(0.0)]), None, rect)
+        f.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.SrcOver), 1.0, t, rect)
+        for i, c in enumerate([(255, 0, 0), (0, 255, 0), (0, 0, 255)]):
+            lin = Gradient.new_linear((0.0, 0.0), (0.0, 200.0)).with_stops([white, Color.from_rgb8(*c)])
+            f.push_layer(Fill.NonZero, BlendMode(mix, Compose.SrcOver), 1.0, t, rect)
+            a = (t * Affine.translate(100., 100.) * Affine.rotate(math.pi / 3.0 * (i * 2 + 1)) * Affine.scale_non_uniform(1.0, 0.357)
+                 * Affine.translate(-100., -100.))
+            f.fill(Fill.NonZero, a, lin, None, Circle((100., 100.), 90.))
+            f.pop_layer()
+        f.pop_layer()
+        return f
+
+    s = Scene()
+    for ix, mix in enumerate(modes):
+        s.append(blend_square(mix), Affine.translate((ix % 4) * 225., (ix // 4) * 225.))
+    return s, 900, 900
+
+
+def deep_blend_scene(complexity=7):
+    """test_scenes.rs:1241-1276: nested 0.9-alpha layers, deeper than the 4-entry register blend stack.  1000 x 1000."""
+    from vello_amd import Mix, BlendMode, Compose
+    s = Scene()
+    main_rect = Rect(10., 10., 910., 910.)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, main_rect)
+    options = [(800., (0, 255, 255)), (700., (255, 0, 0)), (600., (240, 248, 255)), (500., (255, 255, 0)), (400., (0, 128, 0)),
+               (300., (0, 0, 255)), (200., (255, 165, 0)), (100., (255, 255, 255))]
+    depth = 0
+    for width, color in options[:min(complexity, len(options) - 1)]:
+        s.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.SrcOver), 0.9, Affine.IDENTITY, Rect(10., 10., 10. + width, 10. + width))
+        s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(*color), None, main_rect)
+        depth += 1
+    for _ in range(depth):
+        s.pop_layer()
+    return s, 1000, 1000
+
+
+def many_clips_scene(seed=42):
+    """test_scenes.rs:1278-1304: 100 triangles, each under three randomly rotated triangular clip layers (600 clips).
+    The reference draws its angles from rand's StdRng; here a seeded PCG64 (different values, same structure)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tri = BezPath()
+    tri.move_to((-50.0, 0.0)); tri.line_to((25.0, -43.3)); tri.line_to((25.0, 43.3))
+    s = Scene()
+    for y in range(10):
+        for x in range(10):
+            tr = Affine.translate(100. * (x + 0.5), 100. * (y + 0.5))
+            for _ in range(3):
+                s.push_clip_layer(Fill.NonZero, tr * Affine.rotate(float(rng.uniform(0.0, np.pi))), tri)
+            rot = Affine.rotate(float(rng.uniform(0.0, np.pi)))
+            col = Color(float(rng.random()), float(rng.random()), float(rng.random()), 1.0)
+            s.fill(Fill.NonZero, tr * rot, col, None, tri)
+            for _ in range(3):
+                s.pop_layer()
+    return s, 1000, 1000
