@@ -209,7 +209,8 @@ def test_emu_render_frame_keeps_a_scene_per_lane(built):
         L._use_library(None)
 
 
-@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips"])
+@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips", "blurred_rounded_rect", "image_sampling",
+                                   "image_sampling_bicubic"])
 def test_emu_reference_brush_and_layer_scenes(emu_engine, which):
     # test_scenes.rs:978-1043, :1213-1304, :1398-1436: gradient extend modes, the 16 mix modes over gradients, blend
     # stack spill, 600 clip layers

@@ -338,10 +338,12 @@ def test_pure_c_client_of_the_abi(built, tmp_path):
 
 
 @pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
-@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips"])
+@pytest.mark.parametrize("which", ["gradient_extend", "blend_grid", "deep_blend", "many_clips", "blurred_rounded_rect", "image_sampling",
+                                   "image_sampling_bicubic"])
 def test_reference_brush_and_layer_scenes(gpu_engine, which, aa):
     # test_scenes.rs:978-1043 (gradient kinds x extend modes), :1213-1239 + :1398-1436 (16 mix modes over gradients in
-    # nested layers), :1241-1276 (blend stack deeper than 4), :1278-1304 (600 clip layers)
+    # nested layers), :1241-1276 (blend stack deeper than 4), :1278-1304 (600 clip layers), :1988-2031 (blurred rounded
+    # rects), :2053-2113 (image sampling: nearest / bilinear / bicubic under rotation, skew, non-uniform scale)
     import vello_amd
 
     scene, w, h = getattr(workloads, which + "_scene")()

@@ -37,6 +37,24 @@ class Affine:
         s, c = math.sin(th), math.cos(th)
         return Affine((c, s, -s, c, 0, 0))
 
+    @staticmethod
+    def skew(skew_x, skew_y):
+        """kurbo::Affine::skew: x' = x + skew_x * y, y' = skew_y * x + y."""
+        return Affine((1, skew_y, skew_x, 1, 0, 0))
+
+    # kurbo's then_* builders: the new map is applied AFTER self
+    def then_translate(self, x, y):
+        return Affine.translate(x, y) * self
+
+    def then_rotate(self, th):
+        return Affine.rotate(th) * self
+
+    def then_scale(self, s):
+        return Affine.scale(s) * self
+
+    def then_scale_non_uniform(self, sx, sy):
+        return Affine.scale_non_uniform(sx, sy) * self
+
     def __mul__(self, o):
         a, b = self.c, o.c
         return Affine((a[0] * b[0] + a[2] * b[1], a[1] * b[0] + a[3] * b[1], a[0] * b[2] + a[2] * b[3],

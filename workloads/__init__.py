@@ -11,4 +11,5 @@ from .scenes import (circle_scene, smoke_circle_scene, smoke_square_scene, paris
                      random_test_scene, clip_blend_scene, stroke_styles_scene, brushes_scene, heavy_strokes_scene)
 from .pico_svg import load_svg, tiger_scene
 from .ref_scenes import (tricky_strokes_scene, fill_types_scene, robust_paths_scene, gradient_extend_scene, blend_grid_scene,
-                         deep_blend_scene, many_clips_scene)
+                         deep_blend_scene, many_clips_scene, blurred_rounded_rect_scene, image_sampling_scene,
+                         image_sampling_bicubic_scene)

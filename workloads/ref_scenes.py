@@ -239,3 +239,67 @@ def many_clips_scene(seed=42):
             for _ in range(3):
                 s.pop_layer()
     return s, 1000, 1000
+
+
+def blurred_rounded_rect_scene(std_dev=50.0):
+    """test_scenes.rs:1988-2031 at time 0 (std_dev = 50): plain, skewed, circle-like and over-rounded blurred rects on
+    white.  (The emulated box shadow of :2033-2050 needs kurbo's reverse_subpaths and is left out.)  1200 x 1200."""
+    import math
+    s = Scene()
+    rect = (-150.0, -120.0, 150.0, 120.0)
+    blue, black = Color.from_rgb8(0, 0, 255), Color.from_rgb8(0, 0, 0)
+    s.draw_blurred_rounded_rect(Affine.translate(300.0, 300.0), rect, blue, 50.0, std_dev)
+    s.draw_blurred_rounded_rect(Affine.translate(900.0, 300.0) * Affine.skew(math.tan(math.radians(20.0)), 0.0), rect, black, 50.0, std_dev)
+    s.draw_blurred_rounded_rect(Affine.IDENTITY, (100.0, 800.0, 400.0, 1100.0), black, 150.0, std_dev)
+    s.draw_blurred_rounded_rect(Affine.IDENTITY, (600.0, 800.0, 900.0, 900.0), black, 150.0, std_dev)
+    return s, 1200, 1200
+
+
+def _rgba(*c):
+    return np.array(c, dtype=np.uint8)
+
+
+def image_sampling_scene():
+    """test_scenes.rs:141-161, :2053-2084: a 2x2 image magnified 200x under scale, 45-degree rotation, non-uniform scale
+    and skew (bilinear).  1100 x 1100 on white."""
+    import math
+    from vello_amd import ImageData
+    px = np.zeros((2, 2, 4), dtype=np.uint8)
+    px[0, 0], px[0, 1], px[1, 0], px[1, 1] = _rgba(255, 0, 0, 255), _rgba(0, 0, 255, 255), _rgba(0, 255, 255, 255), _rgba(255, 0, 255, 255)
+    image = ImageData(px)
+    s = Scene()
+    s.draw_image(image, Affine.scale(200.0).then_translate(100.0, 100.0))
+    s.draw_image(image, Affine.translate(-1.0, -1.0).then_rotate(math.pi / 4.0).then_translate(1.0, 1.0)
+                 .then_scale(200.0 * math.sqrt(0.5)).then_translate(100.0, 600.0))
+    s.draw_image(image, Affine.scale_non_uniform(100.0, 200.0).then_translate(600.0, 100.0))
+    s.draw_image(image, Affine.skew(0.1, 0.25).then_scale(200.0).then_translate(600.0, 600.0))
+    return s, 1100, 1100
+
+
+def image_sampling_bicubic_scene():
+    """test_scenes.rs:163-193, :2086-2113: a 16x16 checker with red/blue/lime features at Low / Medium / High quality
+    under a rotation and a skew.  1400 x 900 on white."""
+    import math
+    from vello_amd import ImageData, ImageBrush, ImageQuality
+    px = np.zeros((16, 16, 4), dtype=np.uint8)
+    for y in range(16):
+        for x in range(16):
+            c = (0, 0, 0) if ((x // 2) + (y // 2)) % 2 == 0 else (255, 255, 255)
+            if x == 8 or y == 8:
+                c = (255, 0, 0)
+            if x == y or x + y == 15:
+                c = (0, 0, 255)
+            if (x == 2 and y == 13) or (x == 13 and y == 2):
+                c = (0, 255, 0)
+            px[y, x] = _rgba(*c, 255)
+    image = ImageData(px)
+    brushes = [ImageBrush(image, quality=q) for q in (ImageQuality.Low, ImageQuality.Medium, ImageQuality.High)]
+    transforms = [
+        Affine.translate(-8.0, -8.0).then_rotate(math.pi / 5.0).then_scale_non_uniform(18.0, 14.0).then_translate(250.0, 270.0),
+        Affine.translate(250.0, 670.0) * Affine.scale_non_uniform(20.0, 10.0) * Affine.skew(0.35, -0.15) * Affine.translate(-8.0, -8.0),
+    ]
+    s = Scene()
+    for t in transforms:
+        for k, b in enumerate(brushes):
+            s.draw_image(b, t.then_translate(420.0 * k, 0.0))
+    return s, 1400, 900
