@@ -52,8 +52,18 @@ struct CmdFill {
     int32_t backdrop;
 };
 
+// Per-segment line setup of a batch (ms_setup), live only while ms_build_batch runs: shares its storage with the
+// staged Segment records of the one-fill-at-a-time paths (never both at once).
+struct SegSetupLds {
+    float a[64], b[64], xy0y[64], xy1y[64], mask_row[64];
+    int32_t x0i[64], y0i[64];
+    uint32_t flags[64];
+};
 struct FineShared {
-    Segment seg[64];
+    union {
+        Segment seg[64];
+        SegSetupLds su;
+    };
     uint32_t count[64];
     uint32_t winding_y[4];
     uint32_t winding_y_prefix[4];
@@ -140,15 +150,19 @@ struct FineBatch {
     uint32_t rule_backdrop[MS_BATCH_FILLS][2];
 };
 
-// One pixel crossing of segment `sg` (fine.wgsl:222-330): which pixel, the 8/16-bit sample mask from the LUT, and the
-// flags the accumulation needs.  Pure function of its arguments.
+// fine.wgsl:222-330 computes, for every pixel crossing, the line setup of its segment and then the crossing itself.
+// The setup (one IEEE division, the robustness fix-up, the LUT row) depends on the segment alone: ms_setup runs once
+// per segment lane, ms_item_su once per crossing.  Same operations on the same values, only hoisted.
+struct MsSetup {
+    float a, b, xy0y, xy1y, mask_row;
+    int32_t x0i, y0i;
+    uint32_t flags;
+};
+constexpr uint32_t SU_IS_DOWN = 1u, SU_POS_SLOPE = 2u, SU_DELTA0 = 4u, SU_BUMP0 = 8u, SU_END_OK = 16u;
+
 template <int AA>
-__device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, bool last_pixel, bool even_odd,
-                                            const uint32_t *__restrict__ mask_lut) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
-    constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+__device__ __forceinline__ MsSetup ms_setup(const Segment &sg, bool even_odd) {
+    constexpr uint32_t MASK_WIDTH = AA == 2 ? 64u : 32u, MASK_HEIGHT = AA == 2 ? 64u : 32u;
     // line setup, fine.wgsl:236-261
     const bool is_down = sg.p1y >= sg.p0y;
     const vec2 xy0 = is_down ? v2(sg.p0x, sg.p0y) : v2(sg.p1x, sg.p1y);
@@ -168,16 +182,40 @@ __device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, 
     const uint32_t cnt = count_x + span(xy0.y, xy1.y);
     const float robust_err = floorf(a * ((float)cnt - 1.0f) + b) - (float)count_x;
     if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
-    const int32_t x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+    const float half_height = (float)(MASK_HEIGHT / 2u);
+    MsSetup su;
+    su.a = a;
+    su.b = b;
+    su.xy0y = xy0.y;
+    su.xy1y = xy1.y;
+    su.mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
+    su.x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
+    su.y0i = f2i(y0i);
+    const bool is_delta0 = y0i == xy0.y;
+    const bool is_bump0 = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
+    su.flags = (is_down ? SU_IS_DOWN : 0u) | (is_positive_slope ? SU_POS_SLOPE : 0u) | (is_delta0 ? SU_DELTA0 : 0u) |
+               (is_bump0 ? SU_BUMP0 : 0u) | (xy1.x != 0.0f ? SU_END_OK : 0u);
+    return su;
+}
+
+// One pixel crossing: which pixel, the 8/16-bit sample mask from the LUT, and the flags the accumulation needs.
+template <int AA>
+__device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_ix, bool last_pixel, const uint32_t *__restrict__ mask_lut) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
+    constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const bool is_down = (su.flags & SU_IS_DOWN) != 0u, is_positive_slope = (su.flags & SU_POS_SLOPE) != 0u;
+    const float a = su.a, b = su.b;
     const float zf = a * (float)sub_ix + b;
     const float z = floorf(zf);
-    const int32_t x = x0i + f2i(x_sign * z);
-    const int32_t y = f2i(y0i) + (int32_t)sub_ix - f2i(z);
+    const int32_t x = su.x0i + f2i(is_positive_slope ? z : -z);  // x_sign * z
+    const int32_t y = su.y0i + (int32_t)sub_ix - f2i(z);
     bool is_delta, is_bump;
     const float zp = floorf(a * (float)(sub_ix - 1u) + b);
     if (sub_ix == 0u) {
-        is_delta = y0i == xy0.y;
-        is_bump = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
+        is_delta = (su.flags & SU_DELTA0) != 0u;
+        is_bump = (su.flags & SU_BUMP0) != 0u;
     } else {
         is_delta = z == zp;
         is_bump = is_positive_slope && !is_delta;
@@ -185,24 +223,28 @@ __device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, 
     const uint32_t pix_ix = (uint32_t)y * TILE_WIDTH + (uint32_t)x;
     const bool delta_ok = (uint32_t)x < TILE_WIDTH - 1u && (uint32_t)y < TILE_HEIGHT && is_delta;
     const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
-    const float half_height = (float)(MASK_HEIGHT / 2u);
-    const float mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
     const float mask_col = floorf((zf - z) * (float)MASK_WIDTH);
-    const uint32_t mask_ix = mask_block + f2u(mask_row + mask_col);
+    const uint32_t mask_ix = mask_block + f2u(su.mask_row + mask_col);
     uint32_t mask;
     if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
     else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
     if (sub_ix == 0u && !is_bump) {
-        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy0.y - (float)y)));
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy0y - (float)y)));
         mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
     }
-    if (last_pixel && xy1.x != 0.0f) {
-        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (xy1.y - (float)y)));
+    if (last_pixel && (su.flags & SU_END_OK) != 0u) {
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy1y - (float)y)));
         mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
     }
     // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
     return (pix_ix & 0xffu) | ((mask & FULL) << 8) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) |
            (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
+}
+
+template <int AA>
+__device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, bool last_pixel, bool even_odd,
+                                            const uint32_t *__restrict__ mask_lut) {
+    return ms_item_su<AA>(ms_setup<AA>(sg, even_odd), sub_ix, last_pixel, mask_lut);
 }
 
 // The counter updates of one crossing (fine.wgsl:262-270, :331-360).
@@ -475,9 +517,11 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     uint32_t count = 0u;
     if (lane < tot_segs) {
         Segment sg = segments[seg_data + (lane - seg_start)];
-        sh.seg[lane] = sg;
         bt.seg_slot[lane] = slot;
         count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
+        const MsSetup su = ms_setup<AA>(sg, (rule & 1u) != 0u);
+        sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.xy0y[lane] = su.xy0y; sh.su.xy1y[lane] = su.xy1y;
+        sh.su.mask_row[lane] = su.mask_row; sh.su.x0i[lane] = su.x0i; sh.su.y0i[lane] = su.y0i; sh.su.flags[lane] = su.flags;
     }
     uint32_t incl = wave_incl_scan_u32(count, (int)lane);
     sh.count[lane] = incl;
@@ -500,9 +544,10 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
         const bool last_pixel = i + 1u == sh.count[el_ix];
         const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-        Segment sg = sh.seg[el_ix];
-        const bool eo = (bt.rule_backdrop[bt.seg_slot[el_ix]][0] & 1u) != 0u;
-        bt.item[i] = ms_item<AA>(sg, sub_ix, last_pixel, eo, mask_lut);
+        MsSetup su;
+        su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
+        su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
+        bt.item[i] = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
     }
     wave_lds_sync();
     return n_fit;
