@@ -110,36 +110,22 @@ def main():
 
     from vello_amd.distributed import gather_frames
 
-    issued = [0]
-    gather_done = [None] * nif  # per ring slot: event after the collective that last read it
+    from vello_amd.distributed import FramePipeline
 
     def exchange(slot):
         gather_frames(ring[slot], rank, world, dst=0, out=gathered)
         ev = torch.cuda.Event()
         ev.record()
-        gather_done[slot] = ev
+        return ev
 
-    def step():
-        i = issued[0]
-        issued[0] = i + 1
-        slot = i % nif
-        if gather_done[slot] is not None:
-            gather_done[slot].synchronize()  # the collective of the frame that lived here has read it (nif steps ago)
-            gather_done[slot] = None
-        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[slot])
-        if distributed and i >= nif - 1:
-            # the oldest in-flight frame is complete before its collective goes on torch's stream
-            engine.sync_frame(nif - 1)
-            exchange((i - (nif - 1)) % nif)
-
-    def flush():
-        # gather the nif-1 frames still in flight (every rendered frame is exchanged exactly once)
-        if distributed:
-            i = issued[0]
-            for age in range(min(nif - 1, i) - 1, -1, -1):
-                engine.sync_frame(age)
-                exchange((i - 1 - age) % nif)
-        issued[0] = 0
+    pipe = FramePipeline(
+        nif,
+        render=lambda slot: engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[slot]),
+        wait_frame=engine.sync_frame,                      # the frame is complete before its collective goes on torch's stream
+        exchange=exchange if distributed else None,
+        wait_exchange=lambda ev: ev.synchronize(),         # a slot is re-rendered only after its collective has read it
+    )
+    step, flush = pipe.step, pipe.flush
 
     # warmup, with every stage under HIP events to find the dominant kernel
     engine.set_profiling(vello_amd.renderer.STAGES)

@@ -75,3 +75,48 @@ def test_two_rank_scene_sharding_and_gather(built, tmp_path):
         packed, layout = workloads.paris_like_scene(SEED0 + i, n_paths=120, size=float(SIZE)).resolve()
         o.set_scene(packed, layout, SIZE, SIZE, 0xFFFFFFFF, 2)
         assert np.array_equal(frames[f"f{i}"], o.render()), f"scene {i} gathered at rank 0 differs from the oracle"
+
+
+def test_frame_pipeline_exchanges_every_frame_once_in_order():
+    # bench.py --gpus N keeps n frames in flight and gathers the oldest one while the younger ones render; the
+    # bookkeeping is checked here with recording fakes (no GPU): order, wait ages, slot reuse only after the exchange
+    from vello_amd.distributed import FramePipeline
+
+    for n in (1, 2, 3, 6):
+        for k in (1, 2, 5, 6, 7, 20):
+            log, rendered, exchanged, handles = [], [], [], {}
+            frame_of_slot = {}
+
+            def render(slot):
+                assert handles.get(slot) is None, "slot re-rendered before its exchange was waited for"
+                frame_of_slot[slot] = len(rendered)
+                rendered.append(slot)
+                log.append(("render", slot))
+
+            def wait_frame(age):
+                assert 0 <= age < n and age < len(rendered)
+                log.append(("wait", len(rendered) - 1 - age))
+
+            def exchange(slot):
+                f = frame_of_slot[slot]
+                assert ("wait", f) in log, "exchange before the frame was waited for"
+                exchanged.append(f)
+                handles[slot] = f
+                return slot
+
+            def wait_exchange(slot):
+                handles[slot] = None
+
+            p = FramePipeline(n, render, wait_frame, exchange, wait_exchange)
+            for _ in range(k):
+                p.step()
+            p.flush()
+            assert exchanged == list(range(k)), (n, k, exchanged)
+            assert p.issued == 0
+    # single-GPU form: no exchange, nothing but renders into rotating slots
+    calls = []
+    p = FramePipeline(3, calls.append, lambda age: calls.append(("wait", age)))
+    for _ in range(7):
+        p.step()
+    p.flush()
+    assert calls == [0, 1, 2, 0, 1, 2, 0]

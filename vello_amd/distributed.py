@@ -27,3 +27,48 @@ def gather_frames(frame, rank, world, dst=0, out=None):
         return out
     dist.gather(frame, None, dst=dst)
     return None
+
+
+class FramePipeline:
+    """Bookkeeping of a ring of `n_in_flight` frames: render frame i into slot i % n, and once a frame is the oldest one in
+    flight wait for it alone and hand it to `exchange` (the gather), so that the collective of frame i - (n - 1) overlaps
+    the rendering of the n - 1 younger frames.  The callables keep it testable without a GPU:
+
+      render(slot)            enqueue one frame into ring slot `slot`
+      wait_frame(age)         block until the frame enqueued `age` render() calls ago is complete (0 = newest)
+      exchange(slot)          the one exchange step of the path for the finished frame in `slot`; may return a handle
+      wait_exchange(handle)   block until that exchange has finished reading the slot (called before the slot is reused)
+    """
+
+    def __init__(self, n_in_flight, render, wait_frame, exchange=None, wait_exchange=None):
+        self.n = max(1, int(n_in_flight))
+        self.render, self.wait_frame = render, wait_frame
+        self.exchange, self.wait_exchange = exchange, wait_exchange
+        self.issued = 0
+        self.pending = [None] * self.n
+
+    def _exchange(self, slot):
+        if self.exchange is not None:
+            self.pending[slot] = self.exchange(slot)
+
+    def step(self):
+        i = self.issued
+        self.issued = i + 1
+        slot = i % self.n
+        if self.pending[slot] is not None:
+            if self.wait_exchange is not None:
+                self.wait_exchange(self.pending[slot])
+            self.pending[slot] = None
+        self.render(slot)
+        if self.exchange is not None and i >= self.n - 1:
+            self.wait_frame(self.n - 1)
+            self._exchange((i - (self.n - 1)) % self.n)
+
+    def flush(self):
+        """Exchanges the frames still in flight (every rendered frame is exchanged exactly once) and restarts the count."""
+        if self.exchange is not None:
+            i = self.issued
+            for age in range(min(self.n - 1, i) - 1, -1, -1):
+                self.wait_frame(age)
+                self._exchange((i - 1 - age) % self.n)
+        self.issued = 0
