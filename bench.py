@@ -287,10 +287,20 @@ def main():
             ref = o.render()
         cpu_s = (time.perf_counter() - t0) / n_cpu
         same = bool(np.array_equal(ref, frame.cpu().numpy()))
+        # the same oracle with its tile-parallel fine stage on up to 64 threads (the other stages stay serial)
+        n_thr = max(1, min(os.cpu_count() or 1, 64))
+        o.set_threads(n_thr)
+        o.render()
+        t0 = time.perf_counter()
+        for _ in range(n_cpu):
+            o.render()
+        cpu_mt_s = (time.perf_counter() - t0) / n_cpu
         result["cpu_baseline"] = {
             "value": round(1.0 / cpu_s, 4),
             "unit": "frames/s",
             "cores": 1,
+            "value_fine_threaded": round(1.0 / cpu_mt_s, 4),
+            "cores_fine_threaded": n_thr,
             "kind": "port",
             "sample": f"{n_cpu} full frames of the same scene (C restatement of vello_shaders/src/cpu + fine.wgsl, "
                       f"single thread, {os.cpu_count()} host cores present); output identical to GPU frame: {same}",
