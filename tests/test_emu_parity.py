@@ -219,3 +219,26 @@ def test_emu_reference_brush_and_layer_scenes(emu_engine, which):
     scene, w, h = getattr(workloads, which + "_scene")()
     r = vello_amd.Resolver().resolve(scene)
     compare_frame(emu_engine, r.packed, r.layout, w, h, BLACK, AaConfig.Msaa8, "emu_" + which, resolved=r)
+
+
+def test_emu_auto_grow_covers_large_targets(built):
+    # the PTCL pool holds a fixed 64 words per tile: a target with more tiles than the pool was sized for is an
+    # E_INVALID configuration error, unless robust mode may grow the pool
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        eng = vello_amd.Engine(capacities={"ptcl": 64 * 16 + 512})          # enough for 16 tiles only
+        packed, layout = workloads.stroke_styles_scene().resolve()
+        with pytest.raises(vello_amd.VelloHipError):
+            eng.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)       # 256 tiles
+        eng.set_auto_grow(True)
+        img, bump = eng.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)
+        assert bump["failed"] == 0 and eng.capacities()["ptcl"] >= 64 * 256
+        o = Oracle()
+        o.set_scene(packed, layout, 256, 256, WHITE, int(AaConfig.Msaa8))
+        assert np.array_equal(img, o.render())
+    finally:
+        L._use_library(None)

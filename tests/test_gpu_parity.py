@@ -350,3 +350,25 @@ def test_reference_brush_and_layer_scenes(gpu_engine, which, aa):
     r = vello_amd.Resolver().resolve(scene)
     compare_frame(gpu_engine, r.packed, r.layout, w, h, WHITE, aa, f"gpu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
                   resolved=r)
+
+
+def test_large_target_with_auto_grow(built):
+    # 6000 x 6000 = 140 625 tiles x 64 PTCL words: past the fixed 2^23-word pool; robust mode sizes the pool for the target
+    import vello_amd
+    from vello_amd import Affine, Scene
+    from oracle.oracle import Oracle
+
+    base = workloads.random_test_scene(21, n_paths=400, size=512.0, strokes=True, clips=False)
+    s = Scene()
+    s.append(base, Affine.scale(6000.0 / 512.0))
+    packed, layout = s.resolve()
+    eng = vello_amd.Engine()
+    with pytest.raises(vello_amd.VelloHipError):
+        eng.render(packed, layout, 6000, 6000, BLACK, AaConfig.Msaa8)
+    eng.set_auto_grow(True)
+    img, bump = eng.render(packed, layout, 6000, 6000, BLACK, AaConfig.Msaa8)
+    assert bump["failed"] == 0 and eng.capacities()["ptcl"] > (1 << 23)
+    o = Oracle(capacity_scale=4)
+    o.set_threads(32)
+    o.set_scene(packed, layout, 6000, 6000, BLACK, int(AaConfig.Msaa8))
+    assert np.array_equal(img, o.render())

@@ -205,7 +205,26 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
         c->last_error = "no scene uploaded";
         return VELLO_HIP_E_INVALID;
     }
-    int r = configure(c, sc, p, f.cfg);
+    int r;
+    if (c->auto_grow && p && p->width && p->height) {
+        // robust mode: a target with more tiles than the PTCL pool's fixed 64 words per tile (config.rs:408 sizes it for
+        // ~1 Mpx) grows the pool instead of failing; the info words of the scene likewise must fit bin_data
+        uint64_t tiles_xy = (uint64_t)(align_up(p->width, TILE_WIDTH) / TILE_WIDTH) * (align_up(p->height, TILE_HEIGHT) / TILE_HEIGHT);
+        uint64_t need_ptcl = tiles_xy * PTCL_INITIAL_ALLOC + 64u * PTCL_INCREMENT;
+        uint64_t need_bin = (uint64_t)sc.layout.bin_data_start + (1u << 16);
+        if (need_ptcl > c->caps.ptcl || need_bin > c->caps.bin_data) {
+            if (need_ptcl > 0xffff0000ull || need_bin > 0xffff0000ull) {
+                c->last_error = "target / scene too large for 32-bit pool offsets";
+                return VELLO_HIP_E_INVALID;
+            }
+            if ((r = sync_all(c))) return r;
+            if (need_ptcl > c->caps.ptcl) c->caps.ptcl = (uint32_t)(need_ptcl + need_ptcl / 4u);
+            if (need_bin > c->caps.bin_data) c->caps.bin_data = (uint32_t)(need_bin + need_bin / 4u);
+            for (auto &ln : c->lanes)
+                if ((r = alloc_lane_pools(c, ln))) return r;
+        }
+    }
+    r = configure(c, sc, p, f.cfg);
     if (r) return r;
     c->cfg = f.cfg;
     c->have_cfg = true;
