@@ -170,7 +170,9 @@ int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t w
  * buffer sets; the caller then renders the frame again.  A stage that overflows stops the later stages
  * (shared/bump.wgsl:5-9), so one frame may need several rounds.  Returns VELLO_HIP_E_INVALID when nothing had to
  * grow.  With vello_hip_set_auto_grow(ctx, 1) the blocking vello_hip_render does these rounds itself and only
- * reports VELLO_HIP_E_CAPACITY if the demand cannot be met. */
+ * reports VELLO_HIP_E_CAPACITY if the demand cannot be met; every entry point that renders then also sizes the PTCL
+ * pool for the target (64 words per tile are fixed, config.rs:408 allows ~2 Mpx of tiles) instead of failing with
+ * VELLO_HIP_E_INVALID. */
 int vello_hip_get_capacities(vello_hip_ctx *ctx, vello_hip_capacities *out);
 int vello_hip_grow_pools(vello_hip_ctx *ctx, const vello_hip_bump *demand, vello_hip_capacities *new_caps /* nullable */);
 int vello_hip_set_auto_grow(vello_hip_ctx *ctx, int enabled);
