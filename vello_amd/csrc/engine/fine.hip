@@ -138,7 +138,7 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
 // ms_resolve -- and up to MS_BATCH_FILLS consecutive fills of the command list are batched: one segment load,
 // one count/scan, one dense item pass writing records to LDS; each FILL command then only replays its records
 // (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
-constexpr uint32_t MS_BATCH_FILLS = 8u;     // fills per batch (their segments must fit one 64-lane load)
+constexpr uint32_t MS_BATCH_FILLS = 12u;    // fills per batch (their segments must fit one 64-lane load)
 constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
 constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
 
