@@ -95,6 +95,21 @@ __device__ __forceinline__ float cos_cr(float x) {
     }
     return (float)cos(d);
 }
+// sin and cos of the same angle from ONE fp64 range reduction (ocml's sincos evaluates the same two polynomials
+// as its sin and cos, so each result equals sin_cr / cos_cr bit for bit; checked by the GPU parity tests)
+__device__ __forceinline__ void sincos_cr(float x, float &s, float &c) {
+    double d = (double)x;
+    if (fabsf(x) <= 0.015625f) {
+        double d2 = d * d;
+        s = (float)(d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0))))));
+        c = (float)(1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0)))));
+        return;
+    }
+    double sd, cd;
+    sincos(d, &sd, &cd);
+    s = (float)sd;
+    c = (float)cd;
+}
 __device__ __forceinline__ float atan2_cr(float y, float x) {
     if (x > 0.0f && fabsf(y) <= 0.015625f * x) {
         double r = (double)y / (double)x;

@@ -154,14 +154,13 @@ __device__ CubicParams cubic_from_points_derivs(vec2 p0, vec2 p1, vec2 q0, vec2 
     vec2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
     float th1 = atan2_cr(h1.y, h1.x);
     float d1 = length(h1) * scale;
-    float cth0 = cos_cr(th0);
-    float cth1 = cos_cr(th1);
+    float cth0, cth1, s0, s1;
+    sincos_cr(th0, s0, cth0);
+    sincos_cr(th1, s1, cth1);
     float err = 2.0f;
     if (cth0 * cth1 >= 0.0f) {
         float e0 = (2.0f / 3.0f) / maxf(1.0f + cth0, 1e-9f);
         float e1 = (2.0f / 3.0f) / maxf(1.0f + cth1, 1e-9f);
-        float s0 = sin_cr(th0);
-        float s1 = sin_cr(th1);
         float s01 = cth0 * s1 + cth1 * s0;
         float amin = 0.15f * (2.0f * e0 * s0 + 2.0f * e1 * s1 - e0 * e1 * s01);
         float a = 0.15f * (2.0f * d0 * s0 + 2.0f * d1 * s1 - d0 * d1 * s01);
@@ -503,8 +502,8 @@ __device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end,
     uint32_t n_lines = maxu(1u, f2u(ceilf(angle / theta)));
     uint32_t line_ix = em.alloc(n_lines);
     {
-        float cs = cos_cr(theta);
-        float sn = sin_cr(theta);
+        float cs, sn;
+        sincos_cr(theta, sn, cs);
         for (uint32_t i = 0; i < n_lines - 1u; i++) {
             r = v2(cs * r.x + sn * r.y, -sn * r.x + cs * r.y);
             vec2 p1 = xf_apply(transform, center + r);
