@@ -167,7 +167,7 @@ def test_emu_flatten_staging_overflow(emu_engine):
     assert bump["lines"] > 3072
 
 
-@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths"])
+@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths", "funky_paths"])
 def test_emu_reference_test_scenes(emu_engine, which):
     # scenes of the reference's own catalogue (examples/scenes/src/test_scenes.rs:513-770, :1610-1691)
     scene, w, h = getattr(workloads, which + "_scene")()

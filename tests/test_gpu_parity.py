@@ -259,10 +259,11 @@ def test_flatten_staging_overflow(gpu_engine):
 
 
 @pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
-@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths"])
+@pytest.mark.parametrize("which", ["tricky_strokes", "fill_types", "robust_paths", "funky_paths", "cardioid", "many_draw_objects"])
 def test_reference_test_scenes(gpu_engine, which, aa):
     # examples/scenes/src/test_scenes.rs: cusps / 180-degree turns / degenerate cubics under the stroker (:513-697),
-    # self-intersections under both fill rules (:699-770), edges exactly on tile boundaries (:1610-1691)
+    # self-intersections under both fill rules (:699-770), edges exactly on tile boundaries (:1610-1691), path-encoder
+    # edge cases (:293-333), 600 long chords in one stroked path (:1306-1331), 90 000 draw objects (:1928-1948)
     scene, w, h = getattr(workloads, which + "_scene")()
     packed, layout = scene.resolve()
     compare_frame(gpu_engine, packed, layout, w, h, BLACK, aa, f"gpu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)

@@ -303,3 +303,51 @@ def image_sampling_bicubic_scene():
         for k, b in enumerate(brushes):
             s.draw_image(b, t.then_translate(420.0 * k, 0.0))
     return s, 1400, 900
+
+
+def funky_paths_scene():
+    """test_scenes.rs:293-333: path-encoder edge cases -- segments after a ClosePath without a MoveTo, a path of
+    MoveTos only, an empty path -- filled and stroked.  600 x 600."""
+    def missing_movetos():
+        p = BezPath()
+        p.move_to((0., 0.)); p.line_to((100., 100.)); p.line_to((100., 200.)); p.close_path()
+        p.line_to((0., 400.)); p.line_to((100., 400.))
+        return p
+    only_movetos = BezPath()
+    only_movetos.move_to((0., 0.)); only_movetos.move_to((100., 100.))
+    s = Scene()
+    blue, aqua = Color.from_rgb8(0, 0, 255), Color.from_rgb8(0, 255, 255)
+    s.fill(Fill.NonZero, Affine.translate(100., 100.), blue, None, missing_movetos())
+    s.fill(Fill.NonZero, Affine.IDENTITY, blue, None, BezPath())
+    s.fill(Fill.NonZero, Affine.IDENTITY, blue, None, only_movetos)
+    s.stroke(Stroke(8.0), Affine.translate(100., 100.), aqua, None, missing_movetos())
+    return s, 600, 600
+
+
+def cardioid_scene():
+    """test_scenes.rs:1306-1331: 600 chords of a circle (a cardioid envelope) as ONE stroked path of 600 two-point
+    subpaths: long lines across hundreds of tiles.  2048 x 1536."""
+    import math
+    n = 601
+    dth = math.pi * 2.0 / n
+    cx, cy, r = 1024.0, 768.0, 750.0
+    p = BezPath()
+    for i in range(1, n):
+        a0, a1 = i * dth, ((i * 2) % n) * dth
+        p.move_to((cx + math.cos(a0) * r, cy + math.sin(a0) * r))
+        p.line_to((cx + math.cos(a1) * r, cy + math.sin(a1) * r))
+    s = Scene()
+    s.stroke(Stroke(2.0), Affine.IDENTITY, Color.from_rgb8(0, 0, 255), None, p)
+    return s, 2048, 1536
+
+
+def many_draw_objects_scene(n_wide=300, n_high=300):
+    """test_scenes.rs:1928-1948: 90 000 little circles (360 000 cubics), one draw object each.  2000 x 1500."""
+    from vello_amd import Circle
+    s = Scene()
+    yellow = Color.from_rgb8(255, 255, 0)
+    for j in range(n_high):
+        y = (j + 0.5) * (1500.0 / n_high)
+        for i in range(n_wide):
+            s.fill(Fill.NonZero, Affine.IDENTITY, yellow, None, Circle(((i + 0.5) * (2000.0 / n_wide), y), 3.0))
+    return s, 2000, 1500
