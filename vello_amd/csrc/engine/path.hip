@@ -161,42 +161,59 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
             uint32_t max_count = count;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) max_count = maxu(max_count, __shfl_xor(max_count, d));
-            for (uint32_t s = 0; s < max_count; s++) {
-                const bool act = s < count;
-                uint32_t key = 0xffffffffu;
-                uint32_t i = w.imin + s;
-                if (act) {
-                    float zf = w.a * (float)i + w.b;
-                    float z = floorf(zf);
-                    int32_t y = f2i(w.y0 + (float)i - z);
-                    int32_t x = f2i(w.x0 + w.x_sign * z);
-                    int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
-                    bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
-                    if (top_edge && x + 1 < w.bbox2) {
-                        int32_t x_bump = maxi(x + 1, w.bbox0);
-                        atomicAdd(&tile[base + x_bump].backdrop, delta);
+            // Four crossing steps per round: their four returning atomics are in flight together, the records are
+            // written once all have answered (one atomic round trip per step made long lines -- tiger, mmark --
+            // pay ~1.5 us per crossed tile).
+            for (uint32_t s0 = 0; s0 < max_count; s0 += 4u) {
+                bool k_act[4];
+                uint32_t k_i[4], k_r[4];
+                int k_head[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) {
+                    const uint32_t s = s0 + k;
+                    const bool act = s < count;
+                    uint32_t key = 0xffffffffu;
+                    uint32_t i = w.imin + s;
+                    if (act) {
+                        float zf = w.a * (float)i + w.b;
+                        float z = floorf(zf);
+                        int32_t y = f2i(w.y0 + (float)i - z);
+                        int32_t x = f2i(w.x0 + w.x_sign * z);
+                        int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
+                        bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
+                        if (top_edge && x + 1 < w.bbox2) {
+                            int32_t x_bump = maxi(x + 1, w.bbox0);
+                            atomicAdd(&tile[base + x_bump].backdrop, delta);
+                        }
+                        key = (uint32_t)(base + x);
+                        last_z = z;
                     }
-                    key = (uint32_t)(base + x);
-                    last_z = z;
+                    uint32_t prev_key = __shfl_up(key, 1);
+                    bool head = !act || lane == 0 || prev_key != key;
+                    unsigned long long heads = __ballot(head);
+                    unsigned long long le = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
+                    int head_lane = 63 - __clzll((long long)le);
+                    unsigned long long gt = lane == 63 ? 0ull : (heads & (~0ull << (lane + 1)));  // heads after me
+                    int run_end = gt ? (__ffsll((long long)gt) - 1) : 64;
+                    uint32_t r = 0u;
+                    if (act && head) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
+                    k_act[k] = act;
+                    k_i[k] = i;
+                    k_r[k] = r;
+                    k_head[k] = head_lane;
                 }
-                uint32_t prev_key = __shfl_up(key, 1);
-                bool head = !act || lane == 0 || prev_key != key;
-                unsigned long long heads = __ballot(head);
-                unsigned long long le = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
-                int head_lane = 63 - __clzll((long long)le);
-                unsigned long long gt = lane == 63 ? 0ull : (heads & (~0ull << (lane + 1)));  // heads after me
-                int run_end = gt ? (__ffsll((long long)gt) - 1) : 64;
-                uint32_t r = 0u;
-                if (act && head) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
-                uint32_t base_slot = __shfl(r, head_lane);
-                if (act) {
-                    uint32_t seg_within_slice = base_slot + (uint32_t)(lane - head_lane);
-                    uint32_t seg_ix = seg_base + s;
-                    if (seg_ix < cfg.seg_counts_size) {
-                        SegmentCount sc;
-                        sc.line_ix = line_ix;
-                        sc.counts = (seg_within_slice << 16) | i;
-                        seg_counts[seg_ix] = sc;
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; k++) {
+                    uint32_t base_slot = __shfl(k_r[k], k_head[k]);
+                    if (k_act[k]) {
+                        uint32_t seg_within_slice = base_slot + (uint32_t)(lane - k_head[k]);
+                        uint32_t seg_ix = seg_base + s0 + k;
+                        if (seg_ix < cfg.seg_counts_size) {
+                            SegmentCount sc;
+                            sc.line_ix = line_ix;
+                            sc.counts = (seg_within_slice << 16) | k_i[k];
+                            seg_counts[seg_ix] = sc;
+                        }
                     }
                 }
             }
@@ -229,7 +246,8 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
     uint32_t incl = block256_incl_scan_u32(row_count, sh_scan, &total_rows);
     sh_row_count[tid] = incl;
     __syncthreads();
-    for (uint32_t row = tid; row < total_rows; row += 256u) {
+    // gridDim.y workgroups share the rows of one group of 256 paths (a scene of a few hundred big paths is ONE group)
+    for (uint32_t row = blockIdx.y * 256u + tid; row < total_rows; row += gridDim.y * 256u) {
         uint32_t el_ix = 0u;
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++) {
@@ -240,11 +258,20 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
         if (width > 0u) {
             uint32_t seq_ix = row - (el_ix > 0u ? sh_row_count[el_ix - 1u] : 0u);
             uint32_t tile_ix = sh_offset[el_ix] + seq_ix * width;
-            int32_t sum = tiles[tile_ix].backdrop;
-            for (uint32_t x = 1u; x < width; x++) {
-                tile_ix += 1u;
-                sum += tiles[tile_ix].backdrop;
-                tiles[tile_ix].backdrop = sum;
+            // Eight tiles per step: the loads of a step are independent (the reference's load -> add -> store chain
+            // costs one memory latency per tile: 66 us for the tiger's 64-tile-wide paths on a single workgroup).
+            int32_t sum = 0;
+            for (uint32_t x0 = 0u; x0 < width; x0 += 8u) {
+                int32_t v[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) v[k] = x0 + k < width ? tiles[tile_ix + x0 + k].backdrop : 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    if (x0 + k < width) {
+                        sum += v[k];
+                        if (x0 + k > 0u) tiles[tile_ix + x0 + k].backdrop = sum;
+                    }
+                }
             }
         }
     }
@@ -385,7 +412,7 @@ void launch_path_count(const Frame &f, hipStream_t s) {
 void launch_backdrop(const Frame &f, hipStream_t s) {
     uint32_t n_wg = (f.cfg.layout.n_paths + 255u) / 256u;
     if (n_wg == 0) return;
-    hipLaunchKernelGGL(k_backdrop, dim3(n_wg), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
+    hipLaunchKernelGGL(k_backdrop, dim3(n_wg, 4), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
 }
 
 void launch_path_tiling(const Frame &f, hipStream_t s) {
