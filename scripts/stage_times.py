@@ -1,9 +1,12 @@
 """Per-stage GPU time (HIP events, one frame at a time) on tiger / circle / mmark / paris.
-   python scripts/stage_times.py"""
+   python scripts/stage_times.py [B]      (B: use ab_tmp/libvello_hip_B.so instead of the in-tree build, see ab_bench.py)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import vello_amd, workloads
+if len(sys.argv) > 1 and sys.argv[1] != "A":
+    import vello_amd._lib as L
+    L._use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab_tmp", f"libvello_hip_{sys.argv[1]}.so"))
 from vello_amd import AaConfig
 def run(name, packed, layout, w, h, aa):
     eng = vello_amd.Engine(); eng.upload_scene(packed, layout)

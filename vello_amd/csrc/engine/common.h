@@ -5,13 +5,14 @@
 //  * compiled with -ffp-contract=off -fno-fast-math: the tile/pixel DDA in path_count, path_tiling
 //    and fine recomputes floor(a*i+b) three times and must agree bit for bit;
 //  * fma only where flatten.wgsl:668-672 spells fma();
-//  * f32 transcendentals = fp64 ocml value rounded once to f32 (MI355X runs fp64 at half the fp32
-//    vector rate), which equals the correctly rounded result up to ~2^-29 per call and is what the
-//    CPU oracle computes with libm;
+//  * f32 transcendentals = an fp64 evaluation (ocml, or fp64_math.h for sin / cos) rounded once to f32,
+//    which equals the correctly rounded result up to ~2^-28 per call and is what the CPU oracle computes
+//    with libm;
 //  * WGSL u32(f32)/i32(f32) are saturating, round() is ties-to-even.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fp64_math.h"
 
 namespace vk {
 
@@ -75,41 +76,36 @@ constexpr float ONE_MINUS_ULP = 0.99999994f;
 constexpr float ROBUST_EPSILON = 2e-7f;
 
 // ---------------- scalar helpers ----------------
-// Small-argument fast paths: for |x| <= 2^-6 the truncated Taylor series evaluated in fp64 is accurate to
-// < 2^-57 relative, i.e. it rounds to the same f32 as the full ocml routine (both are "the exact value
-// rounded once" up to ~2^-29 per call) at a tenth of the instructions.  Nearly-straight path segments, the
-// overwhelming majority of tags in map-like scenes, only ever take these paths.
-__device__ __forceinline__ float sin_cr(float x) {
-    double d = (double)x;
-    if (fabsf(x) <= 0.015625f) {
-        double d2 = d * d;
-        return (float)(d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0))))));
-    }
-    return (float)sin(d);
-}
-__device__ __forceinline__ float cos_cr(float x) {
-    double d = (double)x;
-    if (fabsf(x) <= 0.015625f) {
-        double d2 = d * d;
-        return (float)(1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0)))));
-    }
-    return (float)cos(d);
-}
-// sin and cos of the same angle from ONE fp64 range reduction (ocml's sincos evaluates the same two polynomials
-// as its sin and cos, so each result equals sin_cr / cos_cr bit for bit; checked by the GPU parity tests)
-__device__ __forceinline__ void sincos_cr(float x, float &s, float &c) {
-    double d = (double)x;
-    if (fabsf(x) <= 0.015625f) {
-        double d2 = d * d;
-        s = (float)(d * (1.0 + d2 * (-1.0 / 6.0 + d2 * (1.0 / 120.0 + d2 * (-1.0 / 5040.0 + d2 * (1.0 / 362880.0))))));
-        c = (float)(1.0 + d2 * (-0.5 + d2 * (1.0 / 24.0 + d2 * (-1.0 / 720.0 + d2 * (1.0 / 40320.0)))));
-        return;
-    }
+// sin / cos: fp64_math.h (one branch-free path for every argument the flattener produces; ocml beyond it).
+static __device__ __attribute__((noinline)) void sincos_large(float x, float &s, float &c) {  // cold: one copy of ocml's Payne-Hanek path
     double sd, cd;
-    sincos(d, &sd, &cd);
+    sincos((double)x, &sd, &cd);
     s = (float)sd;
     c = (float)cd;
 }
+__device__ __forceinline__ void sincos_cr(float x, float &s, float &c) {
+    if (fabsf(x) <= (float)f64::SINCOS_MAX_ARG) {
+        double sd, cd;
+        f64::sincos_medium((double)x, sd, cd);
+        s = (float)sd;
+        c = (float)cd;
+    } else {
+        sincos_large(x, s, c);
+    }
+}
+__device__ __forceinline__ float sin_cr(float x) {
+    float s, c;
+    sincos_cr(x, s, c);
+    return s;
+}
+__device__ __forceinline__ float cos_cr(float x) {
+    float s, c;
+    sincos_cr(x, s, c);
+    return c;
+}
+// Small-argument fast path: for |y / x| <= 2^-6 the truncated Taylor series evaluated in fp64 is accurate to
+// < 2^-57 relative, i.e. it rounds to the same f32 as the full ocml routine (both are "the exact value
+// rounded once" up to ~2^-29 per call) at a fifth of the instructions.
 __device__ __forceinline__ float atan2_cr(float y, float x) {
     if (x > 0.0f && fabsf(y) <= 0.015625f * x) {
         double r = (double)y / (double)x;

@@ -247,12 +247,15 @@ __device__ vec2 es_seg_eval_with_offset(vec2 p0, vec2 p1, const EulerParams &p, 
     float k0 = p.k0, k1 = p.k1;
     vec2 uv = integ_euler_10((k0 + k1 * (0.5f * t - 0.5f)) * t, k1 * t * t);
     float scale = t / p.ch;
-    float s = scale * sin_cr(thm);
-    float cs = scale * cos_cr(thm);
+    float sin_thm, cos_thm, sin_th, cos_th;
+    sincos_cr(thm, sin_thm, cos_thm);
+    float s = scale * sin_thm;
+    float cs = scale * cos_thm;
     float ex = uv.x * cs - uv.y * s;
     float ey = -uv.y * cs - uv.x * s;
     float th = es_params_eval_th(p, t);
-    vec2 xy = v2(ex + normalized_offset * sin_cr(th), ey + normalized_offset * cos_cr(th));
+    sincos_cr(th, sin_th, cos_th);
+    vec2 xy = v2(ex + normalized_offset * sin_th, ey + normalized_offset * cos_th);
     vec2 chord = p1 - p0;
     return v2(p0.x + (chord.x * xy.x - chord.y * xy.y), p0.y + (chord.x * xy.y + chord.y * xy.x));
 }
