@@ -41,6 +41,49 @@ __device__ __forceinline__ void ptcl_store(uint32_t *ptcl, const Config &cfg, ui
     }
 }
 
+// One command = one store instruction: the words of a command are consecutive, so a wave's 64 tiles cost 64 cache
+// lines per COMMAND instead of per WORD (PTCL offsets are only 4-byte aligned; global memory takes unaligned vectors).
+struct __attribute__((packed, aligned(4))) PtclWords2 { uint32_t a, b; };
+struct __attribute__((packed, aligned(4))) PtclWords3 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(4))) PtclWords4 { uint32_t a, b, c, d; };
+template <bool EMIT>
+__device__ __forceinline__ void ptcl_store2(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b) {
+    if constexpr (EMIT) {
+        if (ix + 1u < cfg.ptcl_size) {
+            *reinterpret_cast<PtclWords2 *>(ptcl + ix) = PtclWords2{a, b};
+        } else {
+            ptcl_store<true>(ptcl, cfg, ix, a);
+            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
+        }
+    }
+}
+template <bool EMIT>
+__device__ __forceinline__ void ptcl_store3(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b, uint32_t c) {
+    if constexpr (EMIT) {
+        if (ix + 2u < cfg.ptcl_size) {
+            *reinterpret_cast<PtclWords3 *>(ptcl + ix) = PtclWords3{a, b, c};
+        } else {
+            ptcl_store<true>(ptcl, cfg, ix, a);
+            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
+            ptcl_store<true>(ptcl, cfg, ix + 2u, c);
+        }
+    }
+}
+template <bool EMIT>
+__device__ __forceinline__ void ptcl_store4(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b, uint32_t c,
+                                            uint32_t d) {
+    if constexpr (EMIT) {
+        if (ix + 3u < cfg.ptcl_size) {
+            *reinterpret_cast<PtclWords4 *>(ptcl + ix) = PtclWords4{a, b, c, d};
+        } else {
+            ptcl_store<true>(ptcl, cfg, ix, a);
+            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
+            ptcl_store<true>(ptcl, cfg, ix + 2u, c);
+            ptcl_store<true>(ptcl, cfg, ix + 3u, d);
+        }
+    }
+}
+
 // coarse.wgsl:68-86
 template <bool EMIT>
 __device__ __forceinline__ void alloc_cmd(TileState &st, Alloc &al, uint32_t size, const Config &cfg, Bump *bump, uint32_t *ptcl) {
@@ -53,8 +96,7 @@ __device__ __forceinline__ void alloc_cmd(TileState &st, Alloc &al, uint32_t siz
                 new_cmd = 0u;
                 atomicOr(&bump->failed, STAGE_COARSE);
             }
-            ptcl_store<true>(ptcl, cfg, st.cmd_offset, CMD_JUMP);
-            ptcl_store<true>(ptcl, cfg, st.cmd_offset + 1u, new_cmd);
+            ptcl_store2<true>(ptcl, cfg, st.cmd_offset, CMD_JUMP, new_cmd);
             st.cmd_offset = new_cmd;
             st.cmd_limit = new_cmd + (PTCL_INCREMENT - PTCL_HEADROOM);
         } else {
@@ -75,11 +117,8 @@ __device__ __forceinline__ void write_path(TileState &st, Alloc &al, Tile tile, 
         al.seg_next += n_segs;
         if constexpr (EMIT) tiles[tile_ix].segment_count_or_ix = ~seg_ix;
         alloc_cmd<EMIT>(st, al, 4u, cfg, bump, ptcl);
-        ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset, CMD_FILL);
         uint32_t even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u ? 1u : 0u;
-        ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 1u, (n_segs << 1) | even_odd);
-        ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 2u, seg_ix);
-        ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 3u, (uint32_t)tile.backdrop);
+        ptcl_store4<EMIT>(ptcl, cfg, st.cmd_offset, CMD_FILL, (n_segs << 1) | even_odd, seg_ix, (uint32_t)tile.backdrop);
         st.cmd_offset += 4u;
     } else {
         alloc_cmd<EMIT>(st, al, 1u, cfg, bump, ptcl);
@@ -91,17 +130,14 @@ __device__ __forceinline__ void write_path(TileState &st, Alloc &al, Tile tile, 
 template <bool EMIT>
 __device__ __forceinline__ void write2(TileState &st, Alloc &al, uint32_t a, uint32_t b, const Config &cfg, Bump *bump, uint32_t *ptcl) {
     alloc_cmd<EMIT>(st, al, 2u, cfg, bump, ptcl);
-    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset, a);
-    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 1u, b);
+    ptcl_store2<EMIT>(ptcl, cfg, st.cmd_offset, a, b);
     st.cmd_offset += 2u;
 }
 template <bool EMIT>
 __device__ __forceinline__ void write3(TileState &st, Alloc &al, uint32_t a, uint32_t b, uint32_t c, const Config &cfg, Bump *bump,
                                        uint32_t *ptcl) {
     alloc_cmd<EMIT>(st, al, 3u, cfg, bump, ptcl);
-    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset, a);
-    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 1u, b);
-    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset + 2u, c);
+    ptcl_store3<EMIT>(ptcl, cfg, st.cmd_offset, a, b, c);
     st.cmd_offset += 3u;
 }
 
