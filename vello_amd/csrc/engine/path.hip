@@ -22,6 +22,30 @@ struct LineWalk {
     uint32_t tiles_base;
 };
 
+// A LineSoup record (24 B, 8-byte aligned) and a Path record (32 B) as whole-record vector loads: left to itself the
+// compiler fetches the fields one dword at a time, each under the branch that first needs it (8 + 5 load
+// instructions per line and pass).
+struct __attribute__((aligned(8))) Words2 { uint32_t a, b; };
+struct __attribute__((aligned(16))) Words4 { uint32_t a, b, c, d; };
+__device__ __forceinline__ LineSoup load_line(const LineSoup *__restrict__ lines, uint32_t ix) {
+    const Words2 *p = reinterpret_cast<const Words2 *>(lines + ix);
+    const Words2 w0 = p[0], w1 = p[1], w2 = p[2];
+    LineSoup l;
+    l.path_ix = w0.a; l.pad = w0.b;
+    l.p0x = __uint_as_float(w1.a); l.p0y = __uint_as_float(w1.b);
+    l.p1x = __uint_as_float(w2.a); l.p1y = __uint_as_float(w2.b);
+    return l;
+}
+__device__ __forceinline__ Path load_path(const Path *__restrict__ paths, uint32_t ix) {
+    const Words4 *p = reinterpret_cast<const Words4 *>(paths + ix);
+    const Words4 w0 = p[0];
+    Path r;
+    r.bbox[0] = w0.a; r.bbox[1] = w0.b; r.bbox[2] = w0.c; r.bbox[3] = w0.d;
+    r.tiles = paths[ix].tiles;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    return r;
+}
+
 __device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths) {
     LineWalk w = {};
     const float TILE_SCALE = 0.0625f;
@@ -49,7 +73,7 @@ __device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict
     if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
     float x0 = xt0 * x_sign + (is_positive_slope ? 0.0f : -1.0f);
 
-    Path path = paths[line.path_ix];
+    Path path = load_path(paths, line.path_ix);
     int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2], bbox3 = (int32_t)path.bbox[3];
     float xmin = minf(s0.x, s1.x);
     int32_t stride = bbox2 - bbox0;
@@ -130,7 +154,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
             if (line_ix < n_lines) {
-                LineWalk w = setup_line_walk(lines[line_ix], paths);
+                LineWalk w = setup_line_walk(load_line(lines, line_ix), paths);
                 my_total += w.imax - w.imin;
             }
         }
@@ -144,7 +168,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
             LineWalk w = {};
-            if (line_ix < n_lines) w = setup_line_walk(lines[line_ix], paths);
+            if (line_ix < n_lines) w = setup_line_walk(load_line(lines, line_ix), paths);
             const uint32_t count = w.valid ? w.imax - w.imin : 0u;
             const int32_t delta = w.is_down ? -1 : 1;
             if (w.valid) {
