@@ -162,6 +162,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # the exchange step on its own ("report the gather time separately"): nothing else on the GPUs
+    exchange_ms = None
+    if distributed:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            gather_frames(ring[0], rank, world, dst=0, out=gathered)
+        torch.cuda.synchronize()
+        dist.barrier()
+        exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
+
     # serial-frame passes (separate, not part of `value`): one frame at a time gives the frame latency and
     # the isolated per-kernel durations (no other frame's kernels sharing the CUs)
     n_serial = 0 if args.timed_only else min(args.steps, 50)
@@ -248,6 +260,7 @@ def main():
             "baseline_config": "configs[2]",
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
+            "exchange_alone_ms": None if exchange_ms is None else round(exchange_ms, 4),
             "bump": bump,
             "frames_in_flight": nif,
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
