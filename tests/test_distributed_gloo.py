@@ -120,3 +120,117 @@ def test_frame_pipeline_exchanges_every_frame_once_in_order():
         p.step()
     p.flush()
     assert calls == [0, 1, 2, 0, 1, 2, 0]
+
+
+# ---- bench.py's N > 1 control flow (launch contract, barriers, MAX over ranks, pipelined gather, one JSON line) ----
+# A multi-GPU box is never available to the tests, so the distributed branch of bench.py is exercised here with the
+# GPU-facing pieces replaced by recording fakes: torch.cuda.* no-ops, "nccl" -> gloo, an Engine that paints its rank
+# into the target.  What runs for real: argument/env handling, FramePipeline, gather_frames over gloo, the barrier /
+# all_reduce(MAX) timing protocol, the exchange-alone measurement and the JSON contract.
+def _bench_worker(rank, world, port, out_path):
+    import io
+    import json
+    import runpy
+    import sys
+    import types
+
+    sys.path.insert(0, ROOT)
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "LOCAL_RANK": str(rank),
+                       "WORLD_SIZE": str(world)})
+    torch.cuda.is_available = lambda: True
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a, **k: None
+
+    class _Event:
+        def record(self, *a):
+            pass
+
+        def synchronize(self):
+            pass
+
+    torch.cuda.Event = _Event
+    real_init = dist.init_process_group
+    dist.init_process_group = lambda backend=None, **kw: real_init("gloo", **kw)
+    for name in ("zeros", "tensor"):
+        real = getattr(torch, name)
+
+        def on_cpu(*a, _real=real, **kw):
+            kw.pop("device", None)
+            return _real(*a, **kw)
+
+        setattr(torch, name, on_cpu)
+
+    import vello_amd
+    import vello_amd.renderer
+    import workloads
+
+    calls = {"render": 0, "sync_frame": 0}
+
+    class FakeEngine:
+        def __init__(self, device=0):
+            self.prof = []
+
+        def upload_scene(self, packed, layout, ramps=None):
+            pass
+
+        def set_frames_in_flight(self, n):
+            pass
+
+        def render_resident(self, w, h, base, aa, out=None):
+            calls["render"] += 1
+            out.fill_(rank + 1)
+
+        def render_frame(self, packed, layout, w, h, base, aa, out=None):
+            out.fill_(rank + 1)
+
+        def sync_frame(self, age):
+            calls["sync_frame"] += 1
+            return 0
+
+        def sync(self):
+            return 0
+
+        def set_profiling(self, stages):
+            self.prof = list(stages)
+
+        def stage_ms(self):
+            return {k: ((2.0 if k == "fine" else 0.5), 10) for k in vello_amd.renderer.STAGES}
+
+        def bump(self):
+            return {"failed": 0, "binning": 10, "ptcl": 1000, "tile": 100, "seg_counts": 50, "segments": 50, "blend": 0, "lines": 60}
+
+    vello_amd.Engine = FakeEngine
+    real_scene = workloads.paris_like_scene
+    workloads.paris_like_scene = lambda seed: real_scene(seed, n_paths=60, size=1600.0)
+
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "7", "--warmup", "2"]
+    buf = io.StringIO()
+    real_stdout = sys.stdout
+    sys.stdout = buf
+    try:
+        runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
+    finally:
+        sys.stdout = real_stdout
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    with open(f"{out_path}.{rank}", "w") as fh:
+        json.dump({"lines": lines, "calls": calls}, fh)
+
+
+def test_bench_two_rank_control_flow(built, tmp_path):
+    import json
+
+    world = 2
+    out = str(tmp_path / "bench")
+    mp.spawn(_bench_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0 = json.load(open(out + ".0"))
+    r1 = json.load(open(out + ".1"))
+    assert len(r0["lines"]) == 1 and r1["lines"] == [], "rank 0 prints exactly ONE JSON line, other ranks none"
+    line = json.loads(r0["lines"][0])
+    assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["unit"] == "frames/s" and line["higher_is_better"] is True and line["vs_baseline"] is None
+    # whole-job value: both ranks' frames over the max-over-ranks time
+    assert abs(line["value"] - 2 * 7 / (line["ms_per_step"] * 7e-3)) / line["value"] < 1e-2
+    assert line["config"]["parallelism"] == "scenes2" and line["config"]["exchange_alone_ms"] is not None
+    assert "cpu_baseline" not in line or line["cpu_baseline"] is None or line["n_gpus"] == 1
+    assert line["roofline"]["kernel"] == "k_fine"
+    assert r0["calls"]["render"] >= 9 and r1["calls"]["render"] >= 9
