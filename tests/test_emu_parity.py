@@ -110,6 +110,27 @@ def test_emu_gradient_image_blur_brushes(emu_engine, aa):
                   resolved=r)
 
 
+def test_emu_smoke_brush_goldens(emu_engine):
+    # the kernel sources (g++ / SIMT emulator build) against the reference's gradient and image smoke snapshots
+    import os
+
+    import vello_amd
+    from vello_amd import Extend
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "smoke_goldens.npz"))
+    for pre in (True, False):
+        r = vello_amd.Resolver().resolve(workloads.smoke_gradient_alpha_scene(pre))
+        img, _, _ = compare_frame(emu_engine, r.packed, r.layout, 100, 50, WHITE, AaConfig.Area, f"emu_grad_alpha_{int(pre)}", tol=1,
+                                  resolved=r)
+        assert np.array_equal(img[:, :, :3], gold["gradient_color_alpha_" + ("premultiplied" if pre else "unpremultiplied")])
+    rgba, rgb = gold["data_image_roundtrip_rgba"], gold["data_image_roundtrip_rgb"]
+    for ext in (Extend.Pad, Extend.Reflect, Extend.Repeat):
+        r = vello_amd.Resolver().resolve(workloads.smoke_data_image_scene(rgba, ext))
+        img, _, _ = compare_frame(emu_engine, r.packed, r.layout, 31, 31, BLACK, AaConfig.Area, f"emu_data_image_{int(ext)}", tol=1,
+                                  resolved=r)
+        assert np.array_equal(img[:, :, :3], rgb)
+
+
 def test_emu_auto_grow_reruns_until_the_frame_fits(built):
     # pools start far too small; robust mode grows lines -> seg_counts/segments -> ... round by round
     # (a failed stage hides the demand of the later ones) and the final frame equals the oracle's

@@ -38,6 +38,26 @@ def test_smoke_goldens_on_gpu(gpu_engine, aa):
     assert np.array_equal(img[:, :, :3], gold["filled_square"])
 
 
+def test_smoke_brush_goldens_on_gpu(gpu_engine):
+    # the reference's gradient / image smoke snapshots (regression.rs:33-104, :150-209): GPU == oracle == snapshot
+    import vello_amd
+    from vello_amd import Extend
+
+    gold = np.load(os.path.join(GOLD, "smoke_goldens.npz"))
+    for pre in (True, False):
+        r = vello_amd.Resolver().resolve(workloads.smoke_gradient_alpha_scene(pre))
+        img, _, _ = compare_frame(gpu_engine, r.packed, r.layout, 100, 50, WHITE, AaConfig.Area, f"gpu_grad_alpha_{int(pre)}", tol=1,
+                                  resolved=r)
+        name = "gradient_color_alpha_" + ("premultiplied" if pre else "unpremultiplied")
+        assert np.array_equal(img[:, :, :3], gold[name]), name
+    rgba, rgb = gold["data_image_roundtrip_rgba"], gold["data_image_roundtrip_rgb"]
+    for ext in (Extend.Pad, Extend.Reflect, Extend.Repeat):
+        r = vello_amd.Resolver().resolve(workloads.smoke_data_image_scene(rgba, ext))
+        img, _, _ = compare_frame(gpu_engine, r.packed, r.layout, 31, 31, BLACK, AaConfig.Area, f"gpu_data_image_{int(ext)}", tol=1,
+                                  resolved=r)
+        assert np.array_equal(img[:, :, :3], rgb), f"data_image_roundtrip extend {ext}"
+
+
 def test_config_c1_circle_256_area(gpu_engine):
     packed, layout = workloads.circle_scene().resolve()
     compare_frame(gpu_engine, packed, layout, 256, 256, BLACK, AaConfig.Area, "gpu_c1", tol=1)

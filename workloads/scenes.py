@@ -34,6 +34,27 @@ def smoke_square_scene():
     return s
 
 
+def smoke_gradient_alpha_scene(premultiplied):
+    """vello_tests/tests/regression.rs:150-209 (test_gradient_color_alpha_{premultiplied,unpremultiplied}): 100x50,
+    base colour white."""
+    from vello_amd import Gradient, InterpolationAlphaSpace
+    sp = InterpolationAlphaSpace.Premultiplied if premultiplied else InterpolationAlphaSpace.Unpremultiplied
+    g = Gradient.new_linear((0.0, 0.0), (100.0, 0.0)).with_stops(
+        [(0.0, Color.from_rgba8(255, 255, 0, 0)), (1.0, Color.from_rgba8(0, 0, 255, 255))]).with_interpolation_alpha_space(sp)
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, Rect(0.0, 0.0, 100.0, 50.0))
+    return s
+
+
+def smoke_data_image_scene(rgba, extend):
+    """vello_tests/tests/regression.rs:33-104 (test_data_image_roundtrip_extend_{pad,reflect,repeat}): the image drawn at
+    identity with nearest sampling into a target of its own size."""
+    from vello_amd import ImageBrush, ImageData, ImageQuality
+    s = Scene()
+    s.draw_image(ImageBrush(ImageData(rgba), extend, extend, ImageQuality.Low), Affine.IDENTITY)
+    return s
+
+
 def _polyline(pts, closed):
     n = len(pts)
     verbs = np.full(n + (1 if closed else 0), LINE_TO, dtype=np.uint8)
