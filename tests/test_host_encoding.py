@@ -209,3 +209,96 @@ def test_append_moves_resource_patches(built):
     base = r.layout.draw_data_base
     assert words[base] == 0xFF010101 and words[base + 1] == (0 << 2) and words[base + 6] == (1 << 2)
     assert r.ramps.reshape(-1, 512)[1, 511] == 0xFFFFFFFF
+
+
+# ---- image cache residency (vello_encoding/src/image_cache.rs:213-347, through Resolver as resolve.rs:507-541 drives it) ----
+def _img(w, h, v=0):
+    from vello_amd import ImageData
+
+    px = np.full((h, w, 4), v, dtype=np.uint8)
+    px[:, :, 3] = 255
+    return ImageData(px)
+
+
+def _scene_with(images):
+    from vello_amd import ImageBrush, ImageQuality
+
+    s = Scene()
+    for im in images:
+        s.draw_image(ImageBrush(im, quality=ImageQuality.Low), Affine.IDENTITY)
+    return s
+
+
+def test_image_cache_atlas_size_persists_after_growth(built):
+    # image_cache.rs:226-233 + resolve.rs:524-527: an image that does not fit doubles the atlas; the size stays
+    import vello_amd
+
+    r = vello_amd.Resolver(atlas_sizes=(16, 64))
+    a = _img(24, 24)
+    out = r.resolve(_scene_with([a]))
+    assert out.atlas_size == 32 and out.atlas_resized and out.new_uploads == 1
+    out = r.resolve(_scene_with([a]))
+    assert out.atlas_size == 32 and not out.atlas_resized and out.new_uploads == 0
+
+
+def test_image_cache_dirty_entries_are_uploaded_again(built):
+    # image_cache.rs:236-291: resident entries are reused without an upload; marked dirty they are uploaded again by the
+    # next resolve that USES them (an unused dirty entry stays dirty), at the same place
+    import vello_amd
+
+    r = vello_amd.Resolver(atlas_sizes=(16, 16))
+    a, b = _img(8, 8, 1), _img(4, 4, 2)
+    first = r.resolve(_scene_with([a, b]))
+    assert first.new_uploads == 2
+    where = {(w, h): (x, y) for x, y, px in first.uploads for h, w in [px.shape[:2]]}
+    again = r.resolve(_scene_with([a, b]))
+    assert again.new_uploads == 0
+    r.mark_image_dirty(a)
+    unused = r.resolve(_scene_with([b]))          # `a` is not in this frame: nothing to upload, it stays dirty
+    assert unused.new_uploads == 0
+    used = r.resolve(_scene_with([a, b]))
+    assert used.new_uploads == 1
+    assert {(w, h): (x, y) for x, y, px in used.uploads for h, w in [px.shape[:2]]} == where
+    assert r.resolve(_scene_with([a, b])).new_uploads == 0   # clean again
+
+
+def test_image_cache_stale_entries_are_evicted_under_pressure(built):
+    # image_cache.rs:294-332: an entry no resolve used for two generations makes room when the atlas is full and cannot
+    # grow; at most one eviction scan per resolve; an image that still does not fit is not drawn (resolve.rs:309-316)
+    import vello_amd
+
+    r = vello_amd.Resolver(atlas_sizes=(16, 16))
+    a, b, c = _img(16, 16, 1), _img(16, 16, 2), _img(16, 16, 3)
+    assert r.resolve(_scene_with([a])).new_uploads == 1
+    assert r.image_cache_info() == (1, 16)
+    # generation 2: `a` was used one generation ago: not stale yet, `b` cannot be placed and is not drawn
+    out = r.resolve(_scene_with([b]))
+    assert out.evicted == 0 and out.new_uploads == 0
+    dd = out.packed.view(np.uint32)[out.layout.draw_data_base:]
+    assert dd[1] == 0, "width_height zeroed: nothing is sampled"
+    # two more generations without `a`: now it is stale and gives way
+    r.resolve(Scene())  # a scene without patches does not advance the generation (resolve.rs:189-192)
+    out = r.resolve(_scene_with([b]))
+    out = r.resolve(_scene_with([b]))
+    assert out.evicted == 1 and out.new_uploads == 1 and out.atlas_resized and out.atlas_size == 16
+    assert r.image_cache_info() == (1, 16)
+    # both `b` (used last generation) and `c` want the full atlas: nothing is stale, `c` is not drawn
+    out = r.resolve(_scene_with([b, c]))
+    assert out.evicted == 0 and out.new_uploads == 0
+
+
+def test_image_cache_growth_reuploads_everything_in_use(built):
+    # image_cache.rs:184-210 (repack: every entry moves and becomes dirty) + resolve.rs:524-527 (restart the pass)
+    import vello_amd
+
+    r = vello_amd.Resolver(atlas_sizes=(16, 64))
+    a, b = _img(16, 8, 1), _img(16, 8, 2)
+    assert r.resolve(_scene_with([a, b])).new_uploads == 2
+    c = _img(16, 16, 3)
+    out = r.resolve(_scene_with([a, b, c]))
+    assert out.atlas_size == 32 and out.atlas_resized and out.new_uploads == 3
+    rects = [(x, y, px.shape[1], px.shape[0]) for x, y, px in out.uploads]
+    for i, (x0, y0, w0, h0) in enumerate(rects):
+        assert x0 + w0 <= 32 and y0 + h0 <= 32
+        for x1, y1, w1, h1 in rects[i + 1:]:
+            assert x0 + w0 <= x1 or x1 + w1 <= x0 or y0 + h0 <= y1 or y1 + h1 <= y0, "placements overlap"

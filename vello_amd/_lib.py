@@ -128,9 +128,12 @@ def load_library():
     sig("vh_scene_draw_image", None, [vp, vp, dp])
     sig("vh_scene_n_patches", sz, [vp])
     sig("vh_resolver_new", vp, [])
+    sig("vh_resolver_new_with_atlas_sizes", vp, [u32, u32])
     sig("vh_resolver_free", None, [vp])
     sig("vh_resolver_resolve", sz, [vp, vp, c.POINTER(vp), c.POINTER(u32), c.POINTER(vp), c.POINTER(u32)])
     sig("vh_resolver_upload", vp, [vp, u32, c.POINTER(u32)])
+    sig("vh_resolver_mark_image_dirty", None, [vp, c.c_uint64])
+    sig("vh_resolver_image_cache_info", None, [vp, c.POINTER(u32)])
     sig("vh_scene_stream_bytes", sz, [vp, i32])
     sig("vh_scene_stream_copy", None, [vp, i32, vp])
     sig("vh_scene_counts", None, [vp, c.POINTER(u32)])

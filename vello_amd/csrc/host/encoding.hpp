@@ -259,13 +259,29 @@ struct ImageUpload {
     ImageData image;
     uint32_t x, y;
 };
+// image_cache.rs:37-210.  Residency, dirtiness and staleness follow the reference; the allocator does not: the
+// reference delegates to the guillotiere crate (not vendored), here a shelf packer places images, and because a shelf
+// packer cannot free a single rectangle an eviction repacks the survivors (they are re-uploaded, like after a growth).
+// Atlas positions are late-bound into the draw data at every resolve, so they are not part of the parity surface.
 class ImageCache {
   public:
     static constexpr uint32_t DEFAULT_ATLAS_SIZE = 1024, MAX_ATLAS_SIZE = 8192;
-    void begin_resolve() { uploads_.clear(); }
+    static constexpr uint64_t EVICT_AFTER_GENERATIONS = 2;
+    ImageCache() = default;
+    ImageCache(uint32_t initial_size, uint32_t max_size) : size_(initial_size), max_size_(max_size) {}
+    void begin_resolve();                  // a new generation; nothing queued for upload, nothing evicted yet
+    void restart_resolve_pass();           // placement starts over (after a growth / eviction moved the residents)
     bool get_or_insert(const ImageData &image, uint32_t *x, uint32_t *y);
+    void finish_resolve();                 // what this generation used is clean now
+    void mark_dirty(const ImageData &image);
+    bool can_fit_image(const ImageData &image) const { return image.width <= size_ && image.height <= size_; }
+    bool evict_stale_entries();            // at most once per resolve; true if anything was evicted
     bool bump_size();
+    bool repack_to_size(uint32_t size);    // all or nothing: a failed repack leaves the residency unchanged
     uint32_t size() const { return size_; }
+    uint32_t evicted() const { return evicted_in_resolve_; }
+    size_t n_resident() const { return resident_.size(); }
+    bool is_resident(const ImageData &image) const;
     const std::vector<ImageUpload> &uploads() const { return uploads_; }
     bool resized() const { return resized_; }
     void clear_resized() { resized_ = false; }
@@ -274,10 +290,19 @@ class ImageCache {
     struct Resident {
         ImageData image;
         uint32_t x, y;
+        bool dirty;
+        uint64_t last_used_generation;
     };
-    bool alloc(uint32_t w, uint32_t h, uint32_t *x, uint32_t *y);
-    uint32_t size_ = DEFAULT_ATLAS_SIZE;
-    uint32_t shelf_y_ = 0, shelf_h_ = 0, shelf_x_ = 0;
+    struct Shelves {
+        uint32_t size, shelf_y = 0, shelf_h = 0, shelf_x = 0;
+        bool alloc(uint32_t w, uint32_t h, uint32_t *x, uint32_t *y);
+    };
+    bool repack(uint32_t size, const std::vector<Resident> &keep);
+    uint32_t size_ = DEFAULT_ATLAS_SIZE, max_size_ = MAX_ATLAS_SIZE;
+    Shelves shelves_{DEFAULT_ATLAS_SIZE};
+    bool shelves_init_ = false;
+    uint64_t generation_ = 0;
+    uint32_t evicted_in_resolve_ = 0;
     std::vector<Resident> resident_;
     std::vector<ImageUpload> uploads_;
     bool resized_ = true;  // the atlas texture has to be (re)created before the first upload
@@ -289,12 +314,19 @@ struct Resolved {
     const uint32_t *ramps = nullptr;  // 512 texels per ramp
     uint32_t n_ramps = 0;
     uint32_t atlas_size = 0;          // square atlas side; 0 when the scene has no images
-    bool atlas_resized = false;       // the atlas must be re-created (all resident images are in `uploads`)
+    bool atlas_resized = false;       // the atlas must be re-created: grown, or repacked after an eviction (every image
+                                      // this frame samples is in `uploads`)
+    uint32_t evicted = 0;             // stale residents dropped by this resolve (image_cache.rs:19-22)
     const std::vector<ImageUpload> *uploads = nullptr;
 };
 class Resolver {
   public:
+    Resolver() = default;
+    Resolver(uint32_t atlas_initial_size, uint32_t atlas_max_size) : image_cache_(atlas_initial_size, atlas_max_size) {}
     Resolved resolve(const Encoding &encoding, std::vector<uint8_t> &packed);
+    // resolve.rs:173-179: the next resolve that uses `image` uploads it again (its pixels changed in place)
+    void mark_image_dirty(const ImageData &image) { image_cache_.mark_dirty(image); }
+    const ImageCache &image_cache() const { return image_cache_; }
 
   private:
     RampCache ramp_cache_;

@@ -197,10 +197,17 @@ size_t vh_scene_n_patches(void *s) { return ((SceneHandle *)s)->scene.encoding()
 
 // ---- Resolver (resolve.rs:172-393): ramps + image atlas placement + packed scene ----
 void *vh_resolver_new() { return new ResolverHandle(); }
+// image_cache.rs:65 new_with_sizes: a resolver whose atlas starts / stops growing at the given sides
+void *vh_resolver_new_with_atlas_sizes(uint32_t initial_size, uint32_t max_size) {
+    ResolverHandle *h = new ResolverHandle();
+    h->resolver = vello_encoding::Resolver(initial_size, max_size);
+    return h;
+}
 void vh_resolver_free(void *r) { delete (ResolverHandle *)r; }
-// info_out: n_ramps, atlas_size, atlas_resized, n_uploads.  Pointers stay valid until the next resolve on this resolver.
+// info_out: n_ramps, atlas_size, atlas_resized, n_uploads, evicted.  Pointers stay valid until the next resolve on this
+// resolver.
 size_t vh_resolver_resolve(void *r, void *scene, const uint8_t **packed, uint32_t layout_out[10], const uint32_t **ramps,
-                           uint32_t info_out[4]) {
+                           uint32_t info_out[5]) {
     ResolverHandle *h = (ResolverHandle *)r;
     h->last = h->resolver.resolve(((SceneHandle *)scene)->scene.encoding(), h->packed);
     std::memcpy(layout_out, &h->last.layout, sizeof h->last.layout);
@@ -210,7 +217,20 @@ size_t vh_resolver_resolve(void *r, void *scene, const uint8_t **packed, uint32_
     info_out[1] = h->last.atlas_size;
     info_out[2] = h->last.atlas_resized ? 1u : 0u;
     info_out[3] = h->last.uploads ? (uint32_t)h->last.uploads->size() : 0u;
+    info_out[4] = h->last.evicted;
     return h->packed.size();
+}
+// Resolver::mark_image_dirty (resolve.rs:173-179): the blob with this id changed; re-upload it when next used
+void vh_resolver_mark_image_dirty(void *r, uint64_t image_id) {
+    vello_encoding::ImageData image;
+    image.id = image_id;
+    ((ResolverHandle *)r)->resolver.mark_image_dirty(image);
+}
+// n_resident, atlas size
+void vh_resolver_image_cache_info(void *r, uint32_t out[2]) {
+    const vello_encoding::ImageCache &c = ((ResolverHandle *)r)->resolver.image_cache();
+    out[0] = (uint32_t)c.n_resident();
+    out[1] = c.size();
 }
 const uint8_t *vh_resolver_upload(void *r, uint32_t i, uint32_t xywh_out[4]) {
     ResolverHandle *h = (ResolverHandle *)r;

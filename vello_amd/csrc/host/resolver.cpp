@@ -122,65 +122,117 @@ uint32_t RampCache::add(InterpolationAlphaSpace space, const ColorStop *stops, s
     return append();
 }
 
-// ---------------- ImageCache ----------------
-bool ImageCache::alloc(uint32_t w, uint32_t h, uint32_t *x, uint32_t *y) {
-    if (w > size_ || h > size_) return false;
-    if (shelf_x_ + w > size_) {  // next shelf
-        shelf_y_ += shelf_h_;
-        shelf_h_ = 0;
-        shelf_x_ = 0;
+// ---------------- ImageCache (image_cache.rs:61-210) ----------------
+bool ImageCache::Shelves::alloc(uint32_t w, uint32_t h, uint32_t *x, uint32_t *y) {
+    if (w > size || h > size) return false;
+    if (shelf_x + w > size) {  // next shelf
+        shelf_y += shelf_h;
+        shelf_h = 0;
+        shelf_x = 0;
     }
-    if (shelf_y_ + h > size_) return false;
-    *x = shelf_x_;
-    *y = shelf_y_;
-    shelf_x_ += w;
-    shelf_h_ = std::max(shelf_h_, h);
+    if (shelf_y + h > size) return false;
+    *x = shelf_x;
+    *y = shelf_y;
+    shelf_x += w;
+    shelf_h = std::max(shelf_h, h);
     return true;
 }
 
+void ImageCache::begin_resolve() {
+    generation_ += 1;
+    evicted_in_resolve_ = 0;
+    uploads_.clear();
+}
+
+void ImageCache::restart_resolve_pass() {
+    uploads_.clear();
+    for (Resident &r : resident_)
+        if (r.last_used_generation == generation_) r.last_used_generation = generation_ - 1;
+}
+
+bool ImageCache::is_resident(const ImageData &image) const {
+    for (const Resident &r : resident_)
+        if (r.image.id == image.id) return true;
+    return false;
+}
+
 bool ImageCache::get_or_insert(const ImageData &image, uint32_t *x, uint32_t *y) {
-    for (const Resident &r : resident_) {
+    if (!shelves_init_) {
+        shelves_ = Shelves{size_};
+        shelves_init_ = true;
+    }
+    for (Resident &r : resident_) {
         if (r.image.id == image.id) {
             *x = r.x;
             *y = r.y;
+            if (r.last_used_generation != generation_) {
+                r.last_used_generation = generation_;
+                if (r.dirty) uploads_.push_back(ImageUpload{r.image, r.x, r.y});
+            }
             return true;
         }
     }
-    if (!alloc(image.width, image.height, x, y)) return false;
-    resident_.push_back(Resident{image, *x, *y});
+    if (!shelves_.alloc(image.width, image.height, x, y)) return false;
+    resident_.push_back(Resident{image, *x, *y, true, generation_});
     uploads_.push_back(ImageUpload{image, *x, *y});
     return true;
 }
 
-// image_cache.rs:76-86: double the side and repack everything that is resident
+void ImageCache::finish_resolve() {
+    for (Resident &r : resident_)
+        if (r.last_used_generation == generation_) r.dirty = false;
+}
+
+void ImageCache::mark_dirty(const ImageData &image) {
+    for (Resident &r : resident_)
+        if (r.image.id == image.id) r.dirty = true;
+}
+
+// Places `keep` (in blob-id order, as image_cache.rs:184-188 does) into a fresh atlas of side `size`; every entry
+// becomes dirty because it moved.  All or nothing.
+bool ImageCache::repack(uint32_t size, const std::vector<Resident> &keep) {
+    std::vector<Resident> sorted = keep;
+    std::sort(sorted.begin(), sorted.end(), [](const Resident &a, const Resident &b) { return a.image.id < b.image.id; });
+    Shelves shelves{size};
+    for (Resident &r : sorted) {
+        if (!shelves.alloc(r.image.width, r.image.height, &r.x, &r.y)) return false;
+        r.dirty = true;
+    }
+    resident_ = std::move(sorted);
+    shelves_ = shelves;
+    shelves_init_ = true;
+    size_ = size;
+    resized_ = true;
+    return true;
+}
+
+bool ImageCache::repack_to_size(uint32_t size) { return repack(size, resident_); }
+
+// image_cache.rs:101-111: double the side until everything that is resident fits
 bool ImageCache::bump_size() {
-    uint32_t new_size = size_ * 2;
-    while (new_size <= MAX_ATLAS_SIZE) {
-        std::vector<Resident> old = std::move(resident_);
-        uint32_t old_size = size_;
-        resident_.clear();
-        uploads_.clear();
-        size_ = new_size;
-        shelf_x_ = shelf_y_ = shelf_h_ = 0;
-        bool ok = true;
-        for (const Resident &r : old) {
-            uint32_t x, y;
-            if (!alloc(r.image.width, r.image.height, &x, &y)) {
-                ok = false;
-                break;
-            }
-            resident_.push_back(Resident{r.image, x, y});
-            uploads_.push_back(ImageUpload{r.image, x, y});
-        }
-        if (ok) {
-            resized_ = true;
+    for (uint64_t new_size = (uint64_t)size_ * 2u; new_size <= max_size_; new_size *= 2u) {
+        if (repack_to_size((uint32_t)new_size)) {
+            uploads_.clear();
             return true;
         }
-        resident_ = std::move(old);
-        size_ = old_size;
-        new_size *= 2;
     }
     return false;
+}
+
+// image_cache.rs:167-182: residents no resolve has used for EVICT_AFTER_GENERATIONS generations make room
+bool ImageCache::evict_stale_entries() {
+    if (evicted_in_resolve_ != 0u) return false;
+    if (generation_ < EVICT_AFTER_GENERATIONS) return false;
+    const uint64_t stale_before = generation_ - EVICT_AFTER_GENERATIONS;
+    std::vector<Resident> keep;
+    for (const Resident &r : resident_)
+        if (r.last_used_generation >= stale_before) keep.push_back(r);
+    const uint32_t n_evicted = (uint32_t)(resident_.size() - keep.size());
+    if (n_evicted == 0u) return false;
+    if (!repack(size_, keep)) return false;  // cannot happen for a subset in practice; the residency is untouched if it does
+    uploads_.clear();
+    evicted_in_resolve_ = n_evicted;
+    return true;
 }
 
 // ---------------- Resolver::resolve (resolve.rs:172-393, glyph runs not restated) ----------------
@@ -220,12 +272,16 @@ Resolved Resolver::resolve(const Encoding &encoding, std::vector<uint8_t> &data)
             pending.push_back({p.image, false, 0u, 0u});
         }
     }
-    // resolve_pending_images (resolve.rs:507-541): grow the atlas until everything fits or the maximum is hit
+    // resolve_pending_images (resolve.rs:507-541): place every image; under pressure first drop what no recent frame
+    // used, then grow the atlas, until everything fits or the maximum size is hit (such an image is not drawn).
+    // Both remedies move the residents here, so both restart the placement pass.
     for (bool restart = true; restart;) {
         restart = false;
+        image_cache_.restart_resolve_pass();
         for (PendingImage &pi : pending) {
             pi.placed = image_cache_.get_or_insert(pi.image, &pi.x, &pi.y);
-            if (!pi.placed && image_cache_.bump_size()) {
+            if (pi.placed) continue;
+            if ((image_cache_.can_fit_image(pi.image) && image_cache_.evict_stale_entries()) || image_cache_.bump_size()) {
                 restart = true;
                 break;
             }
@@ -297,7 +353,9 @@ Resolved Resolver::resolve(const Encoding &encoding, std::vector<uint8_t> &data)
         out.atlas_resized = image_cache_.resized();
         image_cache_.clear_resized();
         out.uploads = &image_cache_.uploads();
+        out.evicted = image_cache_.evicted();
     }
+    image_cache_.finish_resolve();
     return out;
 }
 

@@ -319,9 +319,11 @@ class Resolved:
 class Resolver:
     """vello_encoding::Resolver: owns the ramp cache and the image atlas allocation across frames."""
 
-    def __init__(self):
+    def __init__(self, atlas_sizes=None):
+        """atlas_sizes: optional (initial side, maximum side) of the image atlas (default 1024, 8192)."""
         self._lib = load_library()
-        self._h = self._lib.vh_resolver_new()
+        self._h = (self._lib.vh_resolver_new() if atlas_sizes is None
+                   else self._lib.vh_resolver_new_with_atlas_sizes(int(atlas_sizes[0]), int(atlas_sizes[1])))
         self._resident = {}
 
     def __del__(self):
@@ -336,7 +338,7 @@ class Resolver:
         from .renderer import Layout
         ptr, ramps_p = ctypes.c_void_p(), ctypes.c_void_p()
         lay = (ctypes.c_uint32 * 10)()
-        info = (ctypes.c_uint32 * 4)()
+        info = (ctypes.c_uint32 * 5)()
         n = self._lib.vh_resolver_resolve(self._h, scene._h, ctypes.byref(ptr), lay, ctypes.byref(ramps_p), info)
         packed = (np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)).copy()
                   if n else np.zeros(0, dtype=np.uint8))
@@ -351,8 +353,21 @@ class Resolver:
             dp = self._lib.vh_resolver_upload(self._h, i, xywh)
             x, y, w, h = list(xywh)
             px = np.ctypeslib.as_array(ctypes.cast(dp, ctypes.POINTER(ctypes.c_uint8)), shape=(h, w, 4)).copy()
+            self._resident.pop((x, y), None)  # a later upload paints over earlier ones: keep the list in upload order
             self._resident[(x, y)] = px
         uploads_all = [(x, y, px) for (x, y), px in self._resident.items()]
         r = Resolved(packed, Layout(*list(lay)), ramps, atlas_size, atlas_resized, uploads_all)
         r.new_uploads = n_uploads
+        r.evicted = int(info[4])
         return r
+
+    def mark_image_dirty(self, image):
+        """Resolver::mark_image_dirty (resolve.rs:173-179): `image` (an ImageData) changed in place; the next resolve
+        that uses it uploads it again."""
+        self._lib.vh_resolver_mark_image_dirty(self._h, ctypes.c_uint64(image.id))
+
+    def image_cache_info(self):
+        """(resident images, atlas side): test / debug view of the image cache."""
+        out = (ctypes.c_uint32 * 2)()
+        self._lib.vh_resolver_image_cache_info(self._h, out)
+        return int(out[0]), int(out[1])
