@@ -242,6 +242,31 @@ def test_emu_reference_brush_and_layer_scenes(emu_engine, which):
     compare_frame(emu_engine, r.packed, r.layout, w, h, BLACK, AaConfig.Msaa8, "emu_" + which, resolved=r)
 
 
+@pytest.mark.parametrize("which", ["ref_stroke_styles", "ref_stroke_styles_non_uniform", "ref_stroke_styles_skew", "two_point_radial",
+                                   "conflation_artifacts", "labyrinth", "clip_test", "luminance_mask", "image_extend_modes",
+                                   "image_extend_modes_nearest"])
+def test_emu_reference_catalogue_second_batch(emu_engine, which):
+    # test_scenes.rs:335-511 (cap / join / miter-limit matrix under identity, non-uniform scale and skew), :1045-1211
+    # (COLR two-point radial cases x extend modes), :1444-1531 (shared edges of opposite winding), :1533-1608 (140
+    # overlapping sub-paths in one fill), :1708-1911 (even-odd clip, STROKE-styled clip layer, blend layer cut by its clip
+    # rect), :2214-2289 (luminance mask layer), :2168-2212 (image brush extend modes)
+    import vello_amd
+    from vello_amd import Affine, ImageQuality
+
+    if which.startswith("ref_stroke_styles"):
+        t = {"ref_stroke_styles": None, "ref_stroke_styles_non_uniform": Affine.scale_non_uniform(1.2, 0.7),
+             "ref_stroke_styles_skew": Affine.skew(1.0, 0.0)}[which]
+        scene, w, h = workloads.ref_stroke_styles_scene(t)
+    elif which == "image_extend_modes_nearest":
+        scene, w, h = workloads.image_extend_modes_scene(ImageQuality.Low)
+    else:
+        scene, w, h = getattr(workloads, which + "_scene")()
+    r = vello_amd.Resolver().resolve(scene)
+    for aa in (AaConfig.Area, AaConfig.Msaa16):
+        compare_frame(emu_engine, r.packed, r.layout, w, h, WHITE, aa, f"emu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                      resolved=r)
+
+
 def test_emu_auto_grow_covers_large_targets(built):
     # the PTCL pool holds a fixed 64 words per tile: a target with more tiles than the pool was sized for is an
     # E_INVALID configuration error, unless robust mode may grow the pool

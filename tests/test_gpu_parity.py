@@ -373,6 +373,31 @@ def test_reference_brush_and_layer_scenes(gpu_engine, which, aa):
                   resolved=r)
 
 
+@pytest.mark.parametrize("aa", [AaConfig.Area, AaConfig.Msaa16])
+@pytest.mark.parametrize("which", ["ref_stroke_styles", "ref_stroke_styles_non_uniform", "ref_stroke_styles_skew", "two_point_radial",
+                                   "conflation_artifacts", "labyrinth", "clip_test", "luminance_mask", "image_extend_modes",
+                                   "image_extend_modes_nearest"])
+def test_reference_catalogue_second_batch(gpu_engine, which, aa):
+    # test_scenes.rs:335-511 (cap / join / miter-limit matrix under identity, non-uniform scale and skew), :1045-1211
+    # (COLR two-point radial cases x extend modes), :1444-1531 (conflation: shared edges of opposite winding), :1533-1608
+    # (labyrinth: 140 overlapping sub-paths in one fill), :1708-1911 (even-odd clip, STROKE-styled clip layer, clipped
+    # blend layer), :2214-2289 (luminance mask), :2168-2212 (image brush extend modes, bilinear and nearest)
+    import vello_amd
+    from vello_amd import Affine, ImageQuality
+
+    if which.startswith("ref_stroke_styles"):
+        t = {"ref_stroke_styles": None, "ref_stroke_styles_non_uniform": Affine.scale_non_uniform(1.2, 0.7),
+             "ref_stroke_styles_skew": Affine.skew(1.0, 0.0)}[which]
+        scene, w, h = workloads.ref_stroke_styles_scene(t)
+    elif which == "image_extend_modes_nearest":
+        scene, w, h = workloads.image_extend_modes_scene(ImageQuality.Low)
+    else:
+        scene, w, h = getattr(workloads, which + "_scene")()
+    r = vello_amd.Resolver().resolve(scene)
+    compare_frame(gpu_engine, r.packed, r.layout, w, h, WHITE, aa, f"gpu_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                  resolved=r)
+
+
 def test_large_target_with_auto_grow(built):
     # 6000 x 6000 = 140 625 tiles x 64 PTCL words: past the fixed 2^23-word pool; robust mode sizes the pool for the target
     import vello_amd

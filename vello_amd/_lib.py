@@ -115,6 +115,7 @@ def load_library():
     sig("vh_scene_push_layer", None, [vp, i32, u32, u32, c.c_float, dp, vp, vp, sz])
     sig("vh_scene_push_luminance_mask_layer", None, [vp, i32, c.c_float, dp, vp, vp, sz])
     sig("vh_scene_push_clip_layer", None, [vp, i32, dp, vp, vp, sz])
+    sig("vh_scene_push_layer_stroked", i32, [vp, i32, c.c_double, i32, c.c_double, i32, i32, u32, u32, c.c_float, dp, vp, vp, sz])
     sig("vh_scene_pop_layer", None, [vp])
     sig("vh_scene_append", None, [vp, vp, dp])
     sig("vh_brush_solid", vp, [fp])

@@ -111,6 +111,24 @@ void vh_scene_push_luminance_mask_layer(void *s, int fill_rule, float alpha, con
 void vh_scene_push_clip_layer(void *s, int fill_rule, const double *affine, const uint8_t *verbs, const double *pts, size_t n) {
     ((SceneHandle *)s)->scene.push_clip_layer((vello::Fill)fill_rule, affine_from(affine), path_from_arrays(verbs, pts, n));
 }
+// layers clipped to a stroked outline (scene.rs:177-187).  kind: 0 push_layer (mix, compose, alpha), 1 luminance mask
+// (alpha), 2 clip layer.  Returns -1 for a dashed stroke (nothing encoded).
+int vh_scene_push_layer_stroked(void *s, int kind, double width, int join, double miter_limit, int start_cap, int end_cap, uint32_t mix,
+                                uint32_t compose, float alpha, const double *affine, const uint8_t *verbs, const double *pts, size_t n) {
+    kurbo::Stroke st;
+    st.width = width;
+    st.join = (kurbo::Join)join;
+    st.miter_limit = miter_limit;
+    st.start_cap = (kurbo::Cap)start_cap;
+    st.end_cap = (kurbo::Cap)end_cap;
+    vello::Scene &scene = ((SceneHandle *)s)->scene;
+    const kurbo::BezPath path = path_from_arrays(verbs, pts, n);
+    bool ok;
+    if (kind == 0) ok = scene.push_layer(st, vello::BlendMode{mix, compose}, alpha, affine_from(affine), path);
+    else if (kind == 1) ok = scene.push_luminance_mask_layer(st, alpha, affine_from(affine), path);
+    else ok = scene.push_clip_layer(st, affine_from(affine), path);
+    return ok ? 0 : -1;
+}
 void vh_scene_pop_layer(void *s) { ((SceneHandle *)s)->scene.pop_layer(); }
 void vh_scene_append(void *s, void *other, const double *affine) {
     std::optional<Affine> t;

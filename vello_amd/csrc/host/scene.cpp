@@ -118,6 +118,34 @@ void Scene::push_clip_layer(Fill clip_style, const Affine &transform, const kurb
     push_layer_inner(DrawBeginClip::clip(), clip_style, transform, clip);
 }
 
+// scene.rs:159-215, StyleRef::Stroke arm
+bool Scene::push_layer_inner(const DrawBeginClip &params, const kurbo::Stroke &clip_style, const Affine &transform,
+                             const kurbo::BezPath &clip) {
+    if (!clip_style.dash_pattern.empty()) return false;
+    bool encoded;
+    if (clip_style.width == 0.) {
+        encoding_.encode_fill_style(Fill::NonZero);
+        encoded = false;
+    } else {
+        encoded = stroke_gpu_inner(clip_style, transform, clip);
+    }
+    if (!encoded) encoding_.encode_empty_shape();
+    encoding_.encode_begin_clip(params);
+    return true;
+}
+
+bool Scene::push_layer(const kurbo::Stroke &clip_style, BlendMode blend, float alpha, const Affine &transform, const kurbo::BezPath &clip) {
+    return push_layer_inner(DrawBeginClip::make(blend.mix, blend.compose, std::clamp(alpha, 0.0f, 1.0f)), clip_style, transform, clip);
+}
+
+bool Scene::push_luminance_mask_layer(const kurbo::Stroke &clip_style, float alpha, const Affine &transform, const kurbo::BezPath &clip) {
+    return push_layer_inner(DrawBeginClip::luminance_mask(std::clamp(alpha, 0.0f, 1.0f)), clip_style, transform, clip);
+}
+
+bool Scene::push_clip_layer(const kurbo::Stroke &clip_style, const Affine &transform, const kurbo::BezPath &clip) {
+    return push_layer_inner(DrawBeginClip::clip(), clip_style, transform, clip);
+}
+
 void Scene::append(const Scene &other, const std::optional<Affine> &transform) {
     std::optional<Transform> t;
     if (transform) t = Transform::from_kurbo(*transform);

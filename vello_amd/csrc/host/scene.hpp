@@ -57,12 +57,20 @@ class Scene {
     void push_layer(Fill clip_style, BlendMode blend, float alpha, const Affine &transform, const kurbo::BezPath &clip);
     void push_luminance_mask_layer(Fill clip_style, float alpha, const Affine &transform, const kurbo::BezPath &clip);
     void push_clip_layer(Fill clip_style, const Affine &transform, const kurbo::BezPath &clip);
+    // the same three with a stroke as clip style (StyleRef::Stroke, scene.rs:177-187): the layer is clipped to the
+    // stroked outline of `clip`; a zero-width stroke suppresses all drawing until the layer is popped.  Returns false
+    // for a dashed stroke (kurbo::dash is not restated), in which case nothing was encoded.
+    bool push_layer(const kurbo::Stroke &clip_style, BlendMode blend, float alpha, const Affine &transform, const kurbo::BezPath &clip);
+    bool push_luminance_mask_layer(const kurbo::Stroke &clip_style, float alpha, const Affine &transform, const kurbo::BezPath &clip);
+    bool push_clip_layer(const kurbo::Stroke &clip_style, const Affine &transform, const kurbo::BezPath &clip);
     void pop_layer() { encoding_.encode_end_clip(); }
     // scene.rs:463-469
     void append(const Scene &other, const std::optional<Affine> &transform);
 
   private:
     void push_layer_inner(const vello_encoding::DrawBeginClip &params, Fill clip_style, const Affine &transform,
+                          const kurbo::BezPath &clip);
+    bool push_layer_inner(const vello_encoding::DrawBeginClip &params, const kurbo::Stroke &clip_style, const Affine &transform,
                           const kurbo::BezPath &clip);
     void encode_brush(const Brush &brush, float alpha);  // encoding.rs:286-345
     bool stroke_gpu_inner(const kurbo::Stroke &style, const Affine &transform, const kurbo::BezPath &shape);

@@ -5,7 +5,7 @@ import enum
 import numpy as np
 
 from ._lib import load_library, LayoutStruct
-from .kurbo import Affine
+from .kurbo import Affine, Stroke
 
 
 class Fill(enum.IntEnum):
@@ -242,17 +242,33 @@ class Scene:
         bh = _brush_handle(image)
         self._lib.vh_scene_draw_image(self._h, bh._h, transform._ptr())
 
-    def push_layer(self, clip_style, blend, alpha, transform, clip):
+    def _push_stroked(self, kind, st, mix, compose, alpha, transform, clip):
         v, c, vp, cp, n = _path_args(clip)
+        if getattr(st, "dash_pattern", None):
+            raise NotImplementedError("dashed strokes are expanded by kurbo::dash upstream; not restated")
+        r = self._lib.vh_scene_push_layer_stroked(self._h, kind, st.width, int(st.join), st.miter_limit, int(st.start_cap),
+                                                  int(st.end_cap), mix, compose, alpha, transform._ptr(), vp, cp, n)
+        if r != 0:
+            raise NotImplementedError("dashed strokes are expanded by kurbo::dash upstream; not restated")
+
+    def push_layer(self, clip_style, blend, alpha, transform, clip):
+        """Scene::push_layer (scene.rs:105-121); clip_style is a Fill rule or a Stroke (clip to the stroked outline)."""
         if not isinstance(blend, BlendMode):
             blend = BlendMode(blend)
+        if isinstance(clip_style, Stroke):
+            return self._push_stroked(0, clip_style, blend.mix, blend.compose, alpha, transform, clip)
+        v, c, vp, cp, n = _path_args(clip)
         self._lib.vh_scene_push_layer(self._h, int(clip_style), blend.mix, blend.compose, alpha, transform._ptr(), vp, cp, n)
 
     def push_luminance_mask_layer(self, clip_style, alpha, transform, clip):
+        if isinstance(clip_style, Stroke):
+            return self._push_stroked(1, clip_style, 0, 0, alpha, transform, clip)
         v, c, vp, cp, n = _path_args(clip)
         self._lib.vh_scene_push_luminance_mask_layer(self._h, int(clip_style), alpha, transform._ptr(), vp, cp, n)
 
     def push_clip_layer(self, clip_style, transform, clip):
+        if isinstance(clip_style, Stroke):
+            return self._push_stroked(2, clip_style, 0, 0, 1.0, transform, clip)
         v, c, vp, cp, n = _path_args(clip)
         self._lib.vh_scene_push_clip_layer(self._h, int(clip_style), transform._ptr(), vp, cp, n)
 

@@ -351,3 +351,224 @@ def many_draw_objects_scene(n_wide=300, n_high=300):
         for i in range(n_wide):
             s.fill(Fill.NonZero, Affine.IDENTITY, yellow, None, Circle(((i + 0.5) * (2000.0 / n_wide), y), 3.0))
     return s, 2000, 1500
+
+
+def ref_stroke_styles_scene(transform=None):
+    """test_scenes.rs:335-511 without the labels (fonts) and the dashed column (kurbo::dash is host-side upstream): cap
+    combinations, cap x join combinations on a curved path, miter limits and closed paths, each under `transform`
+    (identity, Affine.scale_non_uniform(1.2, 0.7) and Affine.skew(1, 0) in the catalogue).  2450 x 1700."""
+    from vello_amd import Circle
+    transform = transform or Affine.IDENTITY
+    colors = [Color.from_rgb8(*c) for c in _COLORS]
+    simple = BezPath(); simple.move_to((0., 0.)); simple.line_to((100., 0.))
+    join_path = BezPath(); join_path.move_to((0., 0.))
+    join_path.curve_to((20., 0.), (42.5, 5.), (50., 25.)); join_path.curve_to((57.5, 5.), (80., 0.), (100., 0.))
+    miter = BezPath(); miter.move_to((0., 0.))
+    for p in [(90., 16.), (0., 31.), (90., 46.)]:
+        miter.line_to(p)
+    closed = BezPath()
+    closed.move_to((0., 0.)); closed.line_to((90., 21.)); closed.line_to((0., 42.)); closed.close_path()
+    closed.move_to((200., 0.)); closed.curve_to((100., 72.), (300., 72.), (200., 0.)); closed.close_path()
+    closed.move_to((290., 0.)); closed.curve_to((200., 72.), (400., 72.), (310., 0.)); closed.close_path()
+    caps = [Cap.Butt, Cap.Square, Cap.Round]
+    joins = [Join.Bevel, Join.Miter, Join.Round]
+    s = Scene()
+    ci = 0
+    t = Affine.translate(60., 40.) * Affine.scale(2.)
+    y = 0.
+    for start in caps:
+        for end in caps:
+            s.stroke(Stroke(20., start_cap=start, end_cap=end), Affine.translate(0., y + 30.) * t * transform, colors[ci], None, simple)
+            y += 180.
+            ci = (ci + 1) % 4
+    ci = (ci + 9) % 4  # the dashed column advances the colour cycle too
+    t = Affine.translate(550., 0.) * (Affine.translate(450., 0.) * t)
+    y = 0.
+    for cap in caps:
+        for join in joins:
+            s.stroke(Stroke(20., join=join, start_cap=cap, end_cap=cap), Affine.translate(0., y + 30.) * t * transform, colors[ci], None,
+                     join_path)
+            y += 185.
+            ci = (ci + 1) % 4
+    t = Affine.translate(500., 0.) * t
+    y = 0.
+    for ml in [4., 6., 0.1, 10.]:
+        s.stroke(Stroke(10., join=Join.Miter, miter_limit=ml, start_cap=Cap.Butt, end_cap=Cap.Butt), Affine.translate(0., y + 30.) * t * transform,
+                 colors[ci], None, miter)
+        y += 180.
+        ci = (ci + 1) % 4
+    for i, join in enumerate(joins):
+        s.stroke(Stroke(10., join=join, miter_limit=5., start_cap=caps[i], end_cap=caps[i]), Affine.translate(0., y + 30.) * t * transform,
+                 colors[ci], None, closed)
+        y += 180.
+        ci = (ci + 1) % 4
+    return s, 2450, 1700
+
+
+def two_point_radial_scene():
+    """test_scenes.rs:1045-1211: the COLR radial-gradient cases -- small-to-large, large-to-small, equal radii (strip),
+    offset focal circle, and circles touching on the outside (focal on circle) -- each under Pad / Repeat / Reflect, with
+    the two circles stroked on top (kurbo::Ellipse with equal radii = a circle).  1300 x 1120."""
+    import math
+    from vello_amd import Circle, Extend, Gradient
+    colors = [Color.from_rgb8(255, 0, 0), Color.from_rgb8(255, 255, 0), Color.from_rgb8(6, 85, 186)]
+    s = Scene()
+
+    def make(x0, y0, r0, x1, y1, r1, transform, extend):
+        rect = Rect(0.0, 0.0, 400.0, 200.0)
+        s.fill(Fill.NonZero, transform, Color.from_rgb8(255, 255, 255), None, rect)
+        g = Gradient.new_two_point_radial((x0, y0), np.float32(r0), (x1, y1), np.float32(r1)).with_stops(colors).with_extend(extend)
+        s.fill(Fill.NonZero, transform, g, None, rect)
+        s.stroke(Stroke(1.0), transform, Color.from_rgb8(0, 0, 0), None, Circle((x0, y0), float(np.float32(r0)) - 1.0))
+        s.stroke(Stroke(1.0), transform, Color.from_rgb8(0, 0, 0), None, Circle((x1, y1), float(np.float32(r1)) - 1.0))
+
+    modes = [Extend.Pad, Extend.Repeat, Extend.Reflect]
+    for i, mode in enumerate(modes):
+        make(140.0, 100.0, 20.0, 280.0, 100.0, 50.0, Affine.translate(i * 420.0 + 20.0, 20.0), mode)
+    for i, mode in enumerate(modes):
+        make(280.0, 100.0, 50.0, 140.0, 100.0, 20.0, Affine.translate(i * 420.0 + 20.0, 240.0), mode)
+    for i, mode in enumerate(modes):
+        make(140.0, 100.0, 50.0, 280.0, 100.0, 50.0, Affine.translate(i * 420.0 + 20.0, 460.0), mode)
+    for i, mode in enumerate(modes):
+        make(140.0, 125.0, 20.0, 190.0, 100.0, 95.0, Affine.translate(i * 420.0 + 20.0, 680.0), mode)
+    for i, mode in enumerate(modes):
+        x0, y0, r0, x1, y1, r1 = 140.0, 125.0, 20.0, 190.0, 100.0, 96.0
+        dx, dy = x0 - x1, y0 - y1
+        n = math.hypot(dx, dy)
+        make(x1 + dx / n * (r1 - r0), y1 + dy / n * (r1 - r0), r0, x1, y1, r1, Affine.translate(i * 420.0 + 20.0, 900.0), mode)
+    return s, 1300, 1120
+
+
+def conflation_artifacts_scene():
+    """test_scenes.rs:1444-1531: shapes whose shared edges conflate under area coverage -- two triangles of opposite
+    winding sharing a diagonal, and adjacent rectangles (opposite / same winding, even-odd) at a half-pixel offset.
+    300 x 700."""
+    N, S = 50.0, 4.0
+    scale = Affine.scale(S)
+    x, y = N + 0.5, N
+    bg, fg = Color.from_rgb8(255, 194, 19), Color.from_rgb8(12, 165, 255)
+    s = Scene()
+    p = BezPath()
+    p.move_to((0., 0.)); p.line_to((N, N)); p.line_to((0., N)); p.line_to((0., 0.))
+    p.move_to((0., 0.)); p.line_to((N, N)); p.line_to((N, 0.)); p.line_to((0., 0.))
+    s.fill(Fill.NonZero, Affine.translate(x, y) * scale, fg, None, p)
+    y += S * N + 10.0
+    s.fill(Fill.EvenOdd, Affine.translate(x, y) * scale, bg, None, Rect(0., 0., N, N))
+    p = BezPath()
+    p.move_to((0., 0.)); p.line_to((0., N)); p.line_to((N * 0.5, N)); p.line_to((N * 0.5, 0.))
+    p.move_to((N * 0.5, 0.)); p.line_to((N, 0.)); p.line_to((N, N)); p.line_to((N * 0.5, N))
+    s.fill(Fill.EvenOdd, Affine.translate(x, y) * scale, fg, None, p)
+    y += S * N + 10.0
+    s.fill(Fill.EvenOdd, Affine.translate(x, y) * scale, bg, None, Rect(0., 0., N, N))
+    p = BezPath()
+    p.move_to((0., 0.)); p.line_to((0., N)); p.line_to((N * 0.5, N)); p.line_to((N * 0.5, 0.))
+    p.move_to((N * 0.5, 0.)); p.line_to((N * 0.5, N)); p.line_to((N, N)); p.line_to((N, 0.))
+    s.fill(Fill.EvenOdd, Affine.translate(x, y) * scale, fg, None, p)
+    return s, 300, 700
+
+
+_LABYRINTH_ROWS = [
+    [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 1, 0, 1, 0, 1, 0, 0, 0, 0, 1, 1], [0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1],
+    [1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0], [0, 1, 1, 0, 0, 0, 0, 0, 0, 1, 1, 1], [1, 0, 0, 1, 0, 0, 0, 0, 1, 1, 1, 0],
+    [0, 1, 0, 1, 1, 1, 0, 0, 1, 1, 1, 0], [1, 0, 1, 0, 1, 1, 1, 1, 0, 1, 1, 1], [0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 1],
+    [0, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, 0], [1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1],
+]
+_LABYRINTH_COLS = [
+    [1, 1, 1, 1, 0, 1, 1, 1, 1, 1], [0, 0, 1, 0, 0, 0, 1, 1, 1, 0], [0, 1, 1, 0, 1, 1, 1, 0, 0, 1], [1, 1, 0, 0, 0, 0, 1, 0, 1, 0],
+    [0, 0, 1, 0, 1, 0, 0, 0, 0, 1], [0, 0, 1, 1, 1, 0, 0, 0, 1, 0], [0, 1, 0, 1, 1, 1, 0, 0, 0, 0], [1, 1, 1, 0, 1, 1, 1, 0, 1, 0],
+    [1, 1, 0, 1, 1, 0, 0, 0, 1, 0], [0, 0, 1, 0, 0, 0, 0, 0, 0, 1], [0, 0, 1, 1, 0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 0, 1, 0, 0, 1],
+    [1, 1, 1, 1, 1, 1, 0, 1, 1, 1],
+]
+
+
+def labyrinth_scene():
+    """test_scenes.rs:1533-1608: ONE non-zero path of 140-odd thin overlapping rectangles (wall segments 0.2 wide on a
+    unit grid, scaled by 80 at a half-pixel offset): many sub-paths whose edges coincide and overlap.  1000 x 850."""
+    p = BezPath()
+    for y, row in enumerate(_LABYRINTH_ROWS):
+        for x, flag in enumerate(row):
+            if flag:
+                p.move_to((x - 0.1, y + 0.1)); p.line_to((x + 1.1, y + 0.1)); p.line_to((x + 1.1, y - 0.1)); p.line_to((x - 0.1, y - 0.1))
+    for x, col in enumerate(_LABYRINTH_COLS):
+        for y, flag in enumerate(col):
+            if flag:
+                p.move_to((x - 0.1, y - 0.1)); p.line_to((x - 0.1, y + 1.1)); p.line_to((x + 0.1, y + 1.1)); p.line_to((x + 0.1, y - 0.1))
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.translate(20.5, 20.5) * Affine.scale(80.0), Color.from_rgb8(0x70, 0x80, 0x80), None, p)
+    return s, 1000, 850
+
+
+def _pentagram(cx, cy, r):
+    import math
+    pts = [(cx + math.cos(-math.pi / 2 + i * 2 * math.pi / 5) * r, cy + math.sin(-math.pi / 2 + i * 2 * math.pi / 5) * r) for i in range(5)]
+    p = BezPath()
+    p.move_to(pts[0])
+    for i in (2, 4, 1, 3):
+        p.line_to(pts[i])
+    p.close_path()
+    return p
+
+
+def clip_test_scene():
+    """test_scenes.rs:1708-1911 without the clipped text (fonts) and the dashed-stroke clip (kurbo::dash): an even-odd
+    clip layer of a self-intersecting star, a clip layer whose style is a STROKE (clip to the stroked outline) over a
+    gradient, and the blend layer whose clip rect cuts two of its three fills (the issue #1198 transform values).
+    500 x 900."""
+    from vello_amd import BlendMode, Compose, Gradient, Mix
+    s = Scene()
+    demo = Rect(250.0, 20.0, 450.0, 220.0)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(0, 0, 255), None, demo)
+    s.push_clip_layer(Fill.EvenOdd, Affine.IDENTITY, _pentagram(350.0, 120.0, 90.0))
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, demo)
+    s.pop_layer()
+    demo = Rect(250.0, 240.0, 450.0, 440.0)
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(112, 128, 144), None, demo)
+    s.push_clip_layer(Stroke(18.0, join=Join.Round, start_cap=Cap.Round, end_cap=Cap.Round), Affine.IDENTITY, _pentagram(350.0, 340.0, 85.0))
+    g = Gradient.new_linear((250.0, 240.0), (450.0, 440.0)).with_stops([Color.from_rgb8(255, 0, 255), Color.from_rgb8(0, 255, 255)])
+    s.fill(Fill.NonZero, Affine.IDENTITY, g, None, demo)
+    s.pop_layer()
+    scale = 2.0
+    s.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.SrcOver), 1.0, Affine([scale, 0.0, 0.0, scale, 27.07470703125, 176.40660533027858]),
+                 Rect(0.0, 0.0, 74.4, 339.20000000000005))
+    s.fill(Fill.NonZero, Affine([scale, 0.0, 0.0, scale, 27.07470703125, 176.40660533027858]), Color.from_rgb8(0, 0, 255), None,
+           Rect(-1000.0, -1000.0, 2000.0, 2000.0))
+    s.fill(Fill.NonZero, Affine([scale, 0.0, 0.0, scale, 29.027636718750003, 182.9755506427786]), Color.from_rgb8(0, 255, 0), None,
+           Rect(11.0, 13.399999999999999, 59.0, 56.6))
+    s.fill(Fill.NonZero, Affine([scale, 0.0, 0.0, scale, 29.027636718750003, scale * 559.3583631427786]), Color.from_rgb8(255, 0, 0), None,
+           Rect(12.599999999999998, 12.599999999999998, 57.400000000000006, 57.400000000000006))
+    s.pop_layer()
+    return s, 500, 900
+
+
+def luminance_mask_scene():
+    """test_scenes.rs:2214-2289 (the MDN mask-type example): red under a luminance-mask layer holding a dark translucent
+    square and a light translucent circle, inside a src-over layer over white.  55 x 55."""
+    from vello_amd import BlendMode, Circle, Compose, Mix
+    s = Scene()
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(255, 255, 255), None, Rect(0., 0., 60., 60.))
+    box = Rect(5., 5., 50., 50.)
+    s.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.SrcOver), 1.0, Affine.IDENTITY, box)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, box)
+    s.push_luminance_mask_layer(Fill.NonZero, 1.0, Affine.IDENTITY, box)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color(0.1, 0.1, 0.1, 0.4), None, box)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color(0.9, 0.9, 0.9, 0.6), None, Circle((0., 55.), 35.))
+    s.pop_layer()
+    s.pop_layer()
+    return s, 55, 55
+
+
+def image_extend_modes_scene(quality=None):
+    """test_scenes.rs:2168-2212: the 2x2 sample image as the brush of a 6x6 rect magnified 100x, brush offset (2, 2),
+    under Pad, Reflect, Repeat and mixed x-Repeat / y-Reflect; bilinear or nearest.  1500 x 1500 on white."""
+    from vello_amd import Extend, ImageBrush, ImageData, ImageQuality
+    quality = ImageQuality.Medium if quality is None else quality
+    px = np.zeros((2, 2, 4), dtype=np.uint8)
+    px[0, 0], px[0, 1], px[1, 0], px[1, 1] = _rgba(255, 0, 0, 255), _rgba(0, 0, 255, 255), _rgba(0, 255, 255, 255), _rgba(255, 0, 255, 255)
+    image = ImageData(px)
+    off = Affine.translate(2., 2.)
+    rect = Rect(0., 0., 6., 6.)
+    s = Scene()
+    for (xe, ye), (tx, ty) in [((Extend.Pad, Extend.Pad), (100., 100.)), ((Extend.Reflect, Extend.Reflect), (100., 800.)),
+                               ((Extend.Repeat, Extend.Repeat), (800., 100.)), ((Extend.Repeat, Extend.Reflect), (800., 800.))]:
+        s.fill(Fill.NonZero, Affine.scale(100.).then_translate(tx, ty), ImageBrush(image, xe, ye, quality), off, rect)
+    return s, 1500, 1500
