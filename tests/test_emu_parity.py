@@ -267,6 +267,36 @@ def test_emu_reference_catalogue_second_batch(emu_engine, which):
                       resolved=r)
 
 
+def test_emu_image_atlas_residency_sequence(emu_engine):
+    # resolve.rs:507-541 / image_cache.rs end to end: a 32-texel atlas that has to evict, repack and grow while frames keep
+    # sampling it; after every resolve the frame must equal the oracle's rendering of the same atlas state
+    import vello_amd
+    from vello_amd import Affine, ImageBrush, ImageData, ImageQuality, Scene
+
+    def img(w, h, seed):
+        rng = np.random.default_rng(seed)
+        px = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        px[:, :, 3] = 255
+        return ImageData(px)
+
+    def scene_of(images):
+        s = Scene()
+        for k, im in enumerate(images):
+            s.draw_image(ImageBrush(im, quality=ImageQuality.Low), Affine.translate(4.0 + 34.0 * k, 4.0) * Affine.scale(2.0))
+        return s
+
+    res = vello_amd.Resolver(atlas_sizes=(32, 64))
+    a, b, c, d = img(16, 16, 1), img(16, 16, 2), img(16, 16, 3), img(32, 16, 4)
+    frames = [[a, b], [a, b, c], [c], [c], [c], [c, d, a], [a, b, c, d, img(32, 32, 5)]]
+    seen_evict = seen_grow = False
+    for i, images in enumerate(frames):
+        r = res.resolve(scene_of(images))
+        seen_evict |= r.evicted > 0
+        seen_grow |= r.atlas_size > 32
+        compare_frame(emu_engine, r.packed, r.layout, 200, 80, WHITE, AaConfig.Area, f"emu_residency_{i}", tol=1, resolved=r)
+    assert seen_evict and seen_grow
+
+
 def test_emu_auto_grow_covers_large_targets(built):
     # the PTCL pool holds a fixed 64 words per tile: a target with more tiles than the pool was sized for is an
     # E_INVALID configuration error, unless robust mode may grow the pool
