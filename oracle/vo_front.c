@@ -108,9 +108,6 @@ static uint32_t alloc_lines(flat_state *s, uint32_t n) {
     s->bump->lines += n;
     return ix;
 }
-static void output_line(flat_state *s, uint32_t path_ix, vec2 p0, vec2 p1) {
-    write_line(s, alloc_lines(s, 1), path_ix, p0, p1);
-}
 static void output_line_xf(flat_state *s, uint32_t path_ix, vec2 p0, vec2 p1, const vo_xform *t) {
     write_line_xf(s, alloc_lines(s, 1), path_ix, p0, p1, t);
 }

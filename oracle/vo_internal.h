@@ -187,7 +187,7 @@ static inline vec2 vnorm(vec2 a) { float l = vlen(a); return v2(a.x / l, a.y / l
 typedef struct { float m[4]; float t[2]; } vo_xform;
 static inline vo_xform vo_read_transform(const uint32_t *scene, uint32_t base, uint32_t ix) {
     vo_xform r;
-    const uint32_t *p = scene + base + ix * 6u;
+    const uint32_t *p = scene + (uint32_t)(base + ix * 6u); /* u32 index arithmetic, as WGSL: trans_ix may be 0 - 1 */
     for (int i = 0; i < 4; i++) r.m[i] = bits2f(p[i]);
     r.t[0] = bits2f(p[4]);
     r.t[1] = bits2f(p[5]);

@@ -428,6 +428,43 @@ def test_image_atlas_residency_sequence(gpu_engine):
     assert seen_evict and seen_grow
 
 
+def test_fuzz_whole_api(gpu_engine):
+    # workloads/fuzz.py: seeded random scenes over the whole scene API (every brush kind with degenerate parameters, all
+    # mix / compose modes, luminance masks, fill- and stroke-styled clips, zero / hairline / huge stroke widths, skewed,
+    # mirrored and near-singular affines, repeated points, geometry far off screen and on tile corners)
+    import vello_amd
+    from workloads.fuzz import fuzz_scene
+
+    gpu_engine.set_auto_grow(True)
+    try:
+        for seed in range(0, 300):
+            r = vello_amd.Resolver().resolve(fuzz_scene(seed))
+            aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
+            base = [0xFF000000, 0xFFFFFFFF, 0x00000000, 0x80FF8040][seed % 4]
+            compare_frame(gpu_engine, r.packed, r.layout, 128, 128, base, aa, f"gpu_fuzz_{seed}", tol=1 if aa == AaConfig.Area else 0, resolved=r,
+                          order_sensitive=True)
+    finally:
+        gpu_engine.set_auto_grow(False)
+
+
+def test_zero_width_stroke_clip_before_any_transform(gpu_engine):
+    # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
+    # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
+    # transform_base); pointer arithmetic in two steps lands 24 GB away (found by the fuzzer, seed 80).
+    import vello_amd
+    from vello_amd import Affine, Circle, Color, Fill, Rect, Scene, Stroke
+
+    s = Scene()
+    s.push_clip_layer(Stroke(0.0), Affine.IDENTITY, Circle((40.0, 40.0), 20.0))
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(0, 255, 0), None, Rect(0.0, 0.0, 80.0, 80.0))
+    s.pop_layer()
+    s.fill(Fill.NonZero, Affine.translate(3.0, 4.0), Color.from_rgb8(255, 0, 0), None, Rect(10.0, 10.0, 30.0, 30.0))
+    r = vello_amd.Resolver().resolve(s)
+    img, _, _ = compare_frame(gpu_engine, r.packed, r.layout, 80, 80, BLACK, AaConfig.Msaa8, "gpu_zero_width_clip_first", resolved=r)
+    assert (img[:, :, 1] == 0).all(), "the zero-width stroke clip suppresses everything inside the layer"
+    assert tuple(img[20, 20]) == (255, 0, 0, 255)
+
+
 def test_large_target_with_auto_grow(built):
     # 6000 x 6000 = 140 625 tiles x 64 PTCL words: past the fixed 2^23-word pool; robust mode sizes the pool for the target
     import vello_amd

@@ -162,8 +162,11 @@ __device__ __forceinline__ vec2 normalize(vec2 a) {
 struct Xform {
     float m0, m1, m2, m3, t0, t1;
 };
+// The index is u32 arithmetic as in WGSL (flatten.wgsl:306-316): a path encoded before any transform (the zero-width
+// stroke clip of scene.rs:179-183 at the start of a scene) has trans_ix = 0 - 1 and reads the six words below
+// transform_base, inside the scene buffer, instead of 24 GB past it.
 __device__ __forceinline__ Xform read_transform(const uint32_t *scene, uint32_t base, uint32_t ix) {
-    const uint32_t *p = scene + base + ix * 6u;
+    const uint32_t *p = scene + (uint32_t)(base + ix * 6u);
     return Xform{__uint_as_float(p[0]), __uint_as_float(p[1]), __uint_as_float(p[2]),
                  __uint_as_float(p[3]), __uint_as_float(p[4]), __uint_as_float(p[5])};
 }
