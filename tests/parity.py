@@ -23,6 +23,17 @@ def sorted_rows(a, ncol):
     return a[order]
 
 
+def canonical_nan_lines(words):
+    """LineSoup rows (u32 x 6) with every NaN coordinate replaced by ONE quiet-NaN pattern: which sign / payload a NaN
+    carries out of an arithmetic operation is implementation-defined (x86 and gfx950 differ), and a NaN line is a NaN
+    line -- it crosses no tile (scenes reach this only through garbage transforms, e.g. a path encoded before any
+    transform exists)."""
+    w = np.ascontiguousarray(words).reshape(-1, 6).copy()
+    f = w[:, 2:]
+    f[((f & 0x7F800000) == 0x7F800000) & ((f & 0x007FFFFF) != 0)] = 0x7FC00000
+    return w
+
+
 def fine_on_engine_inputs(engine, oracle, width, height, used_words):
     """The oracle's fine stage run on the ENGINE's fine inputs (segments in the engine's order, its PTCL, tiles and
     draw info): isolates fine from the one nondeterminism of the path, the order atomics give the segments of a tile
@@ -81,8 +92,8 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
             _dump(name + "_path_bboxes", hip=pb_h, oracle=pb_o)
         assert np.array_equal(pb_h, pb_o), f"{name}: path_bboxes differ"
         n_lines = ob["lines"]
-        ln_h = sorted_rows(engine.read_buffer("lines", np.uint32, n_lines * 24), 6)
-        ln_o = sorted_rows(oracle.buffer("lines", np.uint32)[: n_lines * 6], 6)
+        ln_h = sorted_rows(canonical_nan_lines(engine.read_buffer("lines", np.uint32, n_lines * 24)), 6)
+        ln_o = sorted_rows(canonical_nan_lines(oracle.buffer("lines", np.uint32)[: n_lines * 6]), 6)
         if not np.array_equal(ln_h, ln_o):
             _dump(name + "_lines", hip=ln_h, oracle=ln_o)
         assert np.array_equal(ln_h, ln_o), f"{name}: line soup differs as a multiset ({(ln_h != ln_o).any(axis=1).sum()} rows)"
