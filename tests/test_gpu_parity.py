@@ -447,6 +447,25 @@ def test_fuzz_whole_api(gpu_engine):
         gpu_engine.set_auto_grow(False)
 
 
+def test_fuzz_target_sizes_and_long_scenes(gpu_engine):
+    # the same generator at awkward target sizes (one pixel, one tile, not multiples of 16, several bins) and with up to
+    # 700 operations per scene (several 256-draw batches per bin in coarse)
+    import vello_amd
+    from workloads.fuzz import fuzz_scene
+
+    gpu_engine.set_auto_grow(True)
+    try:
+        for seed in range(0, 150):
+            w, h = [(333, 205), (97, 530), (512, 512), (16, 16), (1, 1), (700, 40)][seed % 6]
+            r = vello_amd.Resolver().resolve(fuzz_scene(seed, size=max(w, h, 8), n_ops=[40, 700, 300][seed % 3]))
+            aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][(seed // 2) % 3]
+            base = [0xFF000000, 0xFFFFFFFF, 0x00000000, 0x80FF8040][seed % 4]
+            compare_frame(gpu_engine, r.packed, r.layout, w, h, base, aa, f"gpu_fuzz2_{seed}", tol=1 if aa == AaConfig.Area else 0, resolved=r,
+                          order_sensitive=True)
+    finally:
+        gpu_engine.set_auto_grow(False)
+
+
 def test_zero_width_stroke_clip_before_any_transform(gpu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
