@@ -466,6 +466,24 @@ def test_fuzz_target_sizes_and_long_scenes(gpu_engine):
         gpu_engine.set_auto_grow(False)
 
 
+def test_fuzz_auto_grow_from_tiny_pools(built):
+    # robust dynamic memory under fuzz: every pool starts at 64 elements, auto-grow has to find the frame's
+    # demand stage by stage (a failed stage hides the demand of the later ones) and the final frame must equal the oracle's
+    import vello_amd
+    from workloads.fuzz import fuzz_scene
+
+    for seed in range(0, 40):
+        eng = vello_amd.Engine(capacities={"lines": 64, "binning": 64, "tile": 64, "seg_counts": 64, "segments": 64, "blend": 16,
+                                           "ptcl": 64 * 4 + 64})
+        eng.set_auto_grow(True)
+        w, h = [(128, 128), (300, 200), (64, 64)][seed % 3]
+        r = vello_amd.Resolver().resolve(fuzz_scene(seed, size=max(w, h), n_ops=[40, 300][seed % 2]))
+        aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][(seed // 2) % 3]
+        compare_frame(eng, r.packed, r.layout, w, h, 0xFF203040, aa, f"gpu_fuzz3_{seed}", tol=1 if aa == AaConfig.Area else 0, resolved=r,
+                      order_sensitive=True)
+        del eng
+
+
 def test_zero_width_stroke_clip_before_any_transform(gpu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
