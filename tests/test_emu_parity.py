@@ -358,6 +358,39 @@ def test_emu_fuzz_auto_grow_from_tiny_pools(built):
         L._use_library(None)
 
 
+def test_emu_inconsistent_scenes_are_refused(emu_engine):
+    # A packed scene whose streams contradict each other (WebGPU's robust buffer access absorbs this upstream; HIP has
+    # none, so the engine has to refuse it -- never read or write outside its buffers -- and stay usable afterwards)
+    import vello_amd
+
+    good_packed, layout = workloads.stroke_styles_scene().resolve()
+    n_tag_bytes = (layout.path_data_base - layout.path_tag_base) * 4
+
+    def corrupt_tags(byte):
+        p = good_packed.copy()
+        p[layout.path_tag_base * 4: layout.path_tag_base * 4 + n_tag_bytes] = byte
+        return p
+
+    def corrupt_draw_tags(word):
+        p = good_packed.copy()
+        p.view(np.uint32)[layout.draw_tag_base: layout.draw_tag_base + layout.n_draw_objects] = word
+        return p
+
+    cases = {
+        "every tag a f32 cubic: more path data than the stream holds": (corrupt_tags(0x0B), layout),
+        "every tag a TRANSFORM marker": (corrupt_tags(0x20), layout),
+        "every tag a STYLE marker": (corrupt_tags(0x40), layout),
+        "every draw object a radial gradient: more draw data / info than the layout holds": (corrupt_draw_tags(0x29C), layout),
+        "clip tags without clips in the layout": (corrupt_draw_tags(0x49), layout),
+        "more draw objects than paths": (good_packed, layout._replace(n_draw_objects=layout.n_paths + 5)),
+    }
+    for what, (packed, lay) in cases.items():
+        with pytest.raises(vello_amd.VelloHipError):
+            emu_engine.render(packed, lay, 256, 256, WHITE, AaConfig.Msaa8)
+        # the context is not poisoned: the next (valid) frame is right
+        compare_frame(emu_engine, good_packed, layout, 256, 256, WHITE, AaConfig.Msaa8, "emu_invalid_after_" + what.split(":")[0].replace(" ", "_"))
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below

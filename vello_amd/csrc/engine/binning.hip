@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) k_tile_alloc(Config cfg, const uint32_t *
     __shared__ uint32_t sh_offset;
     __shared__ uint32_t sh_fill;
     const uint32_t tid = threadIdx.x;
-    if ((bump->failed & (STAGE_BINNING | STAGE_FLATTEN)) != 0u) return;
+    if ((bump->failed & (STAGE_BINNING | STAGE_FLATTEN | FAILED_SCENE)) != 0u) return;
     const float SX = 1.0f / (float)TILE_WIDTH, SY = 1.0f / (float)TILE_HEIGHT;
     const uint32_t drawobj_ix = blockIdx.x * 256u + tid;
     uint32_t drawtag = DRAWTAG_NOP;

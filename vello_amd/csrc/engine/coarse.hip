@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     __shared__ uint32_t sh_seg_base, sh_chunk_base;
     const uint32_t tid = threadIdx.x;
     {  // coarse.wgsl:161-176
-        uint32_t failed = bump->failed & (STAGE_BINNING | STAGE_TILE_ALLOC | STAGE_FLATTEN);
+        uint32_t failed = bump->failed & (STAGE_BINNING | STAGE_TILE_ALLOC | STAGE_FLATTEN | FAILED_SCENE);
         if (bump->seg_counts > cfg.seg_counts_size) failed |= STAGE_PATH_COUNT;
         if (failed != 0u) {
             if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicOr(&bump->failed, failed);

@@ -20,6 +20,10 @@ constexpr uint32_t PATH_COUNT_CHUNK = 256 * PATH_COUNT_LINES_PER_THREAD;
 // or finished; the bound only turns a driver-level hang into a reported failure.
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
 constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a spin bound trips
+// set in bump.failed by the pathtag scan when the tag stream asks for more path data, transforms, styles or paths
+// than the scene buffer / layout hold (WebGPU's robust buffer access makes this harmless upstream; HIP has none):
+// every later stage that would index with those counts bails out, the frame reports VELLO_HIP_E_INVALID
+constexpr uint32_t FAILED_SCENE = 0x40000000u;
 
 // Words of the per-frame control block (zeroed by ONE hipMemsetAsync per frame, together with
 // the bump allocators and both look-back state arrays which follow it in the same allocation).
@@ -35,6 +39,7 @@ static_assert(sizeof(Control) == 64, "Control");
 struct Frame {
     Config cfg;  // host copy; kernels receive it by value
     uint32_t n_tag_words;
+    uint32_t n_scene_words;  // length of the packed scene
     uint32_t aa;
     // device pointers
     const uint32_t *scene;

@@ -237,6 +237,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
     if (upload_cfg) HIP_TRY(c, hipMemcpy(c->config.ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
     f.n_tag_words = sc.n_tag_words;
+    f.n_scene_words = (uint32_t)(sc.scene_len / 4u);
     f.aa = p->aa;
     f.scene = (const uint32_t *)sc.scene.ptr;
     f.control = (Control *)l.zero_region.ptr;
@@ -514,13 +515,22 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
     sc.brushes = false;
     {
+        // The same pass checks what draw_leaf / clip_leaf will index with (shared/drawtag.wgsl:47-54: bit 0 = clip,
+        // bits 2-4 = draw data words, bits 6-9 = info words).  WebGPU's robust buffer access absorbs an inconsistent
+        // stream upstream; here it must be refused.  (The path tag stream is checked by the pathtag scan, on the GPU.)
         const uint32_t *words_p = reinterpret_cast<const uint32_t *>(scene);
+        uint64_t draw_data_words = 0, info_words = 0, clip_tags = 0;
         for (uint32_t i = 0; i < L.n_draw_objects; i++) {
             uint32_t t = words_p[L.draw_tag_base + i];
-            if (t != DRAWTAG_FILL_COLOR && t != DRAWTAG_BEGIN_CLIP && t != DRAWTAG_END_CLIP && t != DRAWTAG_NOP) {
-                sc.brushes = true;
-                break;
-            }
+            if (t != DRAWTAG_FILL_COLOR && t != DRAWTAG_BEGIN_CLIP && t != DRAWTAG_END_CLIP && t != DRAWTAG_NOP) sc.brushes = true;
+            clip_tags += t & 1u;
+            draw_data_words += (t >> 2) & 0x7u;
+            info_words += (t >> 6) & 0xfu;
+        }
+        if (draw_data_words > (uint64_t)(L.transform_base - L.draw_data_base) || info_words > L.bin_data_start || clip_tags > L.n_clips ||
+            L.n_draw_objects > L.n_paths) {
+            c->last_error = "draw tags need more draw data / info words / clips / paths than the layout provides";
+            return VELLO_HIP_E_INVALID;
         }
     }
     if (scene_len) HIP_TRY(c, hipMemcpyAsync(sc.scene.ptr, scene, scene_len, hipMemcpyHostToDevice, st));
@@ -657,6 +667,10 @@ int vello_hip_sync(vello_hip_ctx *c) {
         if (!l.used || !l.zero_region.ptr) continue;
         vello_hip_bump b;
         HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
+        if ((b.failed & FAILED_SCENE) != 0u) {
+            c->last_error = "the path tag stream needs more path data, transforms or styles than the scene buffer holds";
+            return VELLO_HIP_E_INVALID;
+        }
         if (b.failed != 0u) {
             char msg[160];
             std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,

@@ -701,7 +701,7 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
     {
-        if (is_path) {
+        if (is_path && path_ix < cfg.layout.n_paths) {  // a PATH marker per unclosed layer follows the last path (resolve.rs:127-129)
             path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
             path_bboxes[path_ix].trans_ix = trans_ix;
         }
@@ -810,7 +810,7 @@ __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config 
     uint32_t style_ix = tag.monoid.style_ix;
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
-    if (is_path) {
+    if (is_path && path_ix < cfg.layout.n_paths) {  // a PATH marker per unclosed layer follows the last path (resolve.rs:127-129)
         path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
         path_bboxes[path_ix].trans_ix = trans_ix;
     }
@@ -841,6 +841,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
     // a path are of one kind, so waves stay convergent and segment reads coalesce.
     const uint32_t tag0 = blockIdx.x * FLATTEN_BLOCK_TAGS + tid;
+    if ((control->bump.failed & FAILED_SCENE) != 0u) return;  // the tag stream overruns the scene: nothing may be indexed with it
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
@@ -900,7 +901,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     const uint32_t tid = threadIdx.x;
     // final counts: written by the previous kernel on this stream
     const uint32_t n_curves = control->heavy_count[0], n_heavy = n_curves + control->heavy_count[1];
-    if (blockIdx.x * 256u >= n_heavy) return;
+    if (blockIdx.x * 256u >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;

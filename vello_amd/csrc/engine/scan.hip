@@ -24,7 +24,7 @@ __device__ __forceinline__ TagMonoid reduce_tag(uint32_t tag_word) {
     return c;
 }
 
-__global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag_words, const uint32_t *__restrict__ scene,
+__global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag_words, uint32_t n_scene_words, const uint32_t *__restrict__ scene,
                                                       Control *control, unsigned long long *state,
                                                       TagMonoid *__restrict__ tag_monoids, PathBbox *__restrict__ path_bboxes) {
     __shared__ uint32_t sh_part;
@@ -38,6 +38,10 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
         path_bboxes[i].y0 = 0x7fffffff;
         path_bboxes[i].x1 = (int32_t)0x80000000;
         path_bboxes[i].y1 = (int32_t)0x80000000;
+        // flatten writes these at the path's PATH marker; defined values keep draw_leaf's transform read inside the
+        // scene when flatten is skipped (FAILED_SCENE)
+        path_bboxes[i].draw_flags = 0u;
+        path_bboxes[i].trans_ix = 0u;
     }
 
     if (tid == 0) sh_part = atomicAdd(&control->ticket_pathtag, 1u);
@@ -81,6 +85,18 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
         if (lane == 0) {
 #pragma unroll
             for (int f = 0; f < 5; f++) sh_excl[f] = excl[f];
+            // The last partition holds the totals of the whole tag stream: what flatten is going to index with.
+            if (part == gridDim.x - 1u) {
+                const Layout &L = cfg.layout;
+                const uint32_t n_trans = excl[0] + block_agg[0], pathseg_words = excl[2] + block_agg[2];
+                const uint32_t style_words = excl[3] + block_agg[3];
+                // (PATH markers beyond n_paths are legal -- resolve.rs:127-129 appends one per unclosed layer without
+                // counting it -- and flatten guards its per-path stores instead)
+                const bool ok = (uint64_t)n_trans * 6u <= (uint64_t)(L.style_base - L.transform_base) &&
+                                pathseg_words <= L.draw_tag_base - L.path_data_base &&
+                                (uint64_t)L.style_base + style_words <= n_scene_words;
+                if (!ok) atomicOr(&control->bump.failed, FAILED_SCENE);
+            }
         }
     }
     __syncthreads();
@@ -104,7 +120,7 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
 void launch_pathtag_scan(const Frame &f, hipStream_t s) {
     uint32_t n_parts = (f.n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
     if (n_parts == 0) n_parts = 1;
-    hipLaunchKernelGGL(k_pathtag_scan, dim3(n_parts), dim3(256), 0, s, f.cfg, f.n_tag_words, f.scene, f.control,
+    hipLaunchKernelGGL(k_pathtag_scan, dim3(n_parts), dim3(256), 0, s, f.cfg, f.n_tag_words, f.n_scene_words, f.scene, f.control,
                        f.pathtag_state, f.tag_monoids, f.path_bboxes);
 }
 
