@@ -78,7 +78,12 @@ typedef struct vello_hip_capacities {
  * vello_hip_sync / vello_hip_render with the counters available through vello_hip_get_bump. */
 enum {
     VELLO_HIP_OK = 0,
-    VELLO_HIP_E_INVALID = -1,   /* bad argument / AA mode not enabled at create (render.rs:566-598 panics) */
+    VELLO_HIP_E_INVALID = -1,   /* bad argument / AA mode not enabled at create (render.rs:566-598 panics) / a packed scene
+                                 * whose streams contradict each other: draw tags that need more draw data, info words,
+                                 * clips or paths than the layout provides (refused at upload), or path tags that need more
+                                 * path data, transforms or styles than the scene holds (found by the pathtag scan; the
+                                 * target is left untouched and vello_hip_render / vello_hip_sync report it).  WebGPU's
+                                 * robust buffer access absorbs such scenes upstream; HIP has none, so they are refused. */
     VELLO_HIP_E_HIP = -2,       /* HIP runtime error; see vello_hip_last_error */
     VELLO_HIP_E_NO_DEVICE = -3, /* no gfx950 device / kernels missing: never falls back to a CPU path */
     VELLO_HIP_E_CAPACITY = -4   /* bump.failed != 0 */
