@@ -294,7 +294,7 @@ def main():
         o = Oracle()
         o.set_scene(packed, layout, WIDTH, HEIGHT, BASE_COLOR, int(aa))
         o.render()  # warm
-        n_cpu = 3
+        n_cpu = 12  # ~10 s of single-thread CPU work + ~3 s with the fine stage threaded
         t0 = time.perf_counter()
         for _ in range(n_cpu):
             ref = o.render()
