@@ -391,6 +391,44 @@ def test_emu_inconsistent_scenes_are_refused(emu_engine):
         compare_frame(emu_engine, good_packed, layout, 256, 256, WHITE, AaConfig.Msaa8, "emu_invalid_after_" + what.split(":")[0].replace(" ", "_"))
 
 
+def test_emu_thousands_of_segments_in_one_tile(emu_engine):
+    # fills and hairline strokes of 70 ... 2000 random segments crammed into a couple of tiles: the > 64-segment and
+    # > 512-crossing paths of fine's MSAA (segment batches, record overflow) and counters far beyond one byte per sample
+    import math
+
+    from vello_amd import Affine, BezPath, Color, Fill, Scene, Stroke
+
+    rng = np.random.default_rng(7)
+    emu_engine.set_auto_grow(True)
+    try:
+        for case in range(6):
+            s = Scene()
+            for _ in range(int(rng.integers(1, 6))):
+                p = BezPath()
+                cx, cy = rng.uniform(4, 28, 2)
+                p.move_to((cx, cy))
+                for _ in range(int(rng.choice([70, 130, 600, 2000]))):
+                    a, r = rng.uniform(0, 2 * math.pi), rng.uniform(0.2, 9.0)
+                    end = (cx + r * math.cos(a), cy + r * math.sin(a))
+                    if rng.random() < 0.7:
+                        p.line_to(end)
+                    else:
+                        b = rng.uniform(0, 2 * math.pi)
+                        p.quad_to((cx + r * math.cos(b), cy + r * math.sin(b)), end)
+                p.close_path()
+                col = Color(float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.choice([1.0, 0.5])))
+                if rng.random() < 0.3:
+                    s.stroke(Stroke(float(rng.uniform(0.05, 0.6))), Affine.IDENTITY, col, None, p)
+                else:
+                    s.fill(Fill(int(rng.integers(0, 2))), Affine.IDENTITY, col, None, p)
+            packed, layout = s.resolve()
+            for aa in (AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16):
+                compare_frame(emu_engine, packed, layout, 48, 48, 0xFF101010, aa, f"emu_dense_{case}_{int(aa)}",
+                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True)
+    finally:
+        emu_engine.set_auto_grow(False)
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
