@@ -429,6 +429,39 @@ def test_emu_thousands_of_segments_in_one_tile(emu_engine):
         emu_engine.set_auto_grow(False)
 
 
+@pytest.mark.parametrize("kind", ["clip", "blend"])
+def test_emu_layers_nested_300_deep(emu_engine, kind):
+    # clip_leaf's stack beyond its LDS window (spill), fine's blend stack far beyond BLEND_STACK_SPLIT, the blend spill pool
+    # grown past the reference's 2^20 entries by auto-grow
+    from oracle.oracle import Oracle
+    from vello_amd import Affine, BlendMode, Circle, Color, Compose, Fill, Mix, Rect, Scene
+
+    depth = 300
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(30, 60, 200), None, Rect(0, 0, 96, 96))
+    for d in range(depth):
+        shape = Rect(0.01 * d, 0.02 * d, 96 - 0.01 * d, 96 - 0.015 * d) if d % 3 else Circle((48, 48), 60 - 0.01 * d)
+        if kind == "clip":
+            s.push_clip_layer(Fill.NonZero, Affine.IDENTITY, shape)
+        else:
+            s.push_layer(Fill.NonZero, BlendMode(Mix(d % 16), Compose.SrcOver), 0.97, Affine.IDENTITY, shape)
+        if d % 50 == 0:
+            s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgba8(255, 200, (d * 7) % 255, 120), None,
+                   Circle((20 + d % 60, 30 + (d // 7) % 40), 14))
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(250, 250, 20), None, Circle((48, 48), 30))
+    for _ in range(depth):
+        s.pop_layer()
+    packed, layout = s.resolve()
+    emu_engine.set_auto_grow(True)
+    try:
+        for aa in (AaConfig.Area, AaConfig.Msaa16):
+            _, _, bump = compare_frame(emu_engine, packed, layout, 96, 96, BLACK, aa, f"emu_deep_{kind}_{int(aa)}",
+                                       tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, oracle=Oracle(capacity_scale=16))
+        assert bump["blend"] > (1 << 20)
+    finally:
+        emu_engine.set_auto_grow(False)
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
