@@ -252,7 +252,7 @@ void vo_stage_path_count(vo_ctx *c) {
         ymax = imin(ymax, bbox[3]);
         for (int32_t y = ymin; y < ymax; y++) {
             int32_t base = (int32_t)path.tiles + (y - bbox[1]) * stride;
-            tile[base].backdrop += delta;
+            if ((uint32_t)base < cfg->tiles_size) tile[base].backdrop += delta; /* robust access: an out-of-range store is dropped */
         }
         float last_z = floorf(a * ((float)imin_ - 1.0f) + b);
         uint32_t seg_base = bump->seg_counts;
@@ -266,10 +266,13 @@ void vo_stage_path_count(vo_ctx *c) {
             int top_edge = (i == 0u) ? (y0 == s0.y) : (last_z == z);
             if (top_edge && x + 1 < bbox[2]) {
                 int32_t x_bump = imax(x + 1, bbox[0]);
-                tile[base + x_bump].backdrop += delta;
+                if ((uint32_t)(base + x_bump) < cfg->tiles_size) tile[base + x_bump].backdrop += delta;
             }
-            uint32_t seg_within_slice = tile[base + x].segment_count_or_ix;
-            tile[base + x].segment_count_or_ix += 1u;
+            uint32_t seg_within_slice = 0u; /* robust access: an out-of-range atomic returns 0 and stores nothing */
+            if ((uint32_t)(base + x) < cfg->tiles_size) {
+                seg_within_slice = tile[base + x].segment_count_or_ix;
+                tile[base + x].segment_count_or_ix += 1u;
+            }
             uint32_t seg_ix = seg_base + i - imin_;
             if (seg_ix < cfg->seg_counts_size) {
                 seg_counts[seg_ix].line_ix = line_ix;
@@ -599,7 +602,9 @@ void vo_stage_path_tiling(vo_ctx *c) {
         int32_t bbox[4] = {(int32_t)path.bbox[0], (int32_t)path.bbox[1], (int32_t)path.bbox[2], (int32_t)path.bbox[3]};
         int32_t stride = bbox[2] - bbox[0];
         int32_t tile_ix = (int32_t)path.tiles + (y - bbox[1]) * stride + x - bbox[0];
-        vo_tile tile = tiles[tile_ix];
+        vo_tile tile = {0, 0u}; /* robust access: an out-of-range load reads zero (a crossing index past 16 bits, the
+                                   reference's own limit in path_count.wgsl:196, recomputes a tile that is not the path's) */
+        if ((uint32_t)tile_ix < cfg->tiles_size) tile = tiles[tile_ix];
         uint32_t seg_start = ~tile.segment_count_or_ix;
         if ((int32_t)seg_start < 0) continue;
         vec2 tile_xy = v2((float)x * (float)TILE_WIDTH, (float)y * (float)TILE_HEIGHT);

@@ -47,7 +47,7 @@ def fine_on_engine_inputs(engine, oracle, width, height, used_words):
 
 
 def compare_frame(engine, packed, layout, width, height, base_color, aa, name, tol=0, check_stages=True, oracle=None,
-                  resolved=None, order_sensitive=False):
+                  resolved=None, order_sensitive=False, min_agree=0.99):
     """Renders with both, asserts bump counters, intermediates (up to documented permutations) and the
     final RGBA8 image agree.  tol is the per-channel tolerance on the image (0 for MSAA: integer coverage;
     <=1 for area AA where segment order changes f32 summation order).
@@ -56,7 +56,8 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
     order_sensitive=True (fuzzed scenes) drops the direct +-tol comparison and keeps that exact one: a last-ulp
     difference in a pixel's area can be amplified without bound by what composites it (un-premultiplication at alpha
     ~ 0, Compose modes that divide by alpha, ColorDodge / ColorBurn / the non-separable mix modes), on the reference's
-    own GPUs as much as here."""
+    own GPUs as much as here.  min_agree: the fraction of pixels on which the two orders must still agree within tol
+    (None for scenes with non-finite geometry, where a NaN wins or loses a min / max depending on the order)."""
     oracle = oracle or Oracle()
     oracle.set_scene(packed, layout, width, height, base_color, int(aa))
     ramps = None
@@ -139,7 +140,7 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
         assert np.array_equal(img, same_order), (
             f"{name}: fine differs from the oracle's fine on the same segment order: "
             f"max {np.abs(img.astype(np.int32) - same_order.astype(np.int32)).max()}")
-        if order_sensitive:  # still require the two orders to agree almost everywhere
+        if order_sensitive and min_agree is not None:  # still require the two orders to agree almost everywhere
             frac = float((diff.max(axis=2) > tol).mean())
-            assert frac <= 0.01, f"{name}: {frac:.2%} of the pixels differ by more than {tol} between the two segment orders"
+            assert frac <= 1.0 - min_agree, f"{name}: {frac:.2%} of the pixels differ by more than {tol} between the two segment orders"
     return img, ref, bump

@@ -462,6 +462,47 @@ def test_emu_layers_nested_300_deep(emu_engine, kind):
         emu_engine.set_auto_grow(False)
 
 
+@pytest.mark.parametrize("v", [1e6, 1e9, 3e38, float("inf"), float("nan"), -1e9, -3e38])
+def test_emu_extreme_coordinates(emu_engine, v):
+    # Coordinates, stroke widths and transforms from a million pixels off screen to f32's limits, infinities and NaN.  What
+    # the reference computes there is deterministic IEEE arithmetic and the kernels must reproduce it; what it LEAVES to
+    # WebGPU's robust buffer access must not become a wild access here: a line that starts more than 65 535 tile
+    # crossings outside the viewport overflows the 16-bit crossing index of SegmentCount (path_count.wgsl:196) and
+    # path_tiling recomputes a tile that is not the path's (found with these inputs: the oracle crashed, the engine read
+    # out of bounds).  Also found here: the exact straight-segment shortcut has to stand back when |h|^2 overflows in the
+    # general loop (chords > 3e9 px), and atan2(inf, inf) is pi/4, not inf / inf.
+    from oracle.oracle import Oracle
+    from vello_amd import Affine, BezPath, Color, Fill, Rect, Scene, Stroke
+
+    def scene(kind):
+        s = Scene()
+        s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(10, 200, 30), None, Rect(8, 8, 56, 56))
+        p = BezPath()
+        if kind == 0:
+            p.move_to((10.0, 10.0)); p.line_to((v, 20.0)); p.line_to((30.0, v)); p.close_path()
+            s.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(200, 0, 0), None, p)
+        elif kind == 1:
+            p.move_to((10.0, 10.0)); p.curve_to((v, 5.0), (20.0, v), (40.0, 40.0))
+            s.stroke(Stroke(3.0), Affine.IDENTITY, Color.from_rgb8(200, 0, 200), None, p)
+        elif kind == 2:
+            p.move_to((10.0, 10.0)); p.quad_to((30.0, 50.0), (50.0, 10.0))
+            s.stroke(Stroke(abs(v) if v == v else v), Affine.IDENTITY, Color.from_rgb8(0, 0, 200), None, p)
+        else:
+            p.move_to((10.0, 10.0)); p.line_to((50.0, 12.0)); p.line_to((30.0, 50.0)); p.close_path()
+            s.fill(Fill.EvenOdd, Affine.scale(v) if kind == 3 else Affine.translate(v, 0.0), Color.from_rgb8(0, 200, 200), None, p)
+        return s
+
+    emu_engine.set_auto_grow(True)
+    try:
+        for kind in range(5):
+            packed, layout = scene(kind).resolve()
+            for aa in (AaConfig.Area, AaConfig.Msaa16):
+                compare_frame(emu_engine, packed, layout, 64, 64, BLACK, aa, f"emu_extreme_{kind}_{v}_{int(aa)}",
+                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, min_agree=None, oracle=Oracle(capacity_scale=4))
+    finally:
+        emu_engine.set_auto_grow(False)
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below

@@ -107,7 +107,7 @@ __device__ __forceinline__ float cos_cr(float x) {
 // < 2^-57 relative, i.e. it rounds to the same f32 as the full ocml routine (both are "the exact value
 // rounded once" up to ~2^-29 per call) at a fifth of the instructions.
 __device__ __forceinline__ float atan2_cr(float y, float x) {
-    if (x > 0.0f && fabsf(y) <= 0.015625f * x) {
+    if (x > 0.0f && fabsf(y) <= 0.015625f * x && fabsf(y) < __builtin_inff()) {  // (inf, inf) is pi/4, not inf / inf
         double r = (double)y / (double)x;
         double r2 = r * r;
         return (float)(r * (1.0 + r2 * (-1.0 / 3.0 + r2 * (1.0 / 5.0 + r2 * (-1.0 / 7.0 + r2 * (1.0 / 9.0 + r2 * (-1.0 / 11.0)))))));

@@ -132,7 +132,9 @@ __device__ __forceinline__ bool cubic_is_straight(vec2 p0, vec2 p1, vec2 p2, vec
     float clen = sqrtf(c2);
     float S = scale * clen;
     float ay0 = fabsf(h0y), ay1 = fabsf(h1y), aoff = fabsf(offset);
-    return c2 >= 4e-12f && a0 >= 4e-12f && a1 >= 4e-12f && a0 <= c2 && a1 <= c2 && h0x > 0.0f && h1x > 0.0f && ay0 * S <= 0.02f * h0x &&
+    // c2 <= 1e19: beyond it |h|^2 overflows f32 inside the general loop's length(h0) (flatten.wgsl:106-110), which then
+    // rejects the range and subdivides where this test would say "one line"; such chords (> 3e9 px) take the loop
+    return c2 >= 4e-12f && c2 <= 1e19f && a0 >= 4e-12f && a1 >= 4e-12f && a0 <= c2 && a1 <= c2 && h0x > 0.0f && h1x > 0.0f && ay0 * S <= 0.02f * h0x &&
            ay1 * S <= 0.02f * h1x && aoff * ay0 <= 2.5e-3f * h0x * clen && aoff * ay1 <= 2.5e-3f * h1x * clen;
 }
 

@@ -171,10 +171,12 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
             if (line_ix < n_lines) w = setup_line_walk(load_line(lines, line_ix), paths);
             const uint32_t count = w.valid ? w.imax - w.imin : 0u;
             const int32_t delta = w.is_down ? -1 : 1;
+            // every tile index below is bounded by the buffer explicitly (WebGPU does that for the reference): with
+            // crossing indices past f32's 24 bits the walk can leave the path's tile rectangle
             if (w.valid) {
                 for (int32_t y = w.ymin; y < w.ymax; y++) {
                     int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride;
-                    atomicAdd(&tile[base].backdrop, delta);
+                    if ((uint32_t)base < cfg.tiles_size) atomicAdd(&tile[base].backdrop, delta);
                 }
             }
             float last_z = floorf(w.a * ((float)w.imin - 1.0f) + w.b);
@@ -207,7 +209,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                         bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
                         if (top_edge && x + 1 < w.bbox2) {
                             int32_t x_bump = maxi(x + 1, w.bbox0);
-                            atomicAdd(&tile[base + x_bump].backdrop, delta);
+                            if ((uint32_t)(base + x_bump) < cfg.tiles_size) atomicAdd(&tile[base + x_bump].backdrop, delta);
                         }
                         key = (uint32_t)(base + x);
                         last_z = z;
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                     unsigned long long gt = lane == 63 ? 0ull : (heads & (~0ull << (lane + 1)));  // heads after me
                     int run_end = gt ? (__ffsll((long long)gt) - 1) : 64;
                     uint32_t r = 0u;
-                    if (act && head) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
+                    if (act && head && key < cfg.tiles_size) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
                     k_act[k] = act;
                     k_i[k] = i;
                     k_r[k] = r;
@@ -345,7 +347,11 @@ __global__ void __launch_bounds__(256) k_path_tiling(Config cfg, Bump *bump, con
         int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2];
         int32_t stride = bbox2 - bbox0;
         int32_t tile_ix = (int32_t)path.tiles + (y - bbox1) * stride + x - bbox0;
-        Tile tile = tiles[tile_ix];
+        // Tile indices are trusted upstream because WebGPU bounds every access; here the bound is explicit.  A line that
+        // starts more than 65 535 tile crossings outside the viewport overflows the 16-bit crossing index of
+        // SegmentCount (path_count.wgsl:196, the reference's own limit) and, like a crossing index beyond f32's 24 bits,
+        // recomputes a tile that is not the path's: out of the buffer it reads as an empty tile, as a robust load would.
+        Tile tile = (uint32_t)tile_ix < cfg.tiles_size ? tiles[tile_ix] : Tile{0, 0u};
         uint32_t seg_start = ~tile.segment_count_or_ix;
         if ((int32_t)seg_start < 0) continue;
         vec2 tile_xy = v2((float)x * (float)TILE_WIDTH, (float)y * (float)TILE_HEIGHT);
