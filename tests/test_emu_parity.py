@@ -503,6 +503,23 @@ def test_emu_extreme_coordinates(emu_engine, v):
         emu_engine.set_auto_grow(False)
 
 
+def test_emu_fuzz_extreme_values(emu_engine):
+    # the whole-API fuzzer with 12 % of its points drawn from {+-1e6 ... +-3e38, +-inf, NaN}
+    import vello_amd
+    from oracle.oracle import Oracle
+    from workloads.fuzz import fuzz_scene
+
+    emu_engine.set_auto_grow(True)
+    try:
+        for seed in range(0, 24):
+            r = vello_amd.Resolver().resolve(fuzz_scene(seed, n_ops=14, extreme=True))
+            aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
+            compare_frame(emu_engine, r.packed, r.layout, 128, 128, BLACK, aa, f"emu_fuzzx_{seed}", tol=1 if aa == AaConfig.Area else 0,
+                          resolved=r, order_sensitive=True, min_agree=None, oracle=Oracle(capacity_scale=4))
+    finally:
+        emu_engine.set_auto_grow(False)
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below

@@ -35,7 +35,14 @@ def _affine(rng, size):
     return Affine([float(v) for v in rng.uniform(-1.5, 1.5, 4)] + [float(rng.uniform(0, size)), float(rng.uniform(0, size))])
 
 
+_EXTREME = False  # fuzz_scene(..., extreme=True): also coordinates far beyond the viewport, up to f32's limits, inf and NaN
+_EXTREME_VALUES = [1e6, -1e6, 3e7, -2e8, 1e9, 1e12, 1e20, 3e38, -3e38, float("inf"), float("-inf"), float("nan")]
+
+
 def _point(rng, size):
+    if _EXTREME and rng.random() < 0.12:
+        pick = lambda: float(rng.choice(_EXTREME_VALUES)) if rng.random() < 0.7 else float(rng.uniform(-10, size + 10))
+        return (pick(), pick())
     k = int(rng.integers(0, 10))
     if k == 0:
         return (float(rng.uniform(-1e4, 1e4)), float(rng.uniform(-1e4, 1e4)))     # far outside the viewport
@@ -131,7 +138,16 @@ def _stroke(rng):
                   start_cap=Cap(int(rng.integers(0, 3))), end_cap=Cap(int(rng.integers(0, 3))))
 
 
-def fuzz_scene(seed, size=128, n_ops=40):
+def fuzz_scene(seed, size=128, n_ops=40, extreme=False):
+    global _EXTREME
+    _EXTREME = bool(extreme)
+    try:
+        return _fuzz_scene(seed, size, n_ops)
+    finally:
+        _EXTREME = False
+
+
+def _fuzz_scene(seed, size, n_ops):
     rng = np.random.Generator(np.random.PCG64(seed))
     s = Scene()
     depth = 0
