@@ -520,6 +520,30 @@ def test_emu_fuzz_extreme_values(emu_engine):
         emu_engine.set_auto_grow(False)
 
 
+@pytest.mark.parametrize("atlas", [None, (32, 128)])
+def test_emu_persistent_resolver_over_many_frames(emu_engine, atlas):
+    # ONE Resolver across 150 frames of recurring fuzz scenes: ramp ids reused and evicted in the ramp cache
+    # (ramp_cache.rs:26-63, at most 64 retained), images resident, dirty, evicted, repacked and the atlas grown in the image
+    # cache -- every frame against the oracle's rendering of the same resolved state
+    import vello_amd
+    from workloads.fuzz import fuzz_scene
+
+    res = vello_amd.Resolver() if atlas is None else vello_amd.Resolver(atlas_sizes=atlas)
+    evicted = 0
+    emu_engine.set_auto_grow(True)
+    try:
+        for i in range(150):
+            seed = 5000 + (i * 7) % 90
+            r = res.resolve(fuzz_scene(seed))
+            evicted += r.evicted
+            aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
+            compare_frame(emu_engine, r.packed, r.layout, 128, 128, 0xFF102030, aa, f"emu_seq_{i}", tol=1 if aa == AaConfig.Area else 0,
+                          resolved=r, order_sensitive=True)
+    finally:
+        emu_engine.set_auto_grow(False)
+    assert (evicted > 0) == (atlas is not None)
+
+
 def test_emu_zero_width_stroke_clip_before_any_transform(emu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below
