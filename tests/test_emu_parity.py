@@ -244,7 +244,7 @@ def test_emu_reference_brush_and_layer_scenes(emu_engine, which):
 
 @pytest.mark.parametrize("which", ["ref_stroke_styles", "ref_stroke_styles_non_uniform", "ref_stroke_styles_skew", "two_point_radial",
                                    "conflation_artifacts", "labyrinth", "clip_test", "luminance_mask", "image_extend_modes",
-                                   "image_extend_modes_nearest"])
+                                   "image_extend_modes_nearest", "brush_transform"])
 def test_emu_reference_catalogue_second_batch(emu_engine, which):
     # test_scenes.rs:335-511 (cap / join / miter-limit matrix under identity, non-uniform scale and skew), :1045-1211
     # (COLR two-point radial cases x extend modes), :1444-1531 (shared edges of opposite winding), :1533-1608 (140

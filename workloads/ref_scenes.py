@@ -572,3 +572,19 @@ def image_extend_modes_scene(quality=None):
                                ((Extend.Repeat, Extend.Repeat), (800., 100.)), ((Extend.Repeat, Extend.Reflect), (800., 800.))]:
         s.fill(Fill.NonZero, Affine.scale(100.).then_translate(tx, ty), ImageBrush(image, xe, ye, quality), off, rect)
     return s, 1500, 1500
+
+
+def brush_transform_scene(th=0.7):
+    """test_scenes.rs:944-976 at one instant of its animation: a radial gradient under a rotated non-uniform scale, and a
+    linear gradient whose BRUSH transform rotates about the shape's centre, filled and stroked.  1300 x 900."""
+    import math
+    from vello_amd import Gradient
+    red, green, blue = Color.from_rgb8(255, 0, 0), Color.from_rgb8(0, 128, 0), Color.from_rgb8(0, 0, 255)
+    linear = Gradient.new_linear((0.0, 0.0), (0.0, 200.0)).with_stops([red, green, blue])
+    around = Affine.translate(200.0, 100.0) * Affine.rotate(th) * Affine.translate(-200.0, -100.0)
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.rotate(math.radians(25.0)) * Affine.scale_non_uniform(2.0, 1.0),
+           Gradient.new_radial((200.0, 200.0), 80.0).with_stops([red, green, blue]), None, Rect(100.0, 100.0, 300.0, 300.0))
+    s.fill(Fill.NonZero, Affine.translate(200.0, 600.0), linear, around, Rect(0.0, 0.0, 400.0, 200.0))
+    s.stroke(Stroke(40.0), Affine.translate(800.0, 600.0), linear, around, Rect(0.0, 0.0, 400.0, 200.0))
+    return s, 1300, 900
