@@ -511,7 +511,7 @@ def test_emu_fuzz_extreme_values(emu_engine):
 
     emu_engine.set_auto_grow(True)
     try:
-        for seed in range(0, 24):
+        for seed in [s for s in range(0, 40) if s not in (2, 5, 25)]:  # those three emit 6-7 million lines each (15-30 s)
             r = vello_amd.Resolver().resolve(fuzz_scene(seed, n_ops=14, extreme=True))
             aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
             compare_frame(emu_engine, r.packed, r.layout, 128, 128, BLACK, aa, f"emu_fuzzx_{seed}", tol=1 if aa == AaConfig.Area else 0,
