@@ -517,6 +517,23 @@ def test_inconsistent_scenes_are_refused(gpu_engine):
         compare_frame(gpu_engine, good_packed, layout, 256, 256, WHITE, AaConfig.Msaa8, "gpu_invalid_after_" + what.split(":")[0].replace(" ", "_"))
 
 
+def test_reference_regression_scenes(gpu_engine):
+    # the reference's own regression tests that need no fonts: known_issues.rs:54-90 (clip_blends, issue #1198),
+    # regression.rs:18-31 (rounded_rectangle_watertight, issue #616), :107-121 (stroke_width_zero, issue #662)
+    import vello_amd
+
+    cases = [workloads.clip_blends_scene() + ("clip_blends",)] + workloads.regression_stroke_scenes()
+    for scene, w, h, name in cases:
+        r = vello_amd.Resolver().resolve(scene)
+        for aa in (AaConfig.Area, AaConfig.Msaa16):
+            img, _, _ = compare_frame(gpu_engine, r.packed, r.layout, w, h, BLACK, aa, f"gpu_{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                                      resolved=r)
+        if name == "stroke_width_zero":
+            assert (img[:, :, :3] == 0).all()
+        if name == "clip_blends":
+            assert tuple(img[5, 5]) == (0, 0, 255, 255) and tuple(img[90, 50]) == (0, 0, 212, 255)   # blue x aquamarine, multiplied
+
+
 def test_zero_width_stroke_clip_before_any_transform(gpu_engine):
     # scene.rs:179-183 as the FIRST operation of a scene: the zero-width stroke clip encodes a style and an empty path
     # but no transform, so its tags carry trans_ix = 0 - 1.  WGSL indexes in u32 (the read lands just below

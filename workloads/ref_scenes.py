@@ -588,3 +588,31 @@ def brush_transform_scene(th=0.7):
     s.fill(Fill.NonZero, Affine.translate(200.0, 600.0), linear, around, Rect(0.0, 0.0, 400.0, 200.0))
     s.stroke(Stroke(40.0), Affine.translate(800.0, 600.0), linear, around, Rect(0.0, 0.0, 400.0, 200.0))
     return s, 1300, 900
+
+
+def clip_blends_scene():
+    """vello_tests/tests/known_issues.rs:54-90 (issue #1198): a Multiply layer inside a clip layer of the same triangle,
+    over blue.  100 x 100."""
+    from vello_amd import BlendMode, Compose, Mix
+    s = Scene()
+    box = Rect(0., 0., 100., 100.)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(0, 0, 255), None, box)
+    tri = BezPath()
+    tri.move_to((50., 0.)); tri.line_to((0., 100.)); tri.line_to((100., 100.)); tri.close_path()
+    s.push_clip_layer(Fill.NonZero, Affine.IDENTITY, tri)
+    s.push_layer(Fill.NonZero, BlendMode(Mix.Multiply, Compose.SrcOver), 1.0, Affine.IDENTITY, tri)
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(127, 255, 212), None, box)
+    s.pop_layer()
+    s.pop_layer()
+    return s, 100, 100
+
+
+def regression_stroke_scenes():
+    """vello_tests/tests/regression.rs:18-31 (issue #616: the 2 px stroke of a rounded rectangle must be watertight) and
+    :107-121 (issue #662: a zero-width stroke draws nothing).  Returns [(scene, w, h, name)]."""
+    from vello_amd import RoundedRect
+    a = Scene()
+    a.stroke(Stroke(2.0), Affine.IDENTITY, Color.from_rgb8(255, 255, 255), None, RoundedRect(60.0, 10.0, 80.0, 30.0, 10.0))
+    b = Scene()
+    b.stroke(Stroke(0.0), Affine.IDENTITY, Color.from_rgb8(255, 218, 185), None, Rect(10.0, 10.0, 40.0, 40.0))
+    return [(a, 70, 30, "rounded_rectangle_watertight"), (b, 50, 50, "stroke_width_zero")]
