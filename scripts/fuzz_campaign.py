@@ -6,7 +6,8 @@ test suites carry.  Prints the failing seeds only.
     python scripts/fuzz_campaign.py pools    LO HI     every pool started at 64 elements, auto-grow
     python scripts/fuzz_campaign.py extreme  LO HI     12 % of the points from {+-1e6 ... +-3e38, +-inf, NaN}
 
-Round 1 ran api 0-43500, sizes 0-6000, pools 0-4000, extreme 0-1100 (see DESIGN.md section 4 for what they found).
+Round 1 ran api 0-43500, sizes 0-6000, pools 0-4000, extreme 0-358 (some extreme seeds emit tens of millions of lines and take
+minutes each on the emulator) (see DESIGN.md section 4 for what they found).
 """
 import os
 import sys
