@@ -25,6 +25,7 @@
  *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
  *   vello_hip_grow_pools /     "TODO: apply logic to determine whether   vello/src/lib.rs:762-764,
  *   vello_hip_set_auto_grow    we need to rerun coarse" + pool sizes     vello_encoding/src/config.rs:398-408
+ *   vello_hip_set_debug_flags  (test seam: reference-exact coarse output)  vello_shaders/shader/coarse.wgsl:156-471
  *   vello_hip_run_stages /     CpuShaderType::Present per-stage seam     vello/src/wgpu_engine.rs:57-61, :541-553,
  *   vello_hip_{read,write}_buffer  (CpuBinding byte buffers)             vello_shaders/src/cpu.rs:58-62
  *   vello_hip_set_profiling /  wgpu-profiler per-dispatch GPU timestamps vello/src/wgpu_engine.rs:570-588
@@ -149,7 +150,9 @@ int vello_hip_render(vello_hip_ctx *ctx, const uint8_t *scene, size_t scene_len,
 int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                            const uint32_t *ramps, uint32_t n_ramps);
 /* ... then each call enqueues one full frame (all stages) on the context's stream and returns
- * without waiting.  `out_device` may be NULL (render into the internal target only). */
+ * without waiting.  `out_device` may be NULL (render into the internal target only).  Resident frames ALWAYS show
+ * the scene of the last vello_hip_upload_scene: scenes passed to vello_hip_render_frame are private to their frame
+ * (VELLO_HIP_E_INVALID if no scene was ever uploaded). */
 int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
 /* Animation form (every frame has its own scene): vello_hip_upload_scene + vello_hip_render_resident in one call
  * that does NOT wait for the frame.  The scene is copied into the private slot of the next in-flight buffer set
@@ -181,6 +184,13 @@ int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t w
 int vello_hip_get_capacities(vello_hip_ctx *ctx, vello_hip_capacities *out);
 int vello_hip_grow_pools(vello_hip_ctx *ctx, const vello_hip_bump *demand, vello_hip_capacities *new_caps /* nullable */);
 int vello_hip_set_auto_grow(vello_hip_ctx *ctx, int enabled);
+
+/* Test-seam switches (default 0).  VELLO_HIP_DEBUG_NO_CULL turns off coarse's occlusion culling (a draw hidden under a
+ * later opaque full-tile cover is normally not emitted; the image is the same, but bump.segments / bump.ptcl and the
+ * PTCL words are then <= the reference's): with it set, PTCL, segment slices and every bump counter equal the
+ * reference's (coarse.wgsl:156-471) up to the order its atomics hand out slices and chunks. */
+enum { VELLO_HIP_DEBUG_NO_CULL = 1 };
+int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting
  * (wgpu_engine.rs:757); with n > 1 consecutive vello_hip_render_resident calls rotate over n private buffer

@@ -197,6 +197,9 @@ void vo_stage_path_count(vo_ctx *c) {
         if (robust_err != 0.0f) a -= ROBUST_EPSILON * vo_sign(robust_err);
         float x0 = xt0 * x_sign + (is_positive_slope ? 0.0f : -1.0f);
 
+        /* a line of a PATH marker the layout does not count has no Path record: a robust (WebGPU) load reads zeros,
+         * stride 0, no crossings (path_count.wgsl:112) */
+        if (line.path_ix >= cfg->layout.n_paths) continue;
         vo_path path = paths[line.path_ix];
         int32_t bbox[4] = {(int32_t)path.bbox[0], (int32_t)path.bbox[1], (int32_t)path.bbox[2], (int32_t)path.bbox[3]};
         float xmin = vo_min(s0.x, s1.x);

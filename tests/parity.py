@@ -54,8 +54,162 @@ def fine_on_engine_inputs(engine, oracle, width, height, used_words):
     return oracle.buffer("output", np.uint8)[: width * height * 4].reshape(height, width, 4).copy()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Back half of the pipeline: bin lists, SegmentCount records, PTCL words, per-tile segment slices.
+# What the order of atomics decides (and the reference's GPUs decide differently from run to run as well) is
+# normalised away; everything else must be equal word for word.
+# ---------------------------------------------------------------------------------------------------------------
+CMD_END, CMD_FILL, CMD_SOLID, CMD_COLOR, CMD_LIN_GRAD, CMD_RAD_GRAD, CMD_SWEEP_GRAD = 0, 1, 3, 5, 6, 7, 8
+CMD_IMAGE, CMD_BEGIN_CLIP, CMD_END_CLIP, CMD_JUMP, CMD_BLUR_RECT = 9, 10, 11, 12, 13
+_CMD_SIZE = np.zeros(16, dtype=np.int64)
+for _t, _n in ((CMD_FILL, 4), (CMD_SOLID, 1), (CMD_COLOR, 2), (CMD_LIN_GRAD, 3), (CMD_RAD_GRAD, 3), (CMD_SWEEP_GRAD, 3), (CMD_IMAGE, 2),
+               (CMD_BEGIN_CLIP, 1), (CMD_END_CLIP, 3), (CMD_BLUR_RECT, 3)):
+    _CMD_SIZE[_t] = _n
+
+
+def compare_bins(name, bh_h, bd_h, bh_o, bd_o, n_draw, width, height, bin_data_start):
+    """binning.wgsl:55-203: per (partition of 256 draw objects, bin) the element count and the element list, in order
+    (the rank of an element inside its chunk is a popcount, not an atomic); chunk_offset itself follows bump order."""
+    wb, hb = (((width + 15) // 16) + 15) // 16, (((height + 15) // 16) + 15) // 16
+    n_bins = wb * hb
+    aligned = (n_bins + 255) // 256 * 256
+    n_part = (n_draw + 255) // 256
+    n_cmp = 0
+    for part in range(n_part):
+        hh = bh_h[part * aligned * 2: (part * aligned + n_bins) * 2].reshape(-1, 2)
+        ho = bh_o[part * aligned * 2: (part * aligned + n_bins) * 2].reshape(-1, 2)
+        assert np.array_equal(hh[:, 0], ho[:, 0]), f"{name}: bin_headers element counts differ in partition {part}"
+        for b in np.nonzero(ho[:, 0])[0]:
+            n = int(ho[b, 0])
+            lh = bd_h[bin_data_start + int(hh[b, 1]): bin_data_start + int(hh[b, 1]) + n]
+            lo = bd_o[bin_data_start + int(ho[b, 1]): bin_data_start + int(ho[b, 1]) + n]
+            assert np.array_equal(lh, lo), f"{name}: bin_data differs (partition {part}, bin {b})"
+            n_cmp += n
+    return n_cmp
+
+
+def compare_seg_counts(name, sc_h, lines_h, sc_o, lines_o, n):
+    """path_count.wgsl:172-199: one (line, crossing index within the line) record per tile crossing.  line_ix follows the
+    order of the line soup and the slot within the tile's slice follows the tile atomics: records are compared as the
+    multiset of (line CONTENT, seg_within_line); the slots are checked through the per-tile segment slices."""
+    def canon(sc, lines):
+        sc = sc[: n * 2].reshape(-1, 2)
+        rows = canonical_nan_lines(lines)[sc[:, 0]]
+        return sorted_rows(np.concatenate([rows, (sc[:, 1] & 0xffff)[:, None]], axis=1), 7)
+    a, b = canon(sc_h, lines_h), canon(sc_o, lines_o)
+    assert np.array_equal(a, b), f"{name}: seg_counts differ as a multiset of (line, crossing) ({(a != b).any(axis=1).sum()} rows)"
+
+
+def walk_ptcl_pair(name, ptcl_h, ptcl_o, n_tiles):
+    """Walks the command lists of all tiles of both PTCL buffers in lockstep (vectorised over tiles).  Asserts the
+    streams are equal word for word except (a) CMD_JUMP targets / chunk placement (bump order), (b) the segment index
+    of CMD_FILL (bump order) and (c) word 0 of a tile, its blend-spill offset (bump order).  Returns the fills as
+    (seg_ix_hip, seg_ix_oracle, n_segs) arrays and the number of words compared."""
+    tiles = np.arange(n_tiles, dtype=np.int64)
+    ih, io = tiles * 64 + 1, tiles * 64 + 1
+    active = np.ones(n_tiles, dtype=bool)
+    fills = []
+    n_words = 0
+
+    def follow(ptcl, ix, act):
+        for _ in range(1 << 20):
+            j = act & (ptcl[np.minimum(ix, ptcl.size - 1)] == CMD_JUMP)
+            if not j.any():
+                return ix
+            ix = np.where(j, ptcl[np.minimum(ix + 1, ptcl.size - 1)].astype(np.int64), ix)
+        raise AssertionError(f"{name}: PTCL jump cycle")
+
+    for _ in range(1 << 22):
+        if not active.any():
+            break
+        ih, io = follow(ptcl_h, ih, active), follow(ptcl_o, io, active)
+        a = np.nonzero(active)[0]
+        th, to = ptcl_h[ih[a]], ptcl_o[io[a]]
+        if not np.array_equal(th, to):
+            bad = a[np.nonzero(th != to)[0][0]]
+            raise AssertionError(f"{name}: PTCL command differs in tile {bad}: hip {ptcl_h[ih[bad]]} oracle {ptcl_o[io[bad]]}")
+        assert (th < 16).all() and ((th == CMD_END) | (_CMD_SIZE[np.minimum(th, 15)] > 0)).all(), f"{name}: unknown PTCL command"
+        size = _CMD_SIZE[th]
+        for k in (1, 2, 3):
+            m = size > k
+            if not m.any():
+                continue
+            wh, wo = ptcl_h[ih[a[m]] + k], ptcl_o[io[a[m]] + k]
+            if k == 2:  # CMD_FILL word 2 = segment index: allocation order
+                isf = th[m] == CMD_FILL
+                fills.append((wh[isf].astype(np.int64), wo[isf].astype(np.int64), (ptcl_o[io[a[m]][isf] + 1] >> 1).astype(np.int64)))
+                wh, wo = wh[~isf], wo[~isf]
+            if not np.array_equal(wh, wo):
+                raise AssertionError(f"{name}: PTCL payload word {k} differs ({(wh != wo).sum()} commands)")
+        n_words += int(size.sum()) + int((th == CMD_END).sum())
+        ih[a] += size
+        io[a] += size
+        active[a[th == CMD_END]] = False
+    assert not active.any(), f"{name}: PTCL walk did not terminate"
+    if fills:
+        fh, fo, fn = (np.concatenate(x) for x in zip(*fills))
+    else:
+        fh = fo = fn = np.zeros(0, dtype=np.int64)
+    return fh, fo, fn, n_words
+
+
+def compare_segment_slices(name, seg_h, seg_o, fh, fo, fn):
+    """path_tiling.wgsl:39-173: the PathSegment slice of every CMD_FILL, as a multiset per fill (the slot of a segment
+    inside its tile's slice is the order of the tile atomic in path_count)."""
+    total = int(fn.sum())
+    if total == 0:
+        return 0
+    fill_id = np.repeat(np.arange(fn.size, dtype=np.int64), fn)
+    within = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(fn) - fn, fn)
+    rows_h = canonical_nan_words(seg_h.reshape(-1, 6)[np.repeat(fh, fn) + within])
+    rows_o = canonical_nan_words(seg_o.reshape(-1, 6)[np.repeat(fo, fn) + within])
+
+    def canon(rows):
+        key = np.concatenate([fill_id[:, None].astype(np.uint64), rows.astype(np.uint64)], axis=1)
+        return key[np.lexsort(key.T[::-1])]
+    a, b = canon(rows_h), canon(rows_o)
+    assert np.array_equal(a, b), f"{name}: segments differ within {len(np.unique(a[(a != b).any(axis=1), 0]))} tile slices"
+    return total
+
+
+def compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=None, ref=None):
+    """Renders once more with occlusion culling off (VELLO_HIP_DEBUG_NO_CULL): every counter must then equal the
+    oracle's, and bin lists, SegmentCounts, PTCL and segment slices are diffed."""
+    engine.set_debug_flags(no_cull=True)
+    try:
+        img, bump = engine.render(packed, layout, width, height, base_color, aa, ramps=ramps)
+    finally:
+        engine.set_debug_flags(no_cull=False)
+    ob = oracle.bump()
+    assert bump == ob, f"{name}: bump counters differ with culling off: hip {bump} oracle {ob}"
+    if bump["failed"] != 0:
+        return {}
+    L = layout
+    n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
+    stats = {}
+    bh_h = engine.read_buffer("bin_headers", np.uint32)
+    bd_h = engine.read_buffer("info_bin_data", np.uint32, (L.bin_data_start + ob["binning"]) * 4)
+    stats["bin_entries"] = compare_bins(name, bh_h, bd_h, oracle.buffer("bin_headers", np.uint32), oracle.buffer("info_bin_data", np.uint32),
+                                        L.n_draw_objects, width, height, L.bin_data_start)
+    assert stats["bin_entries"] == ob["binning"], f"{name}: bin lists hold {stats['bin_entries']} entries, bump.binning {ob['binning']}"
+    n_lines, n_sc = ob["lines"], ob["seg_counts"]
+    compare_seg_counts(name, engine.read_buffer("seg_counts", np.uint32, n_sc * 8), engine.read_buffer("lines", np.uint32, n_lines * 24),
+                       oracle.buffer("seg_counts", np.uint32), oracle.buffer("lines", np.uint32)[: n_lines * 6], n_sc)
+    stats["seg_counts"] = n_sc
+    n_ptcl = 64 * n_tiles + ob["ptcl"]
+    ptcl_h = engine.read_buffer("ptcl", np.uint32, n_ptcl * 4)
+    ptcl_o = oracle.buffer("ptcl", np.uint32)[:n_ptcl]
+    fh, fo, fn, stats["ptcl_words"] = walk_ptcl_pair(name, ptcl_h, ptcl_o, n_tiles)
+    assert int(fn.sum()) == ob["segments"], f"{name}: CMD_FILLs cover {int(fn.sum())} segments, bump.segments {ob['segments']}"
+    stats["segments"] = compare_segment_slices(name, engine.read_buffer("segments", np.uint32, ob["segments"] * 24),
+                                               oracle.buffer("segments", np.uint32)[: ob["segments"] * 6], fh, fo, fn)
+    if ref is not None and aa != 0:
+        assert np.array_equal(img, ref), f"{name}: image differs with culling off"
+    return stats
+
+
 def compare_frame(engine, packed, layout, width, height, base_color, aa, name, tol=0, check_stages=True, oracle=None,
-                  resolved=None, order_sensitive=False, min_agree=0.99):
+                  resolved=None, order_sensitive=False, min_agree=0.99, back_half=True):
     """Renders with both, asserts bump counters, intermediates (up to documented permutations) and the
     final RGBA8 image agree.  tol is the per-channel tolerance on the image (0 for MSAA: integer coverage;
     <=1 for area AA where segment order changes f32 summation order).
@@ -133,6 +287,10 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
                 bd_ok = False
                 break
         assert bd_ok, f"{name}: tile backdrops differ (path {i})"
+        # back_half=False: scenes whose crossing indices leave f32's 24 bits / SegmentCount's 16 bits -- two records can
+        # then claim the same slot of a foreign tile and which one stays is the order of the stores
+        if back_half and bump["failed"] == 0 and ob["failed"] == 0:
+            compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=ramps, ref=ref)
     diff = np.abs(img.astype(np.int32) - ref.astype(np.int32))
     if not order_sensitive:
         if diff.max() > tol:

@@ -383,6 +383,8 @@ def test_emu_inconsistent_scenes_are_refused(emu_engine):
         "every draw object a radial gradient: more draw data / info than the layout holds": (corrupt_draw_tags(0x29C), layout),
         "clip tags without clips in the layout": (corrupt_draw_tags(0x49), layout),
         "more draw objects than paths": (good_packed, layout._replace(n_draw_objects=layout.n_paths + 5)),
+        # fewer clip tags than n_clips: k_clip would walk clip_inp entries draw_leaf never wrote
+        "more clips in the layout than clip tags": (good_packed, layout._replace(n_clips=layout.n_clips + 3)),
     }
     for what, (packed, lay) in cases.items():
         with pytest.raises(vello_amd.VelloHipError):
@@ -498,7 +500,7 @@ def test_emu_extreme_coordinates(emu_engine, v):
             packed, layout = scene(kind).resolve()
             for aa in (AaConfig.Area, AaConfig.Msaa16):
                 compare_frame(emu_engine, packed, layout, 64, 64, BLACK, aa, f"emu_extreme_{kind}_{v}_{int(aa)}",
-                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, min_agree=None, oracle=Oracle(capacity_scale=4))
+                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4))
     finally:
         emu_engine.set_auto_grow(False)
 
@@ -515,7 +517,7 @@ def test_emu_fuzz_extreme_values(emu_engine):
             r = vello_amd.Resolver().resolve(fuzz_scene(seed, n_ops=14, extreme=True))
             aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
             compare_frame(emu_engine, r.packed, r.layout, 128, 128, BLACK, aa, f"emu_fuzzx_{seed}", tol=1 if aa == AaConfig.Area else 0,
-                          resolved=r, order_sensitive=True, min_agree=None, oracle=Oracle(capacity_scale=4))
+                          resolved=r, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4))
     finally:
         emu_engine.set_auto_grow(False)
 
@@ -600,3 +602,84 @@ def test_emu_auto_grow_covers_large_targets(built):
         assert np.array_equal(img, o.render())
     finally:
         L._use_library(None)
+
+
+def test_emu_auto_grow_with_frames_in_flight(built):
+    # an overflow on lane A followed by the auto-grow retry on lane B must report the RETRY's outcome; a lane
+    # dropped from the rotation must not keep failing vello_hip_sync
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        eng = vello_amd.Engine(capacities={"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 64})
+        eng.set_frames_in_flight(3)
+        eng.set_auto_grow(True)
+        packed, layout = workloads.stroke_styles_scene().resolve()
+        o = Oracle()
+        o.set_scene(packed, layout, 256, 256, WHITE, int(AaConfig.Msaa8))
+        ref = o.render()
+        for _ in range(2):
+            img, bump = eng.render(packed, layout, 256, 256, WHITE, AaConfig.Msaa8)
+            assert bump["failed"] == 0 and np.array_equal(img, ref)
+            assert eng.sync() == 0
+        # without auto-grow: overflow, then shrink the rotation so that the failed lane drops out of it
+        eng2 = vello_amd.Engine(capacities={"lines": 64, "seg_counts": 64, "segments": 64})
+        eng2.set_frames_in_flight(3)
+        eng2.upload_scene(packed, layout)
+        for _ in range(3):
+            eng2.render_resident(256, 256, WHITE, AaConfig.Msaa8)
+        assert eng2.sync() == -4
+        eng2.set_frames_in_flight(1)
+        small, small_layout = workloads.smoke_square_scene().resolve()
+        eng2.upload_scene(small, small_layout)
+        eng2.render_resident(20, 20, BLACK, AaConfig.Area)
+        assert eng2.sync() == 0, "lanes outside the rotation must not fail the frames of the rotation"
+    finally:
+        L._use_library(None)
+
+
+def test_emu_resident_frames_show_the_uploaded_scene(built):
+    # after vello_hip_render_frame (private per-lane scenes) a resident frame renders the scene of
+    # vello_hip_upload_scene on whichever lane the rotation reaches -- or fails if there is none
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        eng = vello_amd.Engine()
+        eng.set_frames_in_flight(2)
+        a, la = workloads.stroke_styles_scene().resolve()
+        b, lb = workloads.clip_blend_scene().resolve()
+        eng.render_frame(b, lb, 128, 128, BLACK, AaConfig.Msaa8)
+        with pytest.raises(vello_amd.VelloHipError):
+            eng.render_resident(128, 128, BLACK, AaConfig.Msaa8)   # nothing was ever uploaded as THE scene
+        eng.sync()
+        eng.upload_scene(a, la)
+        eng.render_frame(b, lb, 128, 128, BLACK, AaConfig.Msaa8)
+        eng.render_frame(b, lb, 128, 128, BLACK, AaConfig.Msaa8)   # both lanes now hold private scene b
+        o = Oracle()
+        o.set_scene(a, la, 128, 128, BLACK, int(AaConfig.Msaa8))
+        ref = o.render()
+        for _ in range(3):
+            eng.render_resident(128, 128, BLACK, AaConfig.Msaa8)
+            eng.sync_frame(0)
+            assert np.array_equal(eng.read_buffer("output", np.uint8, 128 * 128 * 4).reshape(128, 128, 4), ref)
+        assert eng.sync() == 0
+    finally:
+        L._use_library(None)
+
+
+def test_emu_target_buffers_are_validated(emu_engine):
+    # a target smaller than the frame must be refused before the C ABI is called
+    packed, layout = workloads.smoke_square_scene().resolve()
+    emu_engine.upload_scene(packed, layout)
+    import torch
+
+    small = torch.zeros((10, 20, 4), dtype=torch.uint8)
+    with pytest.raises((ValueError, AssertionError)):
+        emu_engine.render_resident(20, 20, BLACK, AaConfig.Area, out=small)
+    with pytest.raises((ValueError, AssertionError)):
+        emu_engine.render_resident(20, 20, BLACK, AaConfig.Area, out=torch.zeros((20, 20, 4), dtype=torch.float32))

@@ -268,7 +268,7 @@ __device__ void process_batch(TileState &st, Alloc &al, const uint32_t (*sh_bitm
 
 __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const DrawMonoid *__restrict__ draw_monoids,
                                                 const BinHeader *__restrict__ bin_headers, const uint32_t *__restrict__ info_bin_data,
-                                                const Path *__restrict__ paths, Tile *tiles, Bump *bump, uint32_t *ptcl) {
+                                                const Path *__restrict__ paths, Tile *tiles, Bump *bump, uint32_t *ptcl, bool allow_cull) {
     __shared__ uint32_t sh_bitmaps[N_SLICE][N_TILE];
     __shared__ uint32_t sh_kill[N_SLICE][N_TILE];
     __shared__ ElemLds sh_el;
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     const uint32_t blend_offset = st.cmd_offset;
     st.cmd_offset += 1u;
     const uint32_t list_start = st.cmd_offset;
-    const bool cull = cfg.layout.n_clips == 0u;
+    const bool cull = allow_cull && cfg.layout.n_clips == 0u;
 
     uint32_t partition_ix = 0u, rd_ix = 0u, wr_ix = 0u, part_start_ix = 0u, ready_ix = 0u;
 
@@ -478,7 +478,7 @@ void launch_coarse(const Frame &f, hipStream_t s) {
     uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
     if (wb * hb == 0) return;
     hipLaunchKernelGGL(k_coarse, dim3(wb, hb), dim3(256), 0, s, f.cfg, f.scene, f.draw_monoids, f.bin_headers, f.info_bin_data, f.paths,
-                       f.tiles, f.bump(), f.ptcl);
+                       f.tiles, f.bump(), f.ptcl, !f.no_cull);
 }
 
 }  // namespace vk

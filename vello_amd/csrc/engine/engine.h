@@ -69,6 +69,7 @@ struct Frame {
     uint32_t n_ramps;
     const uint32_t *atlas;  // RGBA8 image atlas (render.rs:160-203), atlas_w x atlas_h texels
     uint32_t atlas_w, atlas_h;
+    bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;
     const uint32_t *mask_lut16;

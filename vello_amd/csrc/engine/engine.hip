@@ -74,6 +74,7 @@ struct vello_hip_ctx {
     uint32_t n_active = 1;  // lanes in the rotation (<= lanes.size(): shrinking keeps the buffers)
     uint32_t next_lane = 0, last_lane = 0;
     bool auto_grow = false;
+    uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
     // last frame
     Config cfg{};
     bool have_cfg = false;
@@ -270,6 +271,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.ramps = sc.n_ramps ? (const uint32_t *)sc.ramps.ptr : nullptr;
     f.n_ramps = sc.n_ramps;
     f.brushes = sc.brushes;
+    f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
     f.atlas_w = c->atlas_w;
     f.atlas_h = c->atlas_h;
@@ -527,9 +529,12 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
             draw_data_words += (t >> 2) & 0x7u;
             info_words += (t >> 6) & 0xfu;
         }
-        if (draw_data_words > (uint64_t)(L.transform_base - L.draw_data_base) || info_words > L.bin_data_start || clip_tags > L.n_clips ||
+        // clip_tags == n_clips, not <=: k_clip walks n_clips entries of clip_inp and draw_leaf writes one per clip tag
+        // (resolve counts exactly the BEGIN/END_CLIP tags below n_draw_objects: the END_CLIPs it appends for unclosed
+        // layers lie behind them, resolve.rs:139-141); fewer tags would leave entries uninitialised
+        if (draw_data_words > (uint64_t)(L.transform_base - L.draw_data_base) || info_words > L.bin_data_start || clip_tags != L.n_clips ||
             L.n_draw_objects > L.n_paths) {
-            c->last_error = "draw tags need more draw data / info words / clips / paths than the layout provides";
+            c->last_error = "draw tags need more draw data / info words / paths than the layout provides, or their clip count differs from n_clips";
             return VELLO_HIP_E_INVALID;
         }
     }
@@ -619,12 +624,25 @@ int vello_hip_render_resident(vello_hip_ctx *c, const vello_hip_render_params *p
     if (!c) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     uint32_t li = c->next_lane % c->n_active;
+    Lane &l = c->lanes[li];
+    int r;
+    if (l.use_own) {
+        // the lane last rendered a vello_hip_render_frame scene: resident frames always show the scene of
+        // vello_hip_upload_scene, whichever lane the rotation has reached
+        if (!c->shared.resident) {
+            c->last_error = "no scene uploaded (vello_hip_render_frame scenes are private to their frame)";
+            return VELLO_HIP_E_INVALID;
+        }
+        HIP_TRY(c, hipStreamSynchronize(l.stream));
+        l.use_own = false;
+        if ((r = alloc_lane_scene(c, l, c->shared))) return r;
+    }
     c->next_lane = (li + 1u) % c->n_active;
     c->last_lane = li;
     Frame f;
-    int r = prepare_frame(c, c->lanes[li], params, out_device, out_stride, f, false);
+    r = prepare_frame(c, l, params, out_device, out_stride, f, false);
     if (r) return r;
-    return run_stage_range(c, c->lanes[li], f, 0, VELLO_HIP_STAGE_FINE);
+    return run_stage_range(c, l, f, 0, VELLO_HIP_STAGE_FINE);
 }
 
 int vello_hip_run_stages(vello_hip_ctx *c, const vello_hip_render_params *params, int first, int last) {
@@ -657,29 +675,39 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
     return VELLO_HIP_OK;
 }
 
+// bump.failed of ONE lane's latest frame -> error code.  Failures are per frame: vello_hip_render judges the lane that
+// rendered its frame, vello_hip_sync the lanes of the current rotation, and vello_hip_grow_pools voids the frames that
+// overflowed the old pools (l.used) -- so a retry on another lane is not failed by the lane that overflowed.
+static int check_lane(vello_hip_ctx *c, Lane &l) {
+    if (!l.used || !l.zero_region.ptr) return VELLO_HIP_OK;
+    vello_hip_bump b;
+    HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
+    if (b.failed == 0u) return VELLO_HIP_OK;
+    if ((b.failed & FAILED_SCENE) != 0u) {
+        c->last_error = "the path tag stream needs more path data, transforms or styles than the scene buffer holds";
+        return VELLO_HIP_E_INVALID;
+    }
+    char msg[160];
+    std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,
+                  b.lines, b.binning, b.tile, b.seg_counts, b.segments, b.ptcl);
+    c->last_error = msg;
+    return VELLO_HIP_E_CAPACITY;
+}
+
 int vello_hip_sync(vello_hip_ctx *c) {
     if (!c) return VELLO_HIP_E_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     int r = sync_all(c);
     if (r) return r;
     if (!c->have_cfg) return VELLO_HIP_OK;
-    for (auto &l : c->lanes) {
-        if (!l.used || !l.zero_region.ptr) continue;
-        vello_hip_bump b;
-        HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
-        if ((b.failed & FAILED_SCENE) != 0u) {
-            c->last_error = "the path tag stream needs more path data, transforms or styles than the scene buffer holds";
-            return VELLO_HIP_E_INVALID;
-        }
-        if (b.failed != 0u) {
-            char msg[160];
-            std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,
-                          b.lines, b.binning, b.tile, b.seg_counts, b.segments, b.ptcl);
-            c->last_error = msg;
-            return VELLO_HIP_E_CAPACITY;
-        }
+    // only the lanes of the current rotation: a lane dropped by set_frames_in_flight keeps its old control block
+    int first = VELLO_HIP_OK;
+    for (uint32_t i = 0; i < c->n_active && i < c->lanes.size(); i++) {
+        r = check_lane(c, c->lanes[i]);
+        if (r == VELLO_HIP_E_HIP) return r;
+        if (r && !first) first = r;
     }
-    return VELLO_HIP_OK;
+    return first;
 }
 
 void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
@@ -731,8 +759,16 @@ int vello_hip_grow_pools(vello_hip_ctx *c, const vello_hip_bump *demand, vello_h
     int r = sync_all(c);
     if (r) return r;
     c->caps = d;
-    for (auto &l : c->lanes)
+    for (auto &l : c->lanes) {
         if ((r = alloc_lane_pools(c, l))) return r;
+        l.used = false;  // the frames rendered into the old pools are void; their failure has been acted upon
+    }
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_set_debug_flags(vello_hip_ctx *c, uint32_t flags) {
+    if (!c) return VELLO_HIP_E_INVALID;
+    c->debug_flags = flags;
     return VELLO_HIP_OK;
 }
 
@@ -754,15 +790,14 @@ int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, c
     for (int attempt = 0; attempt < 8; attempt++) {
         r = vello_hip_render_resident(c, params, out_is_device ? out_rgba8 : nullptr, out_stride);
         if (r) return r;
-        sync_r = vello_hip_sync(c);
-        if (sync_r != VELLO_HIP_E_CAPACITY || !c->auto_grow) break;
+        Lane &l = c->lanes[c->last_lane];
+        HIP_TRY(c, hipStreamSynchronize(l.stream));
         vello_hip_bump b;
-        if ((r = vello_hip_get_bump(c, &b))) return r;
+        HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
+        sync_r = check_lane(c, l);  // this frame's lane only: another lane's older failure is not this frame's
+        if (bump_out) *bump_out = b;
+        if (sync_r != VELLO_HIP_E_CAPACITY || !c->auto_grow) break;
         if (vello_hip_grow_pools(c, &b, nullptr) != VELLO_HIP_OK) break;
-    }
-    if (bump_out) {
-        int br = vello_hip_get_bump(c, bump_out);
-        if (br) return br;
     }
     if (sync_r) return sync_r;
     if (out_rgba8 && !out_is_device) {

@@ -46,8 +46,12 @@ __device__ __forceinline__ Path load_path(const Path *__restrict__ paths, uint32
     return r;
 }
 
-__device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths) {
+__device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths, uint32_t n_paths) {
     LineWalk w = {};
+    // A tag stream with more PATH markers than the layout counts (only a hand-made stream: resolve appends its extra
+    // markers behind the last segment, resolve.rs:127-129) yields lines whose path has no Path record.  WebGPU reads
+    // zeros there (stride 0 -> no crossings, path_count.wgsl:112); HIP would read past paths[].
+    if (line.path_ix >= n_paths) return w;
     const float TILE_SCALE = 0.0625f;
     bool is_down = line.p1y >= line.p0y;
     vec2 xy0 = is_down ? v2(line.p0x, line.p0y) : v2(line.p1x, line.p1y);
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
             if (line_ix < n_lines) {
-                LineWalk w = setup_line_walk(load_line(lines, line_ix), paths);
+                LineWalk w = setup_line_walk(load_line(lines, line_ix), paths, cfg.layout.n_paths);
                 my_total += w.imax - w.imin;
             }
         }
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
             LineWalk w = {};
-            if (line_ix < n_lines) w = setup_line_walk(load_line(lines, line_ix), paths);
+            if (line_ix < n_lines) w = setup_line_walk(load_line(lines, line_ix), paths, cfg.layout.n_paths);
             const uint32_t count = w.valid ? w.imax - w.imin : 0u;
             const int32_t delta = w.is_down ? -1 : 1;
             // every tile index below is bounded by the buffer explicitly (WebGPU does that for the reference): with

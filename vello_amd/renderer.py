@@ -48,12 +48,22 @@ def _caps(capacities):
     return ctypes.byref(c)
 
 
-def _data_ptr(texture):
-    """Accepts a numpy array (host) or a torch tensor (host or device)."""
+def _data_ptr(texture, width=None, height=None):
+    """Accepts a numpy array (host) or a torch tensor (host or device): dense uint8 rows of `width` RGBA8 pixels.
+    With width / height given, the buffer must hold the whole target (the engine writes height * width * 4 bytes)."""
     if isinstance(texture, np.ndarray):
-        assert texture.dtype == np.uint8 and texture.flags["C_CONTIGUOUS"]
-        return texture.ctypes.data, False
-    return texture.data_ptr(), bool(texture.is_cuda)
+        if texture.dtype != np.uint8 or not texture.flags["C_CONTIGUOUS"]:
+            raise ValueError("target must be a C-contiguous uint8 array")
+        nbytes, ptr, is_dev = texture.nbytes, texture.ctypes.data, False
+    else:
+        import torch
+
+        if texture.dtype != torch.uint8 or not texture.is_contiguous():
+            raise ValueError("target must be a contiguous torch.uint8 tensor")
+        nbytes, ptr, is_dev = texture.numel(), texture.data_ptr(), bool(texture.is_cuda)
+    if width is not None and nbytes < int(width) * int(height) * 4:
+        raise ValueError(f"target holds {nbytes} bytes, a {width}x{height} RGBA8 frame needs {int(width) * int(height) * 4}")
+    return ptr, is_dev
 
 
 class Renderer:
@@ -76,7 +86,7 @@ class Renderer:
         self._h = None
 
     def render_to_texture(self, scene, texture, params):
-        ptr, is_dev = _data_ptr(texture)
+        ptr, is_dev = _data_ptr(texture, params.width, params.height)
         stride = params.width * 4
         r = self._lib.vh_renderer_render_to_texture(self._h, scene._h, ptr, stride, 1 if is_dev else 0, params.width,
                                                     params.height, params.base_color._ptr(), int(params.antialiasing_method))
@@ -150,7 +160,7 @@ class Engine:
         p = self._params(width, height, base_color, aa)
         ptr, stride = None, 0
         if out is not None:
-            ptr, is_dev = _data_ptr(out)
+            ptr, is_dev = _data_ptr(out, width, height)
             assert is_dev, "render_frame writes to device memory"
             stride = width * 4
         rp, nr = None, 0
@@ -164,7 +174,7 @@ class Engine:
         p = self._params(width, height, base_color, aa)
         ptr, stride = None, 0
         if out is not None:
-            ptr, is_dev = _data_ptr(out)
+            ptr, is_dev = _data_ptr(out, width, height)
             assert is_dev, "render_resident writes to device memory"
             stride = width * 4
         self._check(self._lib.vello_hip_render_resident(self._h, ctypes.byref(p), ptr, stride), "render_resident")
@@ -198,6 +208,10 @@ class Engine:
 
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
+
+    def set_debug_flags(self, no_cull=False):
+        """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments)."""
+        self._check(self._lib.vello_hip_set_debug_flags(self._h, 1 if no_cull else 0), "set_debug_flags")
 
     def set_frames_in_flight(self, n):
         self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
