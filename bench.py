@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Benchmark of the hot path: frames/s on the paris-30k-like scene, 1600x1600, MSAA16 (BASELINE config C3).
+"""Benchmark of the hot path: frames/s on paris-30k-like scenes, 1600x1600, MSAA16 (BASELINE config C3).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -8,18 +8,25 @@ A "step" is one full pass of the pipeline (pathtag scan ... fine) over one resid
 one RGBA8 frame in device memory.  With N > 1 every rank renders its own independent scene (seeds
 0x5EED0001 + rank: weak scaling, no data-path collective) and each step ends with the ONE exchange the path
 has: the gather of the finished frames to rank 0 over RCCL/xGMI.  The scene bytes are resident in HBM before
-the timed region (PCIe-inclusive numbers are in DESIGN.md).
+the timed region (the PCIe-inclusive rates are reported in `config`, never as `value`).
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic bytes of that stage
-(DESIGN.md "algorithmic bytes") / its mean launch duration measured with HIP events on the engine's stream
-inside the timed region (with --in-flight > 1 the kernels of neighbouring frames share the CUs during that
-launch; `avg_launch_ms_isolated`/`achieved_isolated` repeat the measurement with one frame at a time).
-`cpu_baseline` times the CPU oracle (a port of the reference's CPU shaders +
-fine.wgsl, single thread) on a bounded sample of the same workload on rank 0 at N=1.
+Workloads (both SYNTHETIC: the real paris-30k.svg is not in the reference tree):
+  d2      the scene SURVEY.md 8d d2 fixes for C3: 70 % stroked polylines / 25 % polygons / 5 % cubic blobs, steps
+          4-40 px (workloads.paris_like_scene_d2).  It needs pools beyond the reference's fixed sizes (D2_CAPS).
+          This is the workload of `value`.
+  r1mix   round 1's stroke-light mix sized for the reference's own pools (workloads.paris_like_scene), kept beside
+          it in config.secondary for continuity with BENCH_r01.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: SURVEY 8d d4's per-stage terms evaluated with
+the frame's own bump counters / its launch duration measured with HIP events on the engine's stream, ONE FRAME AT
+A TIME (isolated: `frac`), and with --in-flight frames sharing the CUs (`frac_overlapped`, context only).
+`frame_algorithmic_bytes` is d4's single formula.  `cpu_baseline` times the CPU oracle (a C port of the reference's
+CPU shaders + fine.wgsl) on a bounded sample of the same workload on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,8 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 # Frames in flight run on one HIP stream each; the ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
-# queues (default 4) and streams that share a queue serialise (measured: 4 frames in flight on 4 queues = 2229
-# frames/s, 3 = 2769, 6 on 8 queues = 3040).  Must be set before the runtime initialises.
+# queues (default 4) and streams that share a queue serialise.  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -39,28 +45,314 @@ WIDTH = HEIGHT = 1600
 BASE_COLOR = 0xFFFFFFFF
 SEED0 = 0x5EED0001
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+# pools for the d2 scene (elements; vello_hip_capacities).  Its demand: 3.06 M lines, 4.28 M crossings / segments,
+# 9.98 M path tiles, 7.35 M dynamic PTCL words -- beyond config.rs:401-408's 2^21 / 2^21 / 2^21 / 2^23.
+THREADED_STAGES = "fine (tile-parallel); the other stages run on one thread"
+D2_CAPS = {"lines": 1 << 22, "tiles": 1 << 24, "seg_counts": 1 << 23, "segments": 1 << 23, "ptcl": 3 << 22}
 
 
-def stage_bytes(layout, bump, n_tag_words, scene_len, width, height, ptcl_words):
-    """Algorithmic HBM bytes per stage for one frame (each buffer written once, read once per consumer;
-    SURVEY.md 8d d4, split per kernel in DESIGN.md)."""
+def stage_bytes(layout, bump, n_tag_words, width, height, ptcl_words):
+    """Algorithmic HBM bytes per stage for one frame: the terms of SURVEY.md 8d d4 assigned to the kernel that moves
+    them (each buffer written once, read once per consumer); the sum differs from d4's single figure only by the
+    packed scene (S vs the parts the stages read) and is printed separately."""
     P, D = layout.n_paths, layout.n_draw_objects
     L, A, C, G, Bd = bump["lines"], bump["tile"], bump["seg_counts"], bump["segments"], bump["binning"]
     K = layout.n_clips
     Tw = n_tag_words
     path_data = (layout.draw_tag_base - layout.path_data_base) * 4
     return {
-        "pathtag_scan": 4 * Tw + 20 * Tw + 16 * P,
-        "flatten": (4 * Tw + 20 * Tw + path_data) + 24 * L + 24 * P,   # single pass: tags, monoids, path data read once
-        "draw_scan": 4 * D + 24 * D + 16 * D + 4 * D,
-        "clip": 8 * K + 24 * K + 16 * K + 16 * K,
-        "binning": 16 * D + 24 * D + 16 * D + 4 * Bd,
-        "tile_alloc": 4 * D + 16 * D + 32 * D + 8 * A,
-        "path_count": 2 * 24 * L + 16 * C + 8 * C,   # lines read twice, tile RMW per crossing, SegmentCount written
-        "backdrop": 32 * D + 16 * A,
-        "coarse": 4 * Bd + 2 * 8 * A + 4 * ptcl_words + 4 * A,
-        "path_tiling": 8 * C + 24 * C + 8 * C + 24 * G,
-        "fine": 4 * ptcl_words + 24 * G + 4 * width * height,
+        "pathtag_scan": 4 * Tw + 20 * Tw + 24 * P,                      # tags r, monoids w, bbox clear
+        "flatten": 4 * Tw + 20 * Tw + path_data + 24 * L + 24 * P,      # tags, monoids, path data r; lines w; bbox RMW
+        "draw_scan": 4 * D + 16 * D + 8 * D + 24 * P,                   # tags r, monoids w, info w, bbox r
+        "clip": 64 * K,
+        "binning": 16 * D + 24 * P + 16 * D + 4 * D + 4 * Bd,           # monoids, bbox r; draw_bbox w; tags; bin_data w
+        "tile_alloc": 4 * D + 16 * D + 32 * D + 8 * A,                  # tags, draw_bbox r; Path w; tiles zeroed
+        "path_count": 24 * L + 16 * C + 8 * C,                          # lines r; tile RMW per crossing; SegmentCount w
+        "backdrop": 32 * D + 16 * A,                                    # Path r; tile backdrop r + w
+        "coarse": 4 * Bd + 16 * D + 32 * D + 8 * A + 4 * A + 4 * ptcl_words,   # bin_data, monoids, Path, tiles r; seg_ix w; PTCL w
+        "path_tiling": 8 * C + 24 * C + 8 * C + 24 * G,                 # SegmentCount r; line gather; tile r; segments w
+        "fine": 4 * ptcl_words + 24 * G + 4 * width * height,           # PTCL r, segments r, RGBA8 w
+    }
+
+
+def d4_frame_bytes(scene_len, layout, bump, n_tag_words, width, height, ptcl_words):
+    """SURVEY.md 8d d4, verbatim: bytes = S + 48 Tw + 96 P + 168 D + 8 Bd + 48 L + 36 A + 48 C + 48 G + 8 Wp + 4 Npx."""
+    return (scene_len + 48 * n_tag_words + 96 * layout.n_paths + 168 * layout.n_draw_objects + 8 * bump["binning"] + 48 * bump["lines"]
+            + 36 * bump["tile"] + 48 * bump["seg_counts"] + 48 * bump["segments"] + 8 * ptcl_words + 4 * width * height)
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+
+
+def measure_copy_peak(device):
+    """Device-to-device float4 copy of 1 GiB on this GPU, this run: bytes read + written / time."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.zero_()
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 0.0
+    for _ in range(5):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del a, b
+    return best
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return None
+
+
+class Workload:
+    def __init__(self, key, rank):
+        import workloads
+
+        self.key = key
+        if key == "d2":
+            self.scene = workloads.paris_like_scene_d2(SEED0 + rank)
+            self.caps = dict(D2_CAPS)
+            self.mix = "70 % stroked open polylines (width 0.5-4 px, 8-60 vertices, step 4-40 px) / 25 % filled polygons / 5 % cubic blobs (SURVEY 8d d2)"
+        else:
+            self.scene = workloads.paris_like_scene(SEED0 + rank)
+            self.caps = None
+            self.mix = "16 % stroked polylines (width 0.5-3 px, step 1.5-7 px) / 81 % filled polygons / 3 % cubic blobs (round 1's mix, fits config.rs:401-408)"
+        self.packed, self.layout = self.scene.resolve()
+        self.n_tag_words = self.layout.path_data_base - self.layout.path_tag_base
+
+    def describe(self, engine):
+        caps = engine.capacities()
+        return (f"paris-30k-like SYNTHETIC scene '{self.key}' (real paris-30k.svg is not in the reference tree), seed 0x{SEED0:X}+rank, "
+                f"{self.layout.n_paths} paths: {self.mix}; {self.n_tag_words * 4} path tags, {self.packed.nbytes / 1e6:.2f} MB packed encoding, "
+                f"{WIDTH}x{HEIGHT}, MSAA16; pools (elements): " + ", ".join(f"{k} {v}" for k, v in caps.items()))
+
+
+def run_workload(wl, args, rank, local_rank, world, timed_headline):
+    """Uploads the scene and measures it.  For the headline workload the timed region is the contract's: exactly
+    args.steps steps between barrier + synchronize on both sides."""
+    import vello_amd
+    from vello_amd.distributed import FramePipeline, gather_frames
+
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+    dev = f"cuda:{local_rank}"
+    engine = vello_amd.Engine(device=local_rank, capacities=wl.caps)
+    engine.upload_scene(wl.packed, wl.layout)
+    aa = vello_amd.AaConfig.Msaa16
+    nif = max(1, min(args.in_flight, 8))
+    engine.set_frames_in_flight(nif)
+    ring = [torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev) for _ in range(nif)]
+    frame = ring[0]
+    gathered = [torch.zeros_like(frame) for _ in range(world)] if (distributed and rank == 0) else None
+    steps = args.steps if timed_headline else max(20, args.steps // 2)
+
+    def exchange(slot):
+        gather_frames(ring[slot], rank, world, dst=0, out=gathered)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    done_events = []
+
+    def render(slot):
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[slot])
+        if done_events is not None and len(done_events) < 4096:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.ExternalStream(engine.stream(), device=dev))
+            done_events.append(ev)
+
+    pipe = FramePipeline(nif, render=render, wait_frame=engine.sync_frame, exchange=exchange if distributed else None,
+                         wait_exchange=lambda ev: ev.synchronize())
+
+    # warm-up, with every stage under HIP events to find the dominant kernel
+    engine.set_profiling(vello_amd.renderer.STAGES)
+    for _ in range(max(args.warmup, 1)):
+        pipe.step()
+    pipe.flush()
+    torch.cuda.synchronize()
+    rc = engine.sync()
+    if rc != 0:
+        raise SystemExit(f"frame failed: {rc} {engine.bump()}")
+    warm_ms = engine.stage_ms()
+    bump = engine.bump()
+    dominant = max(warm_ms, key=lambda k: warm_ms[k][0] / max(warm_ms[k][1], 1))
+
+    # timed region: exactly K steps, events only around the dominant kernel (+ one completion event per frame)
+    engine.set_profiling([dominant])
+    done_events.clear()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.step()
+    pipe.flush()
+    rc = engine.sync()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit(f"frame failed in the timed region: {rc} {engine.bump()}")
+    dom_ms, dom_n = engine.stage_ms()[dominant]
+    # completion-to-completion intervals of consecutive frames (they finish in order: each lane's stream is a queue of
+    # whole frames and the lanes rotate)
+    intervals = []
+    for a, b in zip(done_events[:-1], done_events[1:]):
+        try:
+            intervals.append(a.elapsed_time(b))
+        except Exception:
+            pass
+    intervals = [x for x in intervals if x > 0]
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    own_fps = steps / elapsed
+
+    exchange_ms = None
+    if distributed and timed_headline:
+        # the exchange step on its own (SURVEY 8e: "report the gather time separately"): nothing else on the GPUs
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            gather_frames(ring[0], rank, world, dst=0, out=gathered)
+        torch.cuda.synchronize()
+        dist.barrier()
+        exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
+
+    # one frame at a time: frame latency (host clock around render + wait) and the isolated per-kernel durations
+    n_serial = 0 if args.timed_only else min(max(steps, 20), 200)
+    engine.set_profiling([])
+    done_events = None
+    serial = []
+    for _ in range(n_serial):
+        t1 = time.perf_counter()
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync_frame(0)
+        serial.append((time.perf_counter() - t1) * 1e3)
+    engine.set_profiling(vello_amd.renderer.STAGES)
+    for _ in range(min(n_serial, 50)):
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync_frame(0)
+    engine.sync()
+    all_ms = engine.stage_ms()
+    engine.set_profiling([])
+    if args.timed_only:
+        all_ms = {k: (0.0, 0) for k in vello_amd.renderer.STAGES}
+        all_ms[dominant] = (dom_ms, dom_n)
+
+    # PCIe-inclusive rates (never `value`): the packed scene starts in host memory every frame.
+    pcie_fps = pcie_pipelined_fps = None
+    if timed_headline and not args.timed_only:
+        n_pcie = 20
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_pcie):  # (a) serial: upload, render, wait -- what a blocking render_to_texture does
+            engine.upload_scene(wl.packed, wl.layout)
+            engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+            engine.sync()
+        pcie_fps = n_pcie / max(time.perf_counter() - t1, 1e-9)
+        n_pipe = 60  # (b) vello_hip_render_frame: the H2D copy of frame i+1 overlaps the kernels of the frames before it
+        for i in range(min(n_pipe, nif)):
+            engine.render_frame(wl.packed, wl.layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
+        engine.sync()
+        t1 = time.perf_counter()
+        for i in range(n_pipe):
+            engine.render_frame(wl.packed, wl.layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
+        engine.sync()
+        pcie_pipelined_fps = n_pipe / max(time.perf_counter() - t1, 1e-9)
+        engine.upload_scene(wl.packed, wl.layout)
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync()
+
+    ptcl_words = 64 * ((WIDTH + 15) // 16) * ((HEIGHT + 15) // 16) + bump["ptcl"]
+    sb = stage_bytes(wl.layout, bump, wl.n_tag_words, WIDTH, HEIGHT, ptcl_words)
+    frame_bytes = d4_frame_bytes(wl.packed.nbytes, wl.layout, bump, wl.n_tag_words, WIDTH, HEIGHT, ptcl_words)
+    iso_ms = all_ms[dominant][0] / max(all_ms[dominant][1], 1)
+    ovl_ms = dom_ms / max(dom_n, 1)
+    res = {
+        "engine": engine, "frame": frame, "steps": steps, "elapsed": elapsed, "own_fps": own_fps, "bump": bump, "dominant": dominant,
+        "exchange_ms": exchange_ms, "pcie_fps": pcie_fps, "pcie_pipelined_fps": pcie_pipelined_fps,
+        "describe": wl.describe(engine),
+        "frame_ms": {"median": pct(intervals, 0.5), "p10": pct(intervals, 0.1), "p90": pct(intervals, 0.9), "n": len(intervals)},
+        "serial_ms": {"median": pct(serial, 0.5), "p10": pct(serial, 0.1), "p90": pct(serial, 0.9), "n": len(serial)},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": f"k_{dominant}",
+            "achieved": round(sb[dominant] / (iso_ms * 1e-3) / 1e9, 2) if iso_ms > 0 else None,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(sb[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso_ms > 0 else None,
+            "algorithmic_bytes_per_launch": int(sb[dominant]),
+            "avg_launch_ms": round(iso_ms, 5),
+            "avg_launch_ms_overlapped": round(ovl_ms, 5),
+            "achieved_overlapped": round(sb[dominant] / (ovl_ms * 1e-3) / 1e9, 2) if ovl_ms > 0 else None,
+            "frac_overlapped": round(sb[dominant] / (ovl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ovl_ms > 0 else None,
+            "frame_algorithmic_bytes": int(frame_bytes),
+            "frame_algorithmic_formula": "SURVEY 8d d4: S + 48Tw + 96P + 168D + 8Bd + 48L + 36A + 48C + 48G + 8Wp + 4Npx",
+            "frame_achieved_GBps": round(frame_bytes / (elapsed / steps) / 1e9, 2),
+            "frame_frac": round(frame_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "frame_achieved_GBps_one_frame_at_a_time": round(frame_bytes / (pct(serial, 0.5) * 1e-3) / 1e9, 2) if serial else None,
+            "stage_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in all_ms.items()},
+            "stage_algorithmic_bytes": {k: int(v) for k, v in sb.items()},
+        },
+    }
+    return res
+
+
+def cpu_baseline(wl, frame):
+    """The CPU oracle on the same workload, bounded: ~10-25 s of CPU work.  Single thread, then THREADED_STAGES
+    threaded on every host core."""
+    from oracle.oracle import Oracle
+
+    o = Oracle(capacity_scale=8)
+    o.set_scene(wl.packed, wl.layout, WIDTH, HEIGHT, BASE_COLOR, 2)
+    t0 = time.perf_counter()
+    ref = o.render()  # also the warm-up
+    one = time.perf_counter() - t0
+    n_cpu = max(2, min(10, int(10.0 / max(one, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n_cpu):
+        ref = o.render()
+    cpu_s = (time.perf_counter() - t0) / n_cpu
+    same = bool(np.array_equal(ref, frame.cpu().numpy()))
+    n_thr = max(1, os.cpu_count() or 1)
+    o.set_threads(n_thr)
+    o.render()
+    n_mt = max(3, min(40, int(8.0 / max(cpu_s / min(n_thr, 16), 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n_mt):
+        ref_mt = o.render()
+    cpu_mt_s = (time.perf_counter() - t0) / n_mt
+    same_mt = bool(np.array_equal(ref_mt, ref))
+    cargo = None
+    try:
+        cargo = subprocess.check_output(["cargo", "--version"], stderr=subprocess.DEVNULL, timeout=10).decode().strip()
+    except Exception:
+        pass
+    return {
+        "value": round(1.0 / cpu_mt_s, 4),
+        "unit": "frames/s",
+        "cores": n_thr,
+        "value_single_thread": round(1.0 / cpu_s, 4),
+        "kind": "port",
+        "sample": f"{n_mt} full frames of the '{wl.key}' scene on {n_thr} threads (+ {n_cpu} on one thread): C restatement of "
+                  f"vello_shaders/src/cpu + fine.wgsl (NOT vello_cpu; cargo on this box: {cargo or 'absent'}); threaded stages: "
+                  f"{THREADED_STAGES}; output identical to the GPU frame: {same}; threaded == single-thread output: {same_mt}",
     }
 
 
@@ -71,6 +363,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--in-flight", type=int, default=6,
                     help="frames the engine keeps in flight (wgpu queues recordings the same way); 1 = serial frames")
+    ap.add_argument("--workload", choices=["both", "d2", "r1mix"], default="both",
+                    help="d2 = SURVEY 8d d2's C3 scene (the workload of `value`); r1mix = round 1's mix; both = d2 + r1mix beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the serial / PCIe / CPU passes (for rocprofv3 runs: every launch it sees is then a "
@@ -92,160 +386,62 @@ def main():
 
         dist.init_process_group("nccl")  # RCCL
 
-    import vello_amd
-    import workloads
+    head_key = "r1mix" if args.workload == "r1mix" else "d2"
+    head_wl = Workload(head_key, rank)
+    peak_measured = measure_copy_peak(f"cuda:{local_rank}") if rank == 0 else None
+    head = run_workload(head_wl, args, rank, local_rank, world, timed_headline=True)
+    second = None
+    if args.workload == "both" and not distributed and not args.timed_only:
+        head["engine"] = None  # free the first context's pools before the second one allocates
+        frame_head = head["frame"]
+        second_wl = Workload("r1mix", rank)
+        second = run_workload(second_wl, args, rank, local_rank, world, timed_headline=False)
+        second["engine"] = None
+    else:
+        frame_head = head["frame"]
 
-    scene = workloads.paris_like_scene(SEED0 + rank)
-    packed, layout = scene.resolve()
-    n_tag_words = layout.path_data_base - layout.path_tag_base
-    engine = vello_amd.Engine(device=local_rank)
-    engine.upload_scene(packed, layout)
-    aa = vello_amd.AaConfig.Msaa16
-    nif = max(1, min(args.in_flight, 8))
-    engine.set_frames_in_flight(nif)
-    # every in-flight frame owns its target (a swapchain of nif images)
-    ring = [torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(nif)]
-    frame = ring[0]
-    gathered = [torch.zeros_like(frame) for _ in range(world)] if (distributed and rank == 0) else None
-
-    from vello_amd.distributed import gather_frames
-
-    from vello_amd.distributed import FramePipeline
-
-    def exchange(slot):
-        gather_frames(ring[slot], rank, world, dst=0, out=gathered)
-        ev = torch.cuda.Event()
-        ev.record()
-        return ev
-
-    pipe = FramePipeline(
-        nif,
-        render=lambda slot: engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[slot]),
-        wait_frame=engine.sync_frame,                      # the frame is complete before its collective goes on torch's stream
-        exchange=exchange if distributed else None,
-        wait_exchange=lambda ev: ev.synchronize(),         # a slot is re-rendered only after its collective has read it
-    )
-    step, flush = pipe.step, pipe.flush
-
-    # warmup, with every stage under HIP events to find the dominant kernel
-    engine.set_profiling(vello_amd.renderer.STAGES)
-    for _ in range(max(args.warmup, 1)):
-        step()
-    flush()
-    torch.cuda.synchronize()
-    rc = engine.sync()
-    if rc != 0:
-        raise SystemExit(f"frame failed: {rc} {engine.bump()}")
-    warm_ms = engine.stage_ms()
-    bump = engine.bump()
-    dominant = max(warm_ms, key=lambda k: warm_ms[k][0] / max(warm_ms[k][1], 1))
-
-    # timed region: exactly K steps, events only around the dominant kernel
-    engine.set_profiling([dominant])
+    # per-rank frames/s (each rank's own clock over the same K steps), for the scaling record
+    per_rank = None
     if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    flush()
-    rc = engine.sync()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if rc != 0:
-        raise SystemExit(f"frame failed in the timed region: {rc} {engine.bump()}")
-    dom_ms, dom_n = engine.stage_ms()[dominant]
-    if distributed:
-        t = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # the exchange step on its own ("report the gather time separately"): nothing else on the GPUs
-    exchange_ms = None
-    if distributed:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            gather_frames(ring[0], rank, world, dst=0, out=gathered)
-        torch.cuda.synchronize()
-        dist.barrier()
-        exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
-
-    # serial-frame passes (separate, not part of `value`): one frame at a time gives the frame latency and
-    # the isolated per-kernel durations (no other frame's kernels sharing the CUs)
-    n_serial = 0 if args.timed_only else min(args.steps, 50)
-    engine.set_profiling([])
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(n_serial):
-        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
-        engine.sync_frame(0)
-    serial_ms = (time.perf_counter() - t1) / max(n_serial, 1) * 1e3
-    engine.set_profiling(vello_amd.renderer.STAGES)
-    for _ in range(n_serial):
-        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
-        engine.sync_frame(0)
-    engine.sync()
-    all_ms = engine.stage_ms()
-    engine.set_profiling([])
-
-    # PCIe-inclusive rates (never `value`): the packed scene starts in host memory every frame.
-    #  (a) serial: upload, render, wait -- what a blocking render_to_texture does;
-    #  (b) pipelined: vello_hip_render_frame puts each frame's scene into the next in-flight slot, so the H2D copy of
-    #      frame i+1 overlaps the kernels of the frames before it (animation form).
-    n_pcie = 0 if args.timed_only else 20
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(n_pcie):
-        engine.upload_scene(packed, layout)
-        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
-        engine.sync()
-    pcie_fps = n_pcie / max(time.perf_counter() - t1, 1e-9)
-    n_pipe = 0 if args.timed_only else 60
-    for i in range(min(n_pipe, nif)):  # warm the private scene slots (first use allocates)
-        engine.render_frame(packed, layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
-    engine.sync()
-    t1 = time.perf_counter()
-    for i in range(n_pipe):
-        engine.render_frame(packed, layout, WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[i % nif])
-    engine.sync()
-    pcie_pipelined_fps = n_pipe / max(time.perf_counter() - t1, 1e-9)
-    engine.upload_scene(packed, layout)  # back to the shared resident scene
-    if args.timed_only:
-        all_ms = {k: (0.0, 0) for k in vello_amd.renderer.STAGES}
-        all_ms[dominant] = (dom_ms, dom_n)
+        t = torch.zeros(world, device=f"cuda:{local_rank}", dtype=torch.float64)
+        t[rank] = head["own_fps"]
+        dist.all_reduce(t)
+        per_rank = [round(float(x), 2) for x in t.tolist()]
 
     if rank != 0:
         if distributed:
             dist.destroy_process_group()
         return
 
-    ptcl_words = 64 * ((WIDTH + 15) // 16) * ((HEIGHT + 15) // 16) + bump["ptcl"]
-    sb = stage_bytes(layout, bump, n_tag_words, packed.nbytes, WIDTH, HEIGHT, ptcl_words)
-    dom_avg_s = (dom_ms / max(dom_n, 1)) * 1e-3
-    achieved = sb[dominant] / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-    frame_bytes = sum(sb.values())
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
+    steps, elapsed = head["steps"], head["elapsed"]
+    ms_per_step = elapsed / steps * 1e3
+    value = world * steps / elapsed
+    dominant = head["dominant"]
 
     # HBM traffic of the dominant kernel from the PMC passes (collected separately, as the pool requires, by
-    # scripts/gpu_calib.sh; corrected with the factors calibrated in the same session)
-    traffic = None
+    # scripts/gpu_calib.sh; corrected with the factors calibrated in the same session; stamped with its commit)
+    traffic = traffic_commit = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            traffic = json.load(fh)["kernels"].get(f"k_{dominant}", {}).get("traffic_bytes")
+            tj = json.load(fh)
+        traffic = tj.get("workloads", {}).get(head_key, tj).get("kernels", {}).get(f"k_{dominant}", {}).get("traffic_bytes")
+        traffic_commit = tj.get("commit")
     except (OSError, ValueError):
         pass
 
+    roof = head["roofline"]
+    roof["peak_measured"] = round(peak_measured, 1) if peak_measured else None
+    roof["peak_measured_how"] = "torch device-to-device copy of 1 GiB on this GPU in this run, read + written bytes / best of 5"
+    roof["traffic"] = traffic
+    roof["traffic_source"] = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, "
+                              f"collected at commit {traffic_commit})")
+    serial_med = head["serial_ms"]["median"]
     result = {
         "metric": "frames/sec paris-30k 1600x1600 MSAA16; scenes/sec at 1/2/4/8 GPU",
         "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
-        "steps": args.steps,
+        "steps": steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
@@ -254,70 +450,39 @@ def main():
         "dtype": "f32+u32",
         "data": "synthetic",
         "config": {
-            "workload": "paris-30k-like SYNTHETIC scene (real paris-30k.svg is not in the reference tree), "
-                        f"seed 0x{SEED0:X}+rank, {layout.n_paths} paths, {n_tag_words * 4} path tags, "
-                        f"{packed.nbytes / 1e6:.2f} MB packed encoding, {WIDTH}x{HEIGHT}, MSAA16",
+            "workload": head["describe"],
             "baseline_config": "configs[2]",
+            "commit": git_head(),
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
-            "exchange_alone_ms": None if exchange_ms is None else round(exchange_ms, 4),
-            "bump": bump,
-            "frames_in_flight": nif,
+            "exchange_alone_ms": None if head["exchange_ms"] is None else round(head["exchange_ms"], 4),
+            "per_rank_frames_per_s": per_rank,
+            "bump": head["bump"],
+            "frames_in_flight": max(1, min(args.in_flight, 8)),
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-            "serial_frame_latency_ms": round(serial_ms, 4),
-            "pcie_inclusive_frames_per_s": round(pcie_fps, 2),
-            "pcie_inclusive_pipelined_frames_per_s": round(pcie_pipelined_fps, 2),
+            "frame_ms_pipelined": head["frame_ms"],
+            "frame_ms_one_at_a_time": head["serial_ms"],
+            "value_one_frame_at_a_time": round(1e3 / serial_med, 2) if serial_med else None,
+            "pcie_inclusive_frames_per_s": None if head["pcie_fps"] is None else round(head["pcie_fps"], 2),
+            "pcie_inclusive_pipelined_frames_per_s": None if head["pcie_pipelined_fps"] is None else round(head["pcie_pipelined_fps"], 2),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": f"k_{dominant}",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "peak_measured": 6290.0,  # float4 copy on this part (MI355X_MICROARCH.md), for reference
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic,
-            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
-            "algorithmic_bytes_per_launch": int(sb[dominant]),
-            "avg_launch_ms": round(dom_avg_s * 1e3, 5),
-            "avg_launch_ms_isolated": round(all_ms[dominant][0] / max(all_ms[dominant][1], 1), 5),
-            "achieved_isolated": round(sb[dominant] / (all_ms[dominant][0] / max(all_ms[dominant][1], 1) * 1e-3) / 1e9, 2),
-            "frame_algorithmic_bytes": int(frame_bytes),
-            "frame_achieved_GBps": round(frame_bytes / (elapsed / args.steps) / 1e9 * (1 if not distributed else 1), 2),
-            "stage_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in all_ms.items()},
-        },
+        "roofline": roof,
     }
-
-    if world == 1 and not args.no_cpu_baseline and not args.timed_only:
-        from oracle.oracle import Oracle
-
-        o = Oracle()
-        o.set_scene(packed, layout, WIDTH, HEIGHT, BASE_COLOR, int(aa))
-        o.render()  # warm
-        n_cpu = 12  # ~10 s of single-thread CPU work + ~3 s with the fine stage threaded
-        t0 = time.perf_counter()
-        for _ in range(n_cpu):
-            ref = o.render()
-        cpu_s = (time.perf_counter() - t0) / n_cpu
-        same = bool(np.array_equal(ref, frame.cpu().numpy()))
-        # the same oracle with its tile-parallel fine stage on up to 64 threads (the other stages stay serial)
-        n_thr = max(1, min(os.cpu_count() or 1, 64))
-        o.set_threads(n_thr)
-        o.render()
-        t0 = time.perf_counter()
-        for _ in range(n_cpu):
-            o.render()
-        cpu_mt_s = (time.perf_counter() - t0) / n_cpu
-        result["cpu_baseline"] = {
-            "value": round(1.0 / cpu_s, 4),
-            "unit": "frames/s",
-            "cores": 1,
-            "value_fine_threaded": round(1.0 / cpu_mt_s, 4),
-            "cores_fine_threaded": n_thr,
-            "kind": "port",
-            "sample": f"{n_cpu} full frames of the same scene (C restatement of vello_shaders/src/cpu + fine.wgsl, "
-                      f"single thread, {os.cpu_count()} host cores present); output identical to GPU frame: {same}",
+    if second is not None:
+        smed = second["serial_ms"]["median"]
+        result["config"]["secondary"] = {
+            "workload": second["describe"],
+            "value": round(second["steps"] / second["elapsed"], 2),
+            "steps": second["steps"],
+            "ms_per_step": round(second["elapsed"] / second["steps"] * 1e3, 4),
+            "value_one_frame_at_a_time": round(1e3 / smed, 2) if smed else None,
+            "frame_ms_pipelined": second["frame_ms"],
+            "frame_ms_one_at_a_time": second["serial_ms"],
+            "bump": second["bump"],
+            "roofline": second["roofline"],
         }
+    if world == 1 and not args.no_cpu_baseline and not args.timed_only:
+        result["cpu_baseline"] = cpu_baseline(head_wl, frame_head)
     print(json.dumps(result))
     if distributed:
         dist.destroy_process_group()

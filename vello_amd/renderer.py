@@ -216,6 +216,10 @@ class Engine:
     def set_frames_in_flight(self, n):
         self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
 
+    def stream(self):
+        """vello_hip_get_stream: the hipStream_t (as an int) of the lane that rendered the newest frame."""
+        return int(self._lib.vello_hip_get_stream(self._h) or 0)
+
     def sync_frame(self, age=0):
         self._check(self._lib.vello_hip_sync_frame(self._h, age), "sync_frame")
 

@@ -118,6 +118,61 @@ def paris_like_scene(seed=0x5EED0001, n_paths=30000, size=1600.0, stroke_frac=0.
     return s
 
 
+def paris_like_scene_d2(seed=0x5EED0001, n_paths=30000, size=1600.0):
+    """C3 exactly as SURVEY.md 8d d2 restates it ("paris-30k-like", SYNTHETIC): 30 000 paths on a 1600x1600 canvas,
+    70 % stroked open polylines (width log-uniform 0.5-4 px, 8-60 vertices, step length 4-40 px drawn once per
+    polyline, heading random walk sigma = 0.4 rad), 25 % filled closed polygons (6-40 vertices, radius 5-60 px,
+    NonZero), 5 % filled cubic blobs; 16 opaque palette colours; kurbo's default stroke style (round joins and caps,
+    miter limit 4: an assumption, kurbo is not in the reference tree).  The survey names PCG32; the generator is
+    numpy's PCG64 with the survey's seed (0x5EED0001 + GPU rank for C5).  Unlike paris_like_scene this one does NOT
+    fit the reference's fixed pools (config.rs:401-408: 2^21 lines / crossings / segments): it needs
+    D2_CAPACITIES (vello_hip_capacities), which is what robust dynamic memory (8f f4) exists for."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    s = Scene()
+    ident = Affine.IDENTITY
+    kinds = rng.random(n_paths)
+    for i in range(n_paths):
+        col = PALETTE[int(rng.integers(0, len(PALETTE)))]
+        k = kinds[i]
+        if k < 0.70:
+            n = int(rng.integers(8, 61))
+            step = rng.uniform(4.0, 40.0)
+            heading = rng.uniform(0, 2 * math.pi) + np.cumsum(rng.normal(0.0, 0.4, n))
+            x0, y0 = rng.uniform(0, size, 2)
+            pts = np.empty((n, 2))
+            pts[:, 0] = x0 + np.cumsum(np.cos(heading) * step)
+            pts[:, 1] = y0 + np.cumsum(np.sin(heading) * step)
+            width = math.exp(rng.uniform(math.log(0.5), math.log(4.0)))
+            s.stroke(Stroke(width), ident, col, None, _polyline(pts, False))
+        elif k < 0.95:
+            n = int(rng.integers(6, 41))
+            r = rng.uniform(5.0, 60.0)
+            cx, cy = rng.uniform(0, size, 2)
+            ang = np.sort(rng.uniform(0, 2 * math.pi, n))
+            rr = r * rng.uniform(0.7, 1.0, n)
+            pts = np.stack([cx + rr * np.cos(ang), cy + rr * np.sin(ang)], axis=1)
+            s.fill(Fill.NonZero, ident, col, None, _polyline(pts, True))
+        else:
+            n = int(rng.integers(4, 13))
+            r = rng.uniform(10.0, 60.0)
+            cx, cy = rng.uniform(0, size, 2)
+            ang = np.linspace(0, 2 * math.pi, n, endpoint=False) + rng.uniform(0, 1)
+            rr = r * rng.uniform(0.7, 1.0, n)
+            px, py = cx + rr * np.cos(ang), cy + rr * np.sin(ang)
+            verbs = [MOVE_TO]
+            coords = [px[0], py[0]]
+            for j in range(n):
+                a, b = j, (j + 1) % n
+                t = 0.55 * r * (2 * math.pi / n) / 1.5
+                c1 = (px[a] - t * math.sin(ang[a]), py[a] + t * math.cos(ang[a]))
+                c2 = (px[b] + t * math.sin(ang[b]), py[b] - t * math.cos(ang[b]))
+                verbs.append(CURVE_TO)
+                coords.extend([c1[0], c1[1], c2[0], c2[1], px[b], py[b]])
+            verbs.append(CLOSE_PATH)
+            s.fill(Fill.NonZero, ident, col, None, BezPath.from_arrays(verbs, coords))
+    return s
+
+
 _MMARK_COLORS = [Color.from_rgb8(*c) for c in [(0x10, 0x10, 0x10), (0x80, 0x80, 0x80), (0xc0, 0xc0, 0xc0), (0x10, 0x10, 0x10),
                                                (0x80, 0x80, 0x80), (0xc0, 0xc0, 0xc0), (0xe0, 0x10, 0x40)]]
 _OFFSETS = [(-4, 0), (2, 0), (1, -2), (1, 2)]
