@@ -184,6 +184,21 @@ def test_config_c3_paris_like_full_size(gpu_engine):
     assert (img[:, :, 3] == 255).all()  # opaque base + opaque paints
 
 
+def test_config_c3_d2_scene_full_size(built):
+    # BASELINE config C3 as SURVEY 8d d2 restates it (70 % stroked polylines / 25 % polygons / 5 % blobs, steps
+    # 4-40 px): 3.06 M lines, 4.28 M crossings -- beyond the reference's fixed pools, so the context is created with
+    # bench.py's D2_CAPS.  Every intermediate incl. bin lists, SegmentCounts, PTCL and segment slices vs the oracle.
+    import bench
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    packed, layout = workloads.paris_like_scene_d2().resolve()
+    eng = vello_amd.Engine(device=0, capacities=bench.D2_CAPS)
+    img, ref, bump = compare_frame(eng, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, "gpu_paris_d2", oracle=Oracle(capacity_scale=8))
+    assert bump["failed"] == 0 and bump["lines"] > (1 << 21) and bump["seg_counts"] > (1 << 21)
+    assert (img[:, :, 3] == 255).all()
+
+
 def test_config_c4_mmark_reduced(gpu_engine):
     # mmark generator at a size the oracle finishes quickly (5k elements); binning stress at 2048^2
     packed, layout = workloads.mmark_scene(n=5000).resolve()
