@@ -40,6 +40,8 @@ struct DrawMonoid { uint32_t path_ix, clip_ix, scene_offset, info_offset; };
 struct Clip { uint32_t ix; int32_t path_ix; };
 struct BinHeader { uint32_t element_count, chunk_offset; };
 struct Bbox4 { float x0, y0, x1, y1; };
+// engine-internal (not a reference layout): what coarse needs of one draw object, gathered once by k_coarse_prep
+struct __attribute__((aligned(16))) CoarseEl { uint32_t tag, flags, w0, dd, di, tiles, bbox_x, bbox_y; };
 
 static_assert(sizeof(Config) == 88, "ConfigUniform");
 static_assert(sizeof(Bump) == 32, "BumpAllocators");
@@ -50,6 +52,7 @@ static_assert(sizeof(Segment) == 24, "PathSegment");
 static_assert(sizeof(Path) == 32, "Path");
 static_assert(sizeof(Tile) == 8, "Tile");
 static_assert(sizeof(DrawMonoid) == 16, "DrawMonoid");
+static_assert(sizeof(CoarseEl) == 32, "CoarseEl");
 
 // ---------------- constants ----------------
 constexpr uint32_t TILE_WIDTH = 16, TILE_HEIGHT = 16, N_TILE_X = 16, N_TILE_Y = 16, N_TILE = 256;

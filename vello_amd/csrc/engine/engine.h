@@ -62,6 +62,9 @@ struct Frame {
     Segment *segments;
     uint32_t *ptcl;
     uint32_t *blend_spill;
+    CoarseEl *coarse_el;     // coarse: one record per draw object (k_coarse_prep)
+    uint32_t *tile_bits;     // coarse: three bit planes over the tile pool (segments present / backdrop zero / backdrop even)
+    uint32_t tile_bits_plane_words;
     uint32_t *clip_stack;  // spill area for clip stacks deeper than the LDS window
     uint8_t *output;
     size_t out_stride;

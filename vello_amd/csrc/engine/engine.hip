@@ -52,6 +52,8 @@ struct Lane {
     DevBuf buf[VELLO_HIP_BUF_COUNT];  // SCENE / CONFIG entries unused (shared, see ctx)
     DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
     DevBuf clip_stack;
+    DevBuf coarse_el;                 // coarse: CoarseEl per draw object
+    DevBuf tile_bits;                 // coarse: 3 bit planes over the tile pool
     DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
     struct EvPair {
         int stage;
@@ -125,6 +127,9 @@ int sync_all(vello_hip_ctx *c) {
     return 0;
 }
 
+// words of one coarse bit plane: 2 per 64 tiles + 2 of slack for the 64-bit windows read at the last tiles
+uint32_t tile_bits_plane_words(uint32_t tiles) { return (tiles + 63u) / 64u * 2u + 2u; }
+
 // pool-capacity buffers of one lane (reference sizes: config.rs:398-408)
 int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     const vello_hip_capacities &d = c->caps;
@@ -137,6 +142,7 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_SEGMENTS], (size_t)d.segments * sizeof(Segment)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
+    if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_plane_words(d.tiles) * 3u * 4u))) return r;
     return 0;
 }
 
@@ -157,6 +163,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
+    if ((r = ensure(c, l.coarse_el, (size_t)(L.n_draw_objects + 1u) * sizeof(CoarseEl)))) return r;
     if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 32u))) return r;  // 2 lists x 4 tags per word x u32
     return 0;
 }
@@ -170,6 +177,10 @@ int configure(vello_hip_ctx *c, const SceneSlot &sc, const vello_hip_render_para
     if (((c->aa_mask >> p->aa) & 1u) == 0u) {
         // render.rs:566-568, :593-598: "shaders not configured to support AA mode"
         c->last_error = "AA mode was not enabled in vello_hip_create(aa_mask)";
+        return VELLO_HIP_E_INVALID;
+    }
+    if (p->width > 0xffffu * TILE_WIDTH || p->height > 0xffffu * TILE_HEIGHT) {
+        c->last_error = "target larger than 65535 tiles in one dimension";  // coarse packs tile coordinates in 16 bits
         return VELLO_HIP_E_INVALID;
     }
     std::memset(&cfg, 0, sizeof cfg);
@@ -260,6 +271,9 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.ptcl = (uint32_t *)l.buf[VELLO_HIP_BUF_PTCL].ptr;
     f.blend_spill = (uint32_t *)l.buf[VELLO_HIP_BUF_BLEND_SPILL].ptr;
     f.clip_stack = (uint32_t *)l.clip_stack.ptr;
+    f.coarse_el = (CoarseEl *)l.coarse_el.ptr;
+    f.tile_bits = (uint32_t *)l.tile_bits.ptr;
+    f.tile_bits_plane_words = tile_bits_plane_words(c->caps.tiles);
     f.heavy_list = (uint32_t *)l.heavy_list.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
@@ -454,6 +468,8 @@ void vello_hip_destroy(vello_hip_ctx *c) {
             if (l.buf[i].ptr && i != VELLO_HIP_BUF_BUMP) (void)hipFree(l.buf[i].ptr);
         if (l.zero_region.ptr) (void)hipFree(l.zero_region.ptr);
         if (l.clip_stack.ptr) (void)hipFree(l.clip_stack.ptr);
+        if (l.coarse_el.ptr) (void)hipFree(l.coarse_el.ptr);
+        if (l.tile_bits.ptr) (void)hipFree(l.tile_bits.ptr);
         if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
