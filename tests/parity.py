@@ -289,10 +289,6 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
                 bd_ok = False
                 break
         assert bd_ok, f"{name}: tile backdrops differ (path {i})"
-        # back_half=False: scenes whose crossing indices leave f32's 24 bits / SegmentCount's 16 bits -- two records can
-        # then claim the same slot of a foreign tile and which one stays is the order of the stores
-        if back_half and bump["failed"] == 0 and ob["failed"] == 0:
-            compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=ramps, ref=ref)
     diff = np.abs(img.astype(np.int32) - ref.astype(np.int32))
     if not order_sensitive:
         if diff.max() > tol:
@@ -311,4 +307,11 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
         if order_sensitive and min_agree is not None:  # still require the two orders to agree almost everywhere
             frac = float((diff.max(axis=2) > tol).mean())
             assert frac <= 1.0 - min_agree, f"{name}: {frac:.2%} of the pixels differ by more than {tol} between the two segment orders"
+    # LAST (it renders once more, with culling off, and leaves that frame in the engine's buffers).
+    # back_half=False: scenes whose crossing indices leave f32's 24 bits / SegmentCount's 16 bits -- two records can
+    # then claim the same slot of a foreign tile and which one stays is the order of the stores
+    if check_stages and back_half and bump["failed"] == 0 and ob["failed"] == 0:
+        if tol > 0:
+            oracle.render()  # the same-order check overwrote the oracle's tiles / PTCL / segments with the engine's
+        compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=ramps, ref=ref)
     return img, ref, bump
