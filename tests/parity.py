@@ -181,7 +181,9 @@ def compare_back_half(engine, oracle, packed, layout, width, height, base_color,
     finally:
         engine.set_debug_flags(no_cull=False)
     ob = oracle.bump()
-    assert bump == ob, f"{name}: bump counters differ with culling off: hip {bump} oracle {ob}"
+    # bump.ptcl is the one counter that is not the reference's: the engine stores a tile's commands in exact-fit regions
+    # linked by CMD_JUMP instead of 256-word chunks (k_coarse); the command words themselves are diffed below
+    assert all(bump[k] == ob[k] for k in BUMP_KEYS if k != "ptcl"), f"{name}: bump counters differ with culling off: hip {bump} oracle {ob}"
     if bump["failed"] != 0:
         return {}
     L = layout
@@ -196,9 +198,8 @@ def compare_back_half(engine, oracle, packed, layout, width, height, base_color,
     compare_seg_counts(name, engine.read_buffer("seg_counts", np.uint32, n_sc * 8), engine.read_buffer("lines", np.uint32, n_lines * 24),
                        oracle.buffer("seg_counts", np.uint32), oracle.buffer("lines", np.uint32)[: n_lines * 6], n_sc)
     stats["seg_counts"] = n_sc
-    n_ptcl = 64 * n_tiles + ob["ptcl"]
-    ptcl_h = engine.read_buffer("ptcl", np.uint32, n_ptcl * 4)
-    ptcl_o = oracle.buffer("ptcl", np.uint32)[:n_ptcl]
+    ptcl_h = engine.read_buffer("ptcl", np.uint32, (64 * n_tiles + bump["ptcl"]) * 4)
+    ptcl_o = oracle.buffer("ptcl", np.uint32)[:64 * n_tiles + ob["ptcl"]]
     fh, fo, fn, stats["ptcl_words"] = walk_ptcl_pair(name, ptcl_h, ptcl_o, n_tiles)
     assert int(fn.sum()) == ob["segments"], f"{name}: CMD_FILLs cover {int(fn.sum())} segments, bump.segments {ob['segments']}"
     stats["segments"] = compare_segment_slices(name, engine.read_buffer("segments", np.uint32, ob["segments"] * 24),
@@ -241,7 +242,7 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
     exact = [k for k in BUMP_KEYS if k not in ("segments", "ptcl")]
     ok = all(bump[k] == ob[k] for k in exact) and bump["segments"] <= ob["segments"]
     if layout.n_clips != 0:
-        ok = ok and bump == ob
+        ok = ok and all(bump[k] == ob[k] for k in BUMP_KEYS if k != "ptcl")
     if not ok:
         _dump(name + "_bump", img=img, ref=ref)
     assert ok, f"{name}: bump counters differ: hip {bump} oracle {ob}"

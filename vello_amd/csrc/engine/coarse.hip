@@ -5,160 +5,59 @@
 // The reference runs one workgroup per 16x16-tile bin, one thread per tile; each batch of 256 draw objects of the
 // bin is merged from the bin lists, a coverage pass reads the Tile record of EVERY (draw object, tile-in-bbox) pair
 // into LDS bitmaps, and every thread then walks its tile's bits in draw order, bumping `bump.segments` once per
-// (tile, path) and `bump.ptcl` once per chunk.  On MI355X that shape is a few dozen workgroups (49 at 1600^2) of
-// dependent global-memory round trips on a 256-CU part, and the coverage pass reads the whole tile pool (a road map's
-// long thin paths allocate 10 M tiles of which a third hold anything).  What the stage computes is kept word for
-// word (per-tile draw order, the clip_zero_depth state machine, chunked PTCL with CMD_JUMP); how is new:
+// (tile, path) and `bump.ptcl` once per 256-word chunk.  On MI355X that shape is a few dozen workgroups (49 at
+// 1600^2) of serial, one-wave-per-SIMD instruction streams and dependent global round trips on a 256-CU part, and the
+// coverage pass reads the whole tile pool (a road map's long thin paths allocate 10 M tiles of which a third hold
+// anything).  What the stage computes is kept (the commands of every tile, word for word and in draw order, the
+// clip_zero_depth state machine, CMD_JUMP-linked storage); how is new:
 //
 //  * k_coarse_prep (one launch, two jobs by block range): (a) per draw object, everything coarse needs from five
 //    buffers (tag, draw flags, first draw-data word, offsets, the Path record) gathered ONCE into a 32-byte record --
 //    the reference re-gathers it per (bin, draw object); (b) per 64 tiles of the pool, three bit planes by wave
 //    ballot: has segments / backdrop == 0 / backdrop even -- all the coverage test needs (coarse.wgsl:318-341).
-//  * k_coarse: one WAVE (= one workgroup) per 8x8-tile quadrant of a bin: 4x the workgroups, no s_barrier, and a
-//    draw object is only considered by the quadrants its bbox touches.  Lanes first act as draw objects: the bin's list
-//    is streamed 256 entries at a time (entries prefetched one round ahead), survivors are queued in LDS and each
-//    gets its 64-bit coverage mask over the quadrant from <= 8 row windows of the bit planes (no Tile reads, no LDS
-//    atomics).  Then lanes act as tiles: per batch of <= 256 queued objects the masks are transposed into per-tile
-//    bitmaps, the Tile records of the INCLUDED pairs only are staged in LDS (8 loads in flight per lane), and the
-//    SIMULATE / EMIT double walk runs from LDS: SIMULATE totals the segments and PTCL chunks each tile needs, a shuffle
-//    scan turns them into offsets behind ONE atomic per counter and batch, EMIT writes.
+//  * k_coarse: one workgroup of four waves per 8x8-tile QUADRANT of a bin (4x the workgroups; a draw object is only
+//    considered by the quadrants its bbox touches).  Threads first act as draw objects: the bin's list is streamed
+//    256 entries at a time (entries prefetched one round ahead), survivors are queued in LDS and each gets its 64-bit
+//    coverage masks over the quadrant from <= 8 row windows of the bit planes (no Tile reads, no LDS atomics).
+//  * PTCL storage is EXACT-FIT: per batch of 256 queued objects a tile gets one region of exactly the words it needs
+//    (+ a two-word tail for the next CMD_JUMP / CMD_END, + slack for small follow-ups) instead of 256-word chunks grown
+//    on demand.  That turns every offset into a prefix sum: command sizes follow from popcounts of bitmaps, so wave w
+//    owns objects [64w, 64w + 64) of the batch and all four emit concurrently, one LANE PER (tile, object) PAIR --
+//    Tile record loaded by the lane that needs it, segment slices from a segmented shuffle scan -- behind ONE atomic
+//    per counter and batch.  The reference's per-tile walk survives only as a short sequential pre-pass over the clip
+//    objects of scenes that have clips (the clip_zero_depth machine is order dependent; everything else is not).
+//    fine follows CMD_JUMP wherever it points, so the command streams are the reference's, only the jump points move.
 //  * occlusion culling (not in the reference): when a batch holds, for a tile, a fully covering OPAQUE solid-colour
 //    draw (CMD_SOLID + CMD_COLOR with alpha 255) outside any clip/blend layer, premultiplied src-over makes everything
 //    underneath irrelevant bit-exactly (x*0 + c == c), so the tile's list is restarted at that draw and the covered
-//    draws of the batch are never emitted nor given segments.  Only for scenes without clips (the clip state machine
-//    must otherwise see every draw); VELLO_HIP_DEBUG_NO_CULL turns it off for word-exact PTCL / segment diffs.
+//    draws of the batch are never emitted nor given segments.  Only for scenes without clips;
+//    VELLO_HIP_DEBUG_NO_CULL turns it off for word-exact PTCL / segment diffs against the reference.
 #include "engine.h"
 
 namespace vk {
 
 namespace {
 
-constexpr uint32_t SUB_W = 8;        // a workgroup owns an 8x8-tile quadrant of a bin
-constexpr uint32_t NB = 256;         // draw objects per batch
-constexpr uint32_t N_SLICE = NB / 32;
-constexpr uint32_t RPL = 4;          // bin-list entries examined per lane and round
-constexpr uint32_t QCAP = 512;       // queue slots: NB - 1 left over + 64 * RPL new ones; power of two
-constexpr uint32_t KMAX = 32;        // Tile records staged in LDS per tile and batch (the rest is read from global memory)
-constexpr uint32_t PART_CHUNK = 256; // bin headers (partitions of 256 draw objects) merged at a time
+constexpr uint32_t SUB_W = 8;         // a workgroup owns an 8x8-tile quadrant of a bin
+constexpr uint32_t NW = 4;            // waves per workgroup; wave w emits objects [64w, 64w + 64) of a batch
+constexpr uint32_t WG = 64 * NW;
+constexpr uint32_t NB = 64 * NW;      // draw objects per batch
+constexpr uint32_t QCAP = 512;        // queue slots: NB - 1 left over + WG new ones; power of two
+constexpr uint32_t PART_CHUNK = 256;  // bin headers (partitions of 256 draw objects) merged at a time
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u;  // a tile's fixed block minus the blend word and the tail
+constexpr uint32_t REGION_SLACK = 62u;  // words a new region holds beyond the batch that asked for it
+// what a draw object emits per tile: a path command (CMD_FILL 4 words / CMD_SOLID 1) + a draw command of 2 or 3 words,
+// or CMD_BEGIN_CLIP alone (coarse.wgsl:377-450)
+constexpr uint32_t KIND_NONE = 0u, KIND_PATH2 = 1u, KIND_PATH3 = 2u, KIND_BEGIN = 3u;
 
-struct TileState {
-    uint32_t cmd_offset, cmd_limit;
-    uint32_t clip_zero_depth, clip_depth, render_blend_depth, max_blend_depth;
-};
-struct Alloc {
-    uint32_t seg_next;    // EMIT: next segment index; SIM: running total
-    uint32_t chunk_next;  // EMIT: next PTCL chunk word offset (relative to ptcl_dyn_start); SIM: chunk count
-};
+typedef unsigned long long u64;
 
-template <bool EMIT>
-__device__ __forceinline__ void ptcl_store(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t v) {
-    if constexpr (EMIT) {
-        if (ix < cfg.ptcl_size) ptcl[ix] = v;
-    }
-}
-
-// One command = one store instruction: the words of a command are consecutive, so a wave's 64 tiles cost 64 cache
-// lines per COMMAND instead of per WORD (PTCL offsets are only 4-byte aligned; global memory takes unaligned vectors).
 struct __attribute__((packed, aligned(4))) PtclWords2 { uint32_t a, b; };
 struct __attribute__((packed, aligned(4))) PtclWords3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(4))) PtclWords4 { uint32_t a, b, c, d; };
-template <bool EMIT>
-__device__ __forceinline__ void ptcl_store2(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b) {
-    if constexpr (EMIT) {
-        if (ix + 1u < cfg.ptcl_size) {
-            *reinterpret_cast<PtclWords2 *>(ptcl + ix) = PtclWords2{a, b};
-        } else {
-            ptcl_store<true>(ptcl, cfg, ix, a);
-            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
-        }
-    }
-}
-template <bool EMIT>
-__device__ __forceinline__ void ptcl_store3(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b, uint32_t c) {
-    if constexpr (EMIT) {
-        if (ix + 2u < cfg.ptcl_size) {
-            *reinterpret_cast<PtclWords3 *>(ptcl + ix) = PtclWords3{a, b, c};
-        } else {
-            ptcl_store<true>(ptcl, cfg, ix, a);
-            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
-            ptcl_store<true>(ptcl, cfg, ix + 2u, c);
-        }
-    }
-}
-template <bool EMIT>
-__device__ __forceinline__ void ptcl_store4(uint32_t *ptcl, const Config &cfg, uint32_t ix, uint32_t a, uint32_t b, uint32_t c,
-                                            uint32_t d) {
-    if constexpr (EMIT) {
-        if (ix + 3u < cfg.ptcl_size) {
-            *reinterpret_cast<PtclWords4 *>(ptcl + ix) = PtclWords4{a, b, c, d};
-        } else {
-            ptcl_store<true>(ptcl, cfg, ix, a);
-            ptcl_store<true>(ptcl, cfg, ix + 1u, b);
-            ptcl_store<true>(ptcl, cfg, ix + 2u, c);
-            ptcl_store<true>(ptcl, cfg, ix + 3u, d);
-        }
-    }
-}
 
-// coarse.wgsl:68-86
-template <bool EMIT>
-__device__ __forceinline__ void alloc_cmd(TileState &st, Alloc &al, uint32_t size, const Config &cfg, Bump *bump, uint32_t *ptcl) {
-    if (st.cmd_offset + size >= st.cmd_limit) {
-        if constexpr (EMIT) {
-            uint32_t ptcl_dyn_start = cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
-            uint32_t new_cmd = ptcl_dyn_start + al.chunk_next;
-            al.chunk_next += PTCL_INCREMENT;
-            if (new_cmd + PTCL_INCREMENT > cfg.ptcl_size) {
-                new_cmd = 0u;
-                atomicOr(&bump->failed, STAGE_COARSE);
-            }
-            ptcl_store2<true>(ptcl, cfg, st.cmd_offset, CMD_JUMP, new_cmd);
-            st.cmd_offset = new_cmd;
-            st.cmd_limit = new_cmd + (PTCL_INCREMENT - PTCL_HEADROOM);
-        } else {
-            al.chunk_next += 1u;
-            st.cmd_offset = 0u;
-            st.cmd_limit = PTCL_INCREMENT - PTCL_HEADROOM;
-        }
-    }
-}
-
-// coarse.wgsl:88-110
-template <bool EMIT>
-__device__ __forceinline__ void write_path(TileState &st, Alloc &al, Tile tile, uint32_t tile_ix, uint32_t draw_flags, const Config &cfg,
-                                           Bump *bump, uint32_t *ptcl, Tile *tiles) {
-    uint32_t n_segs = tile.segment_count_or_ix;
-    if (n_segs != 0u) {
-        uint32_t seg_ix = al.seg_next;
-        al.seg_next += n_segs;
-        if constexpr (EMIT) tiles[tile_ix].segment_count_or_ix = ~seg_ix;
-        alloc_cmd<EMIT>(st, al, 4u, cfg, bump, ptcl);
-        uint32_t even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u ? 1u : 0u;
-        ptcl_store4<EMIT>(ptcl, cfg, st.cmd_offset, CMD_FILL, (n_segs << 1) | even_odd, seg_ix, (uint32_t)tile.backdrop);
-        st.cmd_offset += 4u;
-    } else {
-        alloc_cmd<EMIT>(st, al, 1u, cfg, bump, ptcl);
-        ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset, CMD_SOLID);
-        st.cmd_offset += 1u;
-    }
-}
-
-template <bool EMIT>
-__device__ __forceinline__ void write2(TileState &st, Alloc &al, uint32_t a, uint32_t b, const Config &cfg, Bump *bump, uint32_t *ptcl) {
-    alloc_cmd<EMIT>(st, al, 2u, cfg, bump, ptcl);
-    ptcl_store2<EMIT>(ptcl, cfg, st.cmd_offset, a, b);
-    st.cmd_offset += 2u;
-}
-template <bool EMIT>
-__device__ __forceinline__ void write3(TileState &st, Alloc &al, uint32_t a, uint32_t b, uint32_t c, const Config &cfg, Bump *bump,
-                                       uint32_t *ptcl) {
-    alloc_cmd<EMIT>(st, al, 3u, cfg, bump, ptcl);
-    ptcl_store3<EMIT>(ptcl, cfg, st.cmd_offset, a, b, c);
-    st.cmd_offset += 3u;
-}
-
-// Queue of the draw objects that touch this quadrant, in draw order (a ring of QCAP slots).
+// Queue of the draw objects that touch this quadrant, in draw order (a ring of QCAP slots), and the per-batch tables.
 struct CoarseLds {
     uint32_t tag[QCAP];
     uint32_t flags[QCAP];   // draw_flags = info[di]
@@ -167,112 +66,47 @@ struct CoarseLds {
     uint32_t di[QCAP];
     uint32_t base[QCAP];    // Tile index of quadrant-local (0, 0) in the path's tile rectangle (may lie outside it)
     uint32_t stride[QCAP];
-    uint32_t rect[QCAP];    // x0 | y0 << 4 | w << 8 | h << 12, quadrant-local
-    uint32_t cover[QCAP][4];  // 64-bit masks over the quadrant (bit = y * 8 + x): [0..1] tile included, [2..3] tile occluder
-    uint32_t bitmaps[N_SLICE][64];  // per tile: which objects of the batch it includes
-    Tile rec[KMAX][64];             // per tile: the Tile records of its first KMAX included objects of the batch
+    uint32_t rect[QCAP];    // x0 | y0 << 4 | w << 8 | h << 12 | kind << 16, quadrant-local
+    uint32_t cover[QCAP][8];  // 64-bit masks over the quadrant (bit = y * 8 + x): included, occluder, has segments, backdrop clear
+    // per batch: [w][t] = wave-slice w (64 objects), tile t
+    uint32_t em[NW][64][2];   // objects of the slice that emit commands for the tile
+    uint32_t gm[NW][64][2];   // ... of those, the ones with segments (CMD_FILL)
+    uint32_t cl[NW][64][2];   // backdrop-clear bits (clip pre-pass)
+    uint32_t kslice[NW][64];  // 1 + slice-local index of the tile's last occluder, 0 = none
+    uint32_t kinds[NW][2][2]; // per slice: which objects are BEGIN_CLIPs / END_CLIPs (clip pre-pass)
+    uint32_t S[NW][64], G[NW][64];  // words / segments the slice needs in the tile
+    uint32_t pend[NW][64];          // inclusive prefix over the tiles of the slice's pair counts
+    uint32_t wordbase[NW][64], segbase[NW][64];
     uint32_t part_end[PART_CHUNK];  // inclusive prefix of the element counts of the merged bin headers
     uint32_t part_off[PART_CHUNK];
+    uint32_t wave_cnt[NW];
+    uint32_t bcast;
 };
 
-// Iterator over the set bits (draw objects, in order) of this lane's tile.
-struct BitIter {
-    uint32_t slice, bits;
-    __device__ __forceinline__ void init(const CoarseLds &sh, uint32_t lane, uint32_t first_el) {
-        slice = first_el / 32u;
-        bits = sh.bitmaps[slice][lane] & ~((1u << (first_el & 31u)) - 1u);
-    }
-    __device__ __forceinline__ uint32_t next(const CoarseLds &sh, uint32_t lane, uint32_t n_slices) {
-        while (bits == 0u) {
-            if (slice + 1u >= n_slices) return NONE;  // (stays exhausted: bits is 0 and slice is the last one)
-            slice += 1u;
-            bits = sh.bitmaps[slice][lane];
-        }
-        uint32_t e = slice * 32u + (uint32_t)(__ffs((int)bits) - 1);
-        bits &= bits - 1u;
-        return e;
-    }
-};
+__device__ __forceinline__ uint32_t popc64(u64 x) { return (uint32_t)__popcll(x); }
+__device__ __forceinline__ u64 make64(uint32_t lo, uint32_t hi) { return ((u64)hi << 32) | (u64)lo; }
+__device__ __forceinline__ u64 below64(uint32_t b) { return b >= 64u ? ~0ull : ((1ull << b) - 1ull); }
 
-// One batch of queued draw objects for this lane's tile: coarse.wgsl:349-452.
-// `first_el` / `has_kill`: objects before `first_el` are occluded by the opaque solid draw `first_el`.
-template <bool EMIT>
-__device__ void process_batch(TileState &st, Alloc &al, const CoarseLds &sh, uint32_t qh, uint32_t n_slices, uint32_t lane, uint32_t tile_x,
-                              uint32_t tile_y, uint32_t first_el, bool has_kill, uint32_t list_start, const Config &cfg,
-                              const uint32_t *__restrict__ scene, Tile *tiles, Bump *bump, uint32_t *ptcl) {
-    BitIter it;
-    it.init(sh, lane, first_el);
-    uint32_t k = 0u;  // ordinal of the object among this tile's included ones (index of its staged Tile record)
-    for (uint32_t el_ix = it.next(sh, lane, n_slices); el_ix != NONE; el_ix = it.next(sh, lane, n_slices), k++) {
-        const uint32_t q = (qh + el_ix) & (QCAP - 1u);
-        const uint32_t tile_ix = sh.base[q] + sh.stride[q] * tile_y + tile_x;
-        const Tile tile = k < KMAX ? sh.rec[k][lane] : tiles[tile_ix];
-        const uint32_t drawtag = sh.tag[q];
-        if (st.clip_zero_depth == 0u) {
-            const uint32_t di = sh.di[q];
-            const uint32_t draw_flags = sh.flags[q];
-            if (has_kill && el_ix == first_el) {
-                // everything emitted so far for this tile is covered: restart the list here
-                st.cmd_offset = list_start;
-                st.cmd_limit = list_start - 1u + (PTCL_INITIAL_ALLOC - PTCL_HEADROOM);
-            }
-            switch (drawtag) {
-            case DRAWTAG_FILL_COLOR:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write2<EMIT>(st, al, CMD_COLOR, sh.w0[q], cfg, bump, ptcl);
-                break;
-            case DRAWTAG_BLURRED_ROUNDED_RECT:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write3<EMIT>(st, al, CMD_BLUR_RECT, di + 1u, sh.w0[q], cfg, bump, ptcl);
-                break;
-            case DRAWTAG_FILL_LIN_GRADIENT:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write3<EMIT>(st, al, CMD_LIN_GRAD, sh.w0[q], di + 1u, cfg, bump, ptcl);
-                break;
-            case DRAWTAG_FILL_RAD_GRADIENT:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write3<EMIT>(st, al, CMD_RAD_GRAD, sh.w0[q], di + 1u, cfg, bump, ptcl);
-                break;
-            case DRAWTAG_FILL_SWEEP_GRADIENT:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write3<EMIT>(st, al, CMD_SWEEP_GRAD, sh.w0[q], di + 1u, cfg, bump, ptcl);
-                break;
-            case DRAWTAG_FILL_IMAGE:
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write2<EMIT>(st, al, CMD_IMAGE, di + 1u, cfg, bump, ptcl);
-                break;
-            case DRAWTAG_BEGIN_CLIP: {
-                bool even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
-                int32_t bd = even_odd ? (abs(tile.backdrop) & 1) : tile.backdrop;
-                if (tile.segment_count_or_ix == 0u && bd == 0) {
-                    st.clip_zero_depth = st.clip_depth + 1u;
-                } else {
-                    alloc_cmd<EMIT>(st, al, 1u, cfg, bump, ptcl);
-                    ptcl_store<EMIT>(ptcl, cfg, st.cmd_offset, CMD_BEGIN_CLIP);
-                    st.cmd_offset += 1u;
-                    st.render_blend_depth += 1u;
-                    st.max_blend_depth = maxu(st.max_blend_depth, st.render_blend_depth);
-                }
-                st.clip_depth += 1u;
-                break;
-            }
-            case DRAWTAG_END_CLIP:
-                st.clip_depth -= 1u;
-                write_path<EMIT>(st, al, tile, tile_ix, draw_flags, cfg, bump, ptcl, tiles);
-                write3<EMIT>(st, al, CMD_END_CLIP, sh.w0[q], scene[sh.dd[q] + 1u], cfg, bump, ptcl);
-                st.render_blend_depth -= 1u;
-                break;
-            default: break;
-            }
-        } else {
-            if (drawtag == DRAWTAG_BEGIN_CLIP) {
-                st.clip_depth += 1u;
-            } else if (drawtag == DRAWTAG_END_CLIP) {
-                if (st.clip_depth == st.clip_zero_depth) st.clip_zero_depth = 0u;
-                st.clip_depth -= 1u;
-            }
-        }
-    }
+// position of the k-th (0-based) set bit of m; k < popcount(m)
+__device__ __forceinline__ uint32_t kth_bit64(u64 m, uint32_t k) {
+    uint32_t w = (uint32_t)m, pos = 0u;
+    uint32_t c = (uint32_t)__popc(w);
+    if (k >= c) { k -= c; w = (uint32_t)(m >> 32); pos = 32u; }
+    c = (uint32_t)__popc(w & 0xffffu);
+    if (k >= c) { k -= c; w >>= 16; pos += 16u; }
+    c = (uint32_t)__popc(w & 0xffu);
+    if (k >= c) { k -= c; w >>= 8; pos += 8u; }
+    c = (uint32_t)__popc(w & 0xfu);
+    if (k >= c) { k -= c; w >>= 4; pos += 4u; }
+    c = (uint32_t)__popc(w & 3u);
+    if (k >= c) { k -= c; w >>= 2; pos += 2u; }
+    if (k >= (w & 1u)) pos += 1u;
+    return pos;
+}
+
+// words the objects of mask m (those of gmask with CMD_FILL) emit: FILL 4 / SOLID 1 + draw command 2 or 3; BEGIN 1
+__device__ __forceinline__ uint32_t words_of(u64 m, u64 g, u64 k1, u64 k2, u64 k3) {
+    return 3u * popc64(g) + 3u * popc64(m & k1) + 4u * popc64(m & k2) + popc64(m & k3);
 }
 
 // 64 bits of a bit plane starting at bit `b` (one 8-byte load at a 4-byte aligned address; the planes carry two words of
@@ -331,17 +165,21 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
     }
 }
 
-__global__ void __launch_bounds__(64) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
-                                               const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
-                                               const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
-                                               uint32_t *ptcl, bool allow_cull) {
+
+// coarse.wgsl:156-471.  256 threads: as draw objects while the bin's list is filtered, as 4 x 64 (tile, object) pairs
+// while a batch is emitted; wave 0's lanes are also the 64 tiles of the quadrant (write pointers, clip state).
+__global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
+                                                const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
+                                                const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
+                                                uint32_t *ptcl, bool allow_cull) {
     __shared__ CoarseLds sh;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
     {  // coarse.wgsl:161-176
         uint32_t failed = bump->failed & (STAGE_BINNING | STAGE_TILE_ALLOC | STAGE_FLATTEN | FAILED_SCENE);
         if (bump->seg_counts > cfg.seg_counts_size) failed |= STAGE_PATH_COUNT;
         if (failed != 0u) {
-            if (blockIdx.x == 0 && lane == 0) atomicOr(&bump->failed, failed);
+            if (blockIdx.x == 0 && tid == 0) atomicOr(&bump->failed, failed);
             return;
         }
     }
@@ -357,256 +195,451 @@ __global__ void __launch_bounds__(64) k_coarse(Config cfg, const uint32_t *__res
     const uint32_t n_partitions = (cfg.layout.n_draw_objects + N_TILE - 1u) / N_TILE;
     const uint32_t sub_x0 = N_TILE_X * (bin_ix % width_in_bins) + SUB_W * (quad & 1u);
     const uint32_t sub_y0 = N_TILE_Y * (bin_ix / width_in_bins) + SUB_W * (quad >> 1);
-    const uint32_t tile_x = lane % SUB_W;
-    const uint32_t tile_y = lane / SUB_W;
-    const uint32_t this_tile_ix = (sub_y0 + tile_y) * cfg.width_in_tiles + sub_x0 + tile_x;
     const uint32_t *plane_s = tile_bits;
     const uint32_t *plane_z = tile_bits + plane_words;
     const uint32_t *plane_o = tile_bits + 2u * (size_t)plane_words;
+    const bool has_clips = cfg.layout.n_clips != 0u;
+    const bool cull = allow_cull && !has_clips;
+    const uint32_t ptcl_dyn_start = cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
 
-    TileState st;
-    st.cmd_offset = this_tile_ix * PTCL_INITIAL_ALLOC;
-    st.cmd_limit = st.cmd_offset + (PTCL_INITIAL_ALLOC - PTCL_HEADROOM);
-    st.clip_zero_depth = 0u; st.clip_depth = 0u; st.render_blend_depth = 0u; st.max_blend_depth = 0u;
-    const uint32_t blend_offset = st.cmd_offset;
-    st.cmd_offset += 1u;
-    const uint32_t list_start = st.cmd_offset;
-    const bool cull = allow_cull && cfg.layout.n_clips == 0u;
+    // ---- per-tile state, live in wave 0 (lane = tile) ----
+    const uint32_t this_tile_ix = (sub_y0 + lane / SUB_W) * cfg.width_in_tiles + sub_x0 + lane % SUB_W;
+    const uint32_t blend_offset = this_tile_ix * PTCL_INITIAL_ALLOC;
+    const uint32_t list_start = blend_offset + 1u;
+    uint32_t cur = list_start;       // next command word of the tile's list
+    uint32_t room = INITIAL_ROOM;    // words left in the current region in front of its two-word tail
+    bool dead = false;               // the tile's list ran out of PTCL pool: nothing more is written
+    uint32_t clip_zero_depth = 0u, clip_depth = 0u, render_blend_depth = 0u, max_blend_depth = 0u;
 
     // ---- the bin's element stream: bin headers merged PART_CHUNK partitions at a time (coarse.wgsl:218-263) ----
     uint32_t partition_ix = 0u;                 // next partition to merge
     uint32_t chunk_total = 0u, chunk_pos = 0u;  // elements of the merged partitions / handed out so far
     auto refill = [&]() {
-        wave_lds_sync();  // the binary searches of the previous round are done with part_end / part_off
-        uint32_t carry = 0u;
+        __syncthreads();  // the binary searches of the previous round are done with part_end / part_off
+        if (wave == 0u) {
+            uint32_t carry = 0u;
 #pragma unroll
-        for (uint32_t k = 0; k < PART_CHUNK / 64u; k++) {
-            const uint32_t p = partition_ix + k * 64u + lane;
-            uint32_t count = 0u, off = 0u;
-            if (p < n_partitions) {
-                const BinHeader bh = bin_headers[(size_t)p * aligned_n_bins + bin_ix];
-                count = bh.element_count;
-                off = bh.chunk_offset;
+            for (uint32_t k = 0; k < PART_CHUNK / 64u; k++) {
+                const uint32_t p = partition_ix + k * 64u + lane;
+                uint32_t count = 0u, off = 0u;
+                if (p < n_partitions) {
+                    const BinHeader bh = bin_headers[(size_t)p * aligned_n_bins + bin_ix];
+                    count = bh.element_count;
+                    off = bh.chunk_offset;
+                }
+                const uint32_t incl = wave_incl_scan_u32(count, (int)lane) + carry;
+                sh.part_end[k * 64u + lane] = incl;
+                sh.part_off[k * 64u + lane] = off;
+                carry = (uint32_t)__shfl((int)incl, 63);
             }
-            const uint32_t incl = wave_incl_scan_u32(count, (int)lane) + carry;
-            sh.part_end[k * 64u + lane] = incl;
-            sh.part_off[k * 64u + lane] = off;
-            carry = (uint32_t)__shfl((int)incl, 63);
+            if (lane == 0u) sh.bcast = carry;
         }
-        chunk_total = carry;
+        __syncthreads();
+        chunk_total = sh.bcast;
         chunk_pos = 0u;
         partition_ix += PART_CHUNK;
-        wave_lds_sync();
     };
-    // draw object indices of the next round (NONE = no entry); advances the stream
-    auto fetch_indices = [&](uint32_t (&d)[RPL]) {
+    // the draw object index of this thread's entry of the next round (NONE = none); false when the stream has ended
+    auto fetch_index = [&](uint32_t &d) -> bool {
         while (chunk_pos >= chunk_total && partition_ix < n_partitions) refill();
+        const bool any = chunk_pos < chunk_total;
+        const uint32_t ix = chunk_pos + tid;
+        d = NONE;
+        if (ix < chunk_total) {
+            uint32_t part = 0u;
 #pragma unroll
-        for (uint32_t j = 0; j < RPL; j++) {
-            const uint32_t ix = chunk_pos + j * 64u + lane;
-            d[j] = NONE;
-            if (ix < chunk_total) {
-                uint32_t part = 0u;
-#pragma unroll
-                for (uint32_t i = 0; i < 8u; i++) {
-                    const uint32_t probe = part + (128u >> i);
-                    if (ix >= sh.part_end[probe - 1u]) part = probe;
-                }
-                const uint32_t local = ix - (part > 0u ? sh.part_end[part - 1u] : 0u);
-                d[j] = info_bin_data[cfg.layout.bin_data_start + sh.part_off[part] + local];
+            for (uint32_t i = 0; i < 8u; i++) {
+                const uint32_t probe = part + (128u >> i);
+                if (ix >= sh.part_end[probe - 1u]) part = probe;
             }
+            const uint32_t local = ix - (part > 0u ? sh.part_end[part - 1u] : 0u);
+            d = info_bin_data[cfg.layout.bin_data_start + sh.part_off[part] + local];
         }
-        chunk_pos = minu(chunk_pos + 64u * RPL, chunk_total);
+        chunk_pos = minu(chunk_pos + WG, chunk_total);
+        return any;
     };
 
     uint32_t qh = 0u, qlen = 0u;  // queue head (ring index) and length
-    uint32_t d_cur[RPL];
-    fetch_indices(d_cur);
-    bool more = true;
-    while (more) {
-        // ---- lanes as draw objects: records of this round, indices of the next ----
-        CoarseEl el[RPL];
-#pragma unroll
-        for (uint32_t j = 0; j < RPL; j++) {
-            el[j].tag = DRAWTAG_NOP;
-            el[j].flags = 0u; el[j].w0 = 0u; el[j].dd = 0u; el[j].di = 0u; el[j].tiles = 0u; el[j].bbox_x = 0u; el[j].bbox_y = 0u;
-            if (d_cur[j] != NONE) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(coarse_el + d_cur[j]);
+    uint32_t d_cur;
+    bool more = fetch_index(d_cur);
+    while (more || qlen > 0u) {
+        if (more) {
+            // ---- threads as draw objects: the record of this round's entry, the index of the next round's ----
+            CoarseEl el;
+            el.tag = DRAWTAG_NOP;
+            el.flags = 0u; el.w0 = 0u; el.dd = 0u; el.di = 0u; el.tiles = 0u; el.bbox_x = 0u; el.bbox_y = 0u;
+            if (d_cur != NONE) {
+                const uint4 *p = reinterpret_cast<const uint4 *>(coarse_el + d_cur);
                 const uint4 a = p[0], b = p[1];
-                el[j].tag = a.x; el[j].flags = a.y; el[j].w0 = a.z; el[j].dd = a.w;
-                el[j].di = b.x; el[j].tiles = b.y; el[j].bbox_x = b.z; el[j].bbox_y = b.w;
+                el.tag = a.x; el.flags = a.y; el.w0 = a.z; el.dd = a.w;
+                el.di = b.x; el.tiles = b.y; el.bbox_x = b.z; el.bbox_y = b.w;
             }
-        }
-        uint32_t d_next[RPL];
-        fetch_indices(d_next);
-        bool any_next = false;
-#pragma unroll
-        for (uint32_t j = 0; j < RPL; j++) any_next = any_next || d_next[j] != NONE;
-        more = __ballot(any_next) != 0ull;
-        // keep the objects whose tile rectangle meets this quadrant, in order (coarse.wgsl:264-289)
-        const uint32_t q_new = qh + qlen;  // (un-wrapped) slot of the first object appended this round
-#pragma unroll
-        for (uint32_t j = 0; j < RPL; j++) {
-            const int32_t bx0 = (int32_t)(el[j].bbox_x & 0xffffu), bx1 = (int32_t)(el[j].bbox_x >> 16);
-            const int32_t by0 = (int32_t)(el[j].bbox_y & 0xffffu), by1 = (int32_t)(el[j].bbox_y >> 16);
+            more = fetch_index(d_cur);
+            // keep the objects whose tile rectangle meets this quadrant, in order (coarse.wgsl:264-289)
+            const int32_t bx0 = (int32_t)(el.bbox_x & 0xffffu), bx1 = (int32_t)(el.bbox_x >> 16);
+            const int32_t by0 = (int32_t)(el.bbox_y & 0xffffu), by1 = (int32_t)(el.bbox_y >> 16);
             const int32_t dx = bx0 - (int32_t)sub_x0, dy = by0 - (int32_t)sub_y0;
             const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, 0, (int32_t)SUB_W);
             const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, 0, (int32_t)SUB_W);
-            const bool keep = el[j].tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
-            const unsigned long long m = __ballot(keep);
+            const bool keep = el.tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
+            const u64 m = __ballot(keep);
+            if (lane == 0u) sh.wave_cnt[wave] = popc64(m);
+            __syncthreads();
+            uint32_t before = 0u, total_new = 0u;
+#pragma unroll
+            for (uint32_t w = 0; w < NW; w++) {
+                const uint32_t c = sh.wave_cnt[w];
+                if (w < wave) before += c;
+                total_new += c;
+            }
+            const uint32_t q_new = qh + qlen;  // (un-wrapped) slot of the first object appended this round
             if (keep) {
-                const uint32_t q = (qh + qlen + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (QCAP - 1u);
+                const uint32_t q = (q_new + before + popc64(m & below64(lane))) & (QCAP - 1u);
                 const uint32_t stride = (uint32_t)(bx1 - bx0);
-                sh.tag[q] = el[j].tag;
-                sh.flags[q] = el[j].flags;
-                sh.w0[q] = el[j].w0;
-                sh.dd[q] = el[j].dd;
-                sh.di[q] = el[j].di;
+                uint32_t kind = KIND_NONE;
+                switch (el.tag) {
+                case DRAWTAG_FILL_COLOR: case DRAWTAG_FILL_IMAGE: kind = KIND_PATH2; break;
+                case DRAWTAG_BLURRED_ROUNDED_RECT: case DRAWTAG_FILL_LIN_GRADIENT: case DRAWTAG_FILL_RAD_GRADIENT:
+                case DRAWTAG_FILL_SWEEP_GRADIENT: case DRAWTAG_END_CLIP: kind = KIND_PATH3; break;
+                case DRAWTAG_BEGIN_CLIP: kind = KIND_BEGIN; break;
+                default: break;
+                }
+                sh.tag[q] = el.tag;
+                sh.flags[q] = el.flags;
+                sh.w0[q] = el.w0;
+                sh.dd[q] = el.dd;
+                sh.di[q] = el.di;
                 sh.stride[q] = stride;
-                sh.base[q] = el[j].tiles - (uint32_t)(dy * (int32_t)stride + dx);
-                sh.rect[q] = (uint32_t)x0 | ((uint32_t)y0 << 4) | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)(y1 - y0) << 12);
+                sh.base[q] = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
+                sh.rect[q] = (uint32_t)x0 | ((uint32_t)y0 << 4) | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)(y1 - y0) << 12) | (kind << 16);
             }
-            qlen += (uint32_t)__popcll(m);
-        }
-        wave_lds_sync();
-        // coverage masks of the new objects, one object per lane: <= 8 row windows of the bit planes
-        // (coarse.wgsl:290-347 reads a Tile per (object, tile) pair and sets LDS bits with atomics)
-        const uint32_t q_end = qh + qlen;
-        for (uint32_t qi = q_new + lane; qi < q_end; qi += 64u) {
-            const uint32_t q = qi & (QCAP - 1u);
-            const uint32_t rect = sh.rect[q], tag = sh.tag[q], w0 = sh.w0[q];
-            const uint32_t x0 = rect & 15u, y0 = (rect >> 4) & 15u, w = (rect >> 8) & 15u, h = rect >> 12;
-            const uint32_t base = sh.base[q], stride = sh.stride[q];
-            const bool is_clip = (tag & 1u) != 0u;
-            const uint32_t BLEND_CLIP = (128u << 8) | 3u;
-            const bool is_blend = is_clip && w0 != BLEND_CLIP;
-            const bool even_odd = (sh.flags[q] & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
-            const uint32_t *plane_c = even_odd ? plane_o : plane_z;
-            const uint32_t wmask = (1u << w) - 1u;
-            unsigned long long ws[SUB_W], wc[SUB_W];
+            qlen += total_new;
+            __syncthreads();
+            // coverage masks of the new objects, one object per thread: <= 8 row windows of the bit planes
+            // (coarse.wgsl:290-347 reads a Tile per (object, tile) pair and sets LDS bits with atomics)
+            if (tid < total_new) {
+                const uint32_t q = (q_new + tid) & (QCAP - 1u);
+                const uint32_t rect = sh.rect[q], tag = sh.tag[q], w0 = sh.w0[q];
+                const uint32_t rx0 = rect & 15u, ry0 = (rect >> 4) & 15u, w = (rect >> 8) & 15u, h = (rect >> 12) & 15u;
+                const uint32_t base = sh.base[q], stride = sh.stride[q];
+                const bool is_clip = (tag & 1u) != 0u;
+                const uint32_t BLEND_CLIP = (128u << 8) | 3u;
+                const bool is_blend = is_clip && w0 != BLEND_CLIP;
+                const bool even_odd = (sh.flags[q] & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
+                const uint32_t *plane_c = even_odd ? plane_o : plane_z;
+                const uint32_t wmask = (1u << w) - 1u;
+                u64 ws[SUB_W], wc[SUB_W];
 #pragma unroll
-            for (uint32_t r = 0; r < SUB_W; r++) {
-                ws[r] = 0ull;
-                wc[r] = 0ull;
-                if (r < h) {
-                    const uint32_t b = base + stride * (y0 + r) + x0;
-                    ws[r] = plane_window(plane_s, b);
-                    wc[r] = plane_window(plane_c, b);
+                for (uint32_t r = 0; r < SUB_W; r++) {
+                    ws[r] = 0ull;
+                    wc[r] = 0ull;
+                    if (r < h) {
+                        const uint32_t b = base + stride * (ry0 + r) + rx0;
+                        ws[r] = plane_window(plane_s, b);
+                        wc[r] = plane_window(plane_c, b);
+                    }
                 }
-            }
-            unsigned long long inc = 0ull, kil = 0ull;
+                u64 inc = 0ull, kil = 0ull, seg = 0ull, clr = 0ull;
 #pragma unroll
-            for (uint32_t r = 0; r < SUB_W; r++) {
-                if (r < h) {
-                    const uint32_t s = (uint32_t)ws[r] & wmask;
-                    const uint32_t clear = (uint32_t)wc[r] & wmask;  // backdrop_clear per tile of the row
-                    // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
-                    const uint32_t in = is_blend ? wmask : (s | ((is_clip ? clear : ~clear) & wmask));
-                    const uint32_t shift = (y0 + r) * SUB_W + x0;
-                    inc |= (unsigned long long)in << shift;
-                    kil |= (unsigned long long)(in & ~s) << shift;
+                for (uint32_t r = 0; r < SUB_W; r++) {
+                    if (r < h) {
+                        const uint32_t s = (uint32_t)ws[r] & wmask;
+                        const uint32_t clear = (uint32_t)wc[r] & wmask;  // backdrop_clear per tile of the row
+                        // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
+                        const uint32_t in = is_blend ? wmask : (s | ((is_clip ? clear : ~clear) & wmask));
+                        const uint32_t shift = (ry0 + r) * SUB_W + rx0;
+                        inc |= (u64)in << shift;
+                        kil |= (u64)(in & ~s) << shift;
+                        seg |= (u64)(in & s) << shift;
+                        clr |= (u64)(in & clear) << shift;
+                    }
                 }
+                // fully covering opaque solid colour: occludes every earlier draw of the tile
+                if (!(cull && tag == DRAWTAG_FILL_COLOR && (w0 >> 24) == 0xffu)) kil = 0ull;
+                sh.cover[q][0] = (uint32_t)inc; sh.cover[q][1] = (uint32_t)(inc >> 32);
+                sh.cover[q][2] = (uint32_t)kil; sh.cover[q][3] = (uint32_t)(kil >> 32);
+                sh.cover[q][4] = (uint32_t)seg; sh.cover[q][5] = (uint32_t)(seg >> 32);
+                sh.cover[q][6] = (uint32_t)clr; sh.cover[q][7] = (uint32_t)(clr >> 32);
             }
-            // fully covering opaque solid colour: occludes every earlier draw of the tile
-            if (!(cull && tag == DRAWTAG_FILL_COLOR && (w0 >> 24) == 0xffu)) kil = 0ull;
-            sh.cover[q][0] = (uint32_t)inc;
-            sh.cover[q][1] = (uint32_t)(inc >> 32);
-            sh.cover[q][2] = (uint32_t)kil;
-            sh.cover[q][3] = (uint32_t)(kil >> 32);
+            __syncthreads();
         }
-        wave_lds_sync();
 
-        // ---- lanes as tiles: full batches, and whatever is left when the stream has ended ----
+        // ---- full batches, and whatever is left when the stream has ended ----
         while (qlen >= NB || (!more && qlen > 0u)) {
             const uint32_t n = minu(qlen, NB);
-            const uint32_t n_slices = (n + 31u) / 32u;
-            // transpose the objects' masks into this tile's bitmap; remember the last occluder
-            uint32_t first_el = 0u;
-            bool has_kill = false;
-            const bool hi = lane >= 32u;
-            const uint32_t sh_l = lane & 31u;
-            for (uint32_t sl = 0; sl < n_slices; sl++) {
-                uint32_t word = 0u;
-                const uint32_t cnt = minu(32u, n - sl * 32u);
-                for (uint32_t b = 0; b < cnt; b++) {
-                    const uint32_t q = (qh + sl * 32u + b) & (QCAP - 1u);
-                    const uint32_t mi = ((hi ? sh.cover[q][1] : sh.cover[q][0]) >> sh_l) & 1u;
-                    const uint32_t mk = ((hi ? sh.cover[q][3] : sh.cover[q][2]) >> sh_l) & 1u;
-                    word |= mi << b;
-                    if (mk != 0u) {
-                        first_el = sl * 32u + b;
-                        has_kill = true;
-                    }
-                }
-                sh.bitmaps[sl][lane] = word;
-            }
-            wave_lds_sync();
-            // stage the Tile records of this tile's included objects (from the occluder on), 8 loads in flight
+            const uint32_t cnt = n > wave * 64u ? minu(n - wave * 64u, 64u) : 0u;  // objects of this wave's slice
+            const uint32_t q0 = qh + wave * 64u;
+            // lanes as objects of the slice: which kinds are where (wave-uniform masks)
+            const uint32_t my_kind = lane < cnt ? (sh.rect[(q0 + lane) & (QCAP - 1u)] >> 16) : KIND_NONE;
+            const u64 k1 = __ballot(my_kind == KIND_PATH2), k2 = __ballot(my_kind == KIND_PATH3), k3 = __ballot(my_kind == KIND_BEGIN);
+            const u64 k_end = has_clips ? __ballot(lane < cnt && sh.tag[(q0 + lane) & (QCAP - 1u)] == DRAWTAG_END_CLIP) : 0ull;
+            // lanes as tiles: transpose the objects' masks into this tile's bitmaps over the slice
+            u64 inc = 0ull, seg = 0ull, clr = 0ull;
+            uint32_t klast = 0u;
             {
-                BitIter it;
-                it.init(sh, lane, first_el);
-                bool done = false;
-                for (uint32_t k0 = 0; k0 < KMAX && !done; k0 += 8u) {
-                    Tile t[8];
-                    bool valid[8];
+                const uint32_t half = lane >> 5, sh_l = lane & 31u;
+                uint32_t inc_w[2] = {0u, 0u}, seg_w[2] = {0u, 0u}, clr_w[2] = {0u, 0u};
 #pragma unroll
-                    for (uint32_t u = 0; u < 8u; u++) {
-                        const uint32_t e = it.next(sh, lane, n_slices);
-                        valid[u] = e != NONE;
-                        t[u] = Tile{0, 0u};
-                        if (valid[u]) {
-                            const uint32_t q = (qh + e) & (QCAP - 1u);
-                            t[u] = tiles[sh.base[q] + sh.stride[q] * tile_y + tile_x];
-                        }
+                for (uint32_t hh = 0; hh < 2u; hh++) {
+                    const uint32_t c_h = cnt > hh * 32u ? minu(cnt - hh * 32u, 32u) : 0u;
+                    for (uint32_t b = 0; b < c_h; b++) {
+                        const uint32_t *c = sh.cover[(q0 + hh * 32u + b) & (QCAP - 1u)];
+                        inc_w[hh] |= ((c[half] >> sh_l) & 1u) << b;
+                        seg_w[hh] |= ((c[4u + half] >> sh_l) & 1u) << b;
+                        if (cull && ((c[2u + half] >> sh_l) & 1u) != 0u) klast = hh * 32u + b + 1u;
+                        if (has_clips) clr_w[hh] |= ((c[6u + half] >> sh_l) & 1u) << b;
                     }
-#pragma unroll
-                    for (uint32_t u = 0; u < 8u; u++)
-                        if (valid[u]) sh.rec[k0 + u][lane] = t[u];
-                    done = !valid[7];
+                }
+                inc = make64(inc_w[0], inc_w[1]);
+                seg = make64(seg_w[0], seg_w[1]);
+                clr = make64(clr_w[0], clr_w[1]);
+            }
+            sh.kslice[wave][lane] = klast;
+            if (has_clips) {
+                sh.em[wave][lane][0] = (uint32_t)inc; sh.em[wave][lane][1] = (uint32_t)(inc >> 32);
+                sh.gm[wave][lane][0] = (uint32_t)seg; sh.gm[wave][lane][1] = (uint32_t)(seg >> 32);
+                sh.cl[wave][lane][0] = (uint32_t)clr; sh.cl[wave][lane][1] = (uint32_t)(clr >> 32);
+                if (lane == 0u) {
+                    sh.kinds[wave][0][0] = (uint32_t)k3; sh.kinds[wave][0][1] = (uint32_t)(k3 >> 32);
+                    sh.kinds[wave][1][0] = (uint32_t)k_end; sh.kinds[wave][1][1] = (uint32_t)(k_end >> 32);
                 }
             }
-            wave_lds_sync();
-            // SIMULATE: how many segments / PTCL chunks does this tile need for the batch?
-            TileState sim = st;
-            Alloc cnt;
-            cnt.seg_next = 0u;
-            cnt.chunk_next = 0u;
-            process_batch<false>(sim, cnt, sh, qh, n_slices, lane, tile_x, tile_y, first_el, has_kill, list_start, cfg, scene, tiles, bump,
-                                 ptcl);
-            const uint32_t seg_incl = wave_incl_scan_u32(cnt.seg_next, (int)lane);
-            const uint32_t chunk_incl = wave_incl_scan_u32(cnt.chunk_next, (int)lane);
-            const uint32_t total_segs = (uint32_t)__shfl((int)seg_incl, 63);
-            const uint32_t total_chunks = (uint32_t)__shfl((int)chunk_incl, 63);
-            uint32_t seg_base = 0u, chunk_base = 0u;
-            if (lane == 0u) {
-                seg_base = total_segs ? atomicAdd(&bump->segments, total_segs) : 0u;
-                chunk_base = total_chunks ? atomicAdd(&bump->ptcl, total_chunks * PTCL_INCREMENT) : 0u;
+            __syncthreads();  // (1) occluders / clip inputs of all slices visible
+            bool tile_killed = false;  // the tile's list restarts in this batch
+            if (cull) {
+                // the last occluder of the tile in the batch: earlier objects are dropped
+                bool later = false;
+#pragma unroll
+                for (uint32_t w = 0; w < NW; w++) {
+                    const uint32_t kl = sh.kslice[w][lane];
+                    tile_killed = tile_killed || kl != 0u;
+                    if (w > wave && kl != 0u) later = true;
+                }
+                if (later) inc = 0ull;
+                else if (klast != 0u) inc &= ~below64(klast - 1u);
             }
-            seg_base = (uint32_t)__shfl((int)seg_base, 0);
-            chunk_base = (uint32_t)__shfl((int)chunk_base, 0);
-            // EMIT
-            Alloc al;
-            al.seg_next = seg_base + (seg_incl - cnt.seg_next);
-            al.chunk_next = chunk_base + (chunk_incl - cnt.chunk_next) * PTCL_INCREMENT;
-            process_batch<true>(st, al, sh, qh, n_slices, lane, tile_x, tile_y, first_el, has_kill, list_start, cfg, scene, tiles, bump, ptcl);
+            if (has_clips) {
+                // The clip state machine is order dependent (coarse.wgsl:416-450): wave 0 walks, per tile, the CLIP objects
+                // of the whole batch in order and clears the bits of everything that does not emit.
+                if (wave == 0u) {
+#pragma unroll 1
+                    for (uint32_t w = 0; w < NW; w++) {
+                        const u64 m = make64(sh.em[w][lane][0], sh.em[w][lane][1]);
+                        const u64 sg = make64(sh.gm[w][lane][0], sh.gm[w][lane][1]);
+                        const u64 cr = make64(sh.cl[w][lane][0], sh.cl[w][lane][1]);
+                        const u64 kb = make64(sh.kinds[w][0][0], sh.kinds[w][0][1]);  // BEGIN_CLIPs of the slice
+                        const u64 ke = make64(sh.kinds[w][1][0], sh.kinds[w][1][1]);  // END_CLIPs
+                        u64 clipbits = m & (kb | ke);
+                        u64 act = 0ull;
+                        uint32_t pos = 0u;
+                        while (clipbits != 0ull) {
+                            const uint32_t b = (uint32_t)__ffsll((long long)clipbits) - 1u;
+                            clipbits &= clipbits - 1ull;
+                            if (clip_zero_depth == 0u) act |= below64(b) & ~below64(pos);
+                            const bool is_begin = ((kb >> b) & 1ull) != 0ull;
+                            if (clip_zero_depth == 0u) {
+                                if (is_begin) {
+                                    const bool empty = ((sg >> b) & 1ull) == 0ull && ((cr >> b) & 1ull) != 0ull;
+                                    if (empty) {
+                                        clip_zero_depth = clip_depth + 1u;
+                                    } else {
+                                        act |= 1ull << b;
+                                        render_blend_depth += 1u;
+                                        max_blend_depth = maxu(max_blend_depth, render_blend_depth);
+                                    }
+                                    clip_depth += 1u;
+                                } else {
+                                    clip_depth -= 1u;
+                                    act |= 1ull << b;
+                                    render_blend_depth -= 1u;
+                                }
+                            } else {
+                                if (is_begin) {
+                                    clip_depth += 1u;
+                                } else {
+                                    if (clip_depth == clip_zero_depth) clip_zero_depth = 0u;
+                                    clip_depth -= 1u;
+                                }
+                            }
+                            pos = b + 1u;
+                        }
+                        if (clip_zero_depth == 0u) act |= ~below64(pos);
+                        const u64 e = m & act;
+                        sh.em[w][lane][0] = (uint32_t)e; sh.em[w][lane][1] = (uint32_t)(e >> 32);
+                    }
+                }
+                __syncthreads();
+                inc = make64(sh.em[wave][lane][0], sh.em[wave][lane][1]);
+            }
+            // what the slice emits for this tile
+            const u64 em = inc & (k1 | k2 | k3);
+            const u64 gmask = seg & em & (k1 | k2);
+            const uint32_t n_pairs_t = popc64(em);
+            const uint32_t pair_incl = wave_incl_scan_u32(n_pairs_t, (int)lane);
+            const uint32_t total_pairs = (uint32_t)__shfl((int)pair_incl, 63);
+            sh.em[wave][lane][0] = (uint32_t)em; sh.em[wave][lane][1] = (uint32_t)(em >> 32);
+            sh.gm[wave][lane][0] = (uint32_t)gmask; sh.gm[wave][lane][1] = (uint32_t)(gmask >> 32);
+            sh.pend[wave][lane] = pair_incl;
+            sh.S[wave][lane] = words_of(em, gmask, k1, k2, k3);
+            sh.G[wave][lane] = 0u;
+            wave_lds_sync();
+            const uint32_t n_iter = (total_pairs + 63u) / 64u;
+            // pair p of the slice, tile-major: which tile, which object, does it have segments
+            auto pair_of = [&](uint32_t p, uint32_t &t, uint32_t &b, bool &has_segs) {
+                t = 0u;
+#pragma unroll
+                for (uint32_t i = 0; i < 6u; i++) {
+                    const uint32_t probe = t + (32u >> i);
+                    if (p >= sh.pend[wave][probe - 1u]) t = probe;
+                }
+                const uint32_t k = p - (t > 0u ? sh.pend[wave][t - 1u] : 0u);
+                const u64 m = make64(sh.em[wave][t][0], sh.em[wave][t][1]);
+                b = kth_bit64(m, k);
+                has_segs = ((make64(sh.gm[wave][t][0], sh.gm[wave][t][1]) >> b) & 1ull) != 0ull;
+            };
+            // COUNT: segments per tile (the words follow from the bitmaps)
+            for (uint32_t it = 0; it < n_iter; it++) {
+                const uint32_t p = it * 64u + lane;
+                if (p < total_pairs) {
+                    uint32_t t, b;
+                    bool has_segs;
+                    pair_of(p, t, b, has_segs);
+                    if (has_segs) {
+                        const uint32_t q = (q0 + b) & (QCAP - 1u);
+                        const uint32_t tile_ix = sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W);
+                        atomicAdd(&sh.G[wave][t], tiles[tile_ix].segment_count_or_ix);
+                    }
+                }
+            }
+            __syncthreads();  // (2) S, G of all slices
+            // ALLOCATE (wave 0, lane = tile): one region per tile that needs one, one atomic per counter
+            if (wave == 0u) {
+                uint32_t s_w[NW], g_w[NW], W = 0u, Gt = 0u;
+#pragma unroll
+                for (uint32_t w = 0; w < NW; w++) {
+                    s_w[w] = sh.S[w][lane];
+                    g_w[w] = sh.G[w][lane];
+                    W += s_w[w];
+                    Gt += g_w[w];
+                }
+                if (tile_killed && !dead) {  // everything emitted so far is covered: restart the list in the tile's own block
+                    cur = list_start;
+                    room = INITIAL_ROOM;
+                }
+                const bool need = W > room && !dead;
+                const uint32_t rsize = need ? W + 2u + REGION_SLACK : 0u;
+                const uint32_t r_incl = wave_incl_scan_u32(rsize, (int)lane);
+                const uint32_t g_incl = wave_incl_scan_u32(Gt, (int)lane);
+                const uint32_t r_total = (uint32_t)__shfl((int)r_incl, 63), g_total = (uint32_t)__shfl((int)g_incl, 63);
+                uint32_t r_base = 0u, g_base = 0u;
+                if (lane == 0u) {
+                    r_base = r_total ? atomicAdd(&bump->ptcl, r_total) : 0u;
+                    g_base = g_total ? atomicAdd(&bump->segments, g_total) : 0u;
+                }
+                r_base = (uint32_t)__shfl((int)r_base, 0);
+                g_base = (uint32_t)__shfl((int)g_base, 0);
+                if (need) {
+                    const uint32_t start = ptcl_dyn_start + r_base + (r_incl - rsize);
+                    if (start < ptcl_dyn_start || start + rsize > cfg.ptcl_size || start + rsize < start) {
+                        atomicOr(&bump->failed, STAGE_COARSE);
+                        dead = true;
+                    } else {
+                        *reinterpret_cast<PtclWords2 *>(ptcl + cur) = PtclWords2{CMD_JUMP, start};
+                        cur = start;
+                        room = W + REGION_SLACK;
+                    }
+                }
+                uint32_t wb = dead ? NONE : cur, sb = g_base + (g_incl - Gt);
+#pragma unroll
+                for (uint32_t w = 0; w < NW; w++) {
+                    sh.wordbase[w][lane] = wb;
+                    sh.segbase[w][lane] = sb;
+                    if (!dead) wb += s_w[w];
+                    sb += g_w[w];
+                }
+                if (!dead) {
+                    cur += W;
+                    room -= W;
+                }
+            }
+            __syncthreads();  // (3) bases
+            // EMIT: one lane per (tile, object) pair
+            {
+                uint32_t carry_t = NONE, carry_v = 0u;  // segmented scan across iterations
+                for (uint32_t it = 0; it < n_iter; it++) {
+                    const uint32_t p = it * 64u + lane;
+                    const bool valid = p < total_pairs;
+                    uint32_t t = NONE, b = 0u;
+                    bool has_segs = false;
+                    if (valid) pair_of(p, t, b, has_segs);
+                    const uint32_t q = (q0 + b) & (QCAP - 1u);
+                    const uint32_t tile_ix = valid ? sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W) : 0u;
+                    Tile tile{0, 0u};
+                    if (has_segs) tile = tiles[tile_ix];
+                    const uint32_t n_segs = tile.segment_count_or_ix;
+                    // exclusive prefix of n_segs among the pairs of the same tile (pairs are tile-major)
+                    uint32_t v = n_segs;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t ov = (uint32_t)__shfl_up((int)v, d);
+                        const uint32_t ot = (uint32_t)__shfl_up((int)t, d);
+                        if ((int)lane >= d && ot == t) v += ov;
+                    }
+                    if (t == carry_t) v += carry_v;
+                    const uint32_t seg_excl = v - n_segs;
+                    // (t of the last VALID lane; invalid lanes carry NONE, which no pair matches)
+                    carry_t = (uint32_t)__shfl((int)t, 63);
+                    carry_v = (uint32_t)__shfl((int)v, 63);
+                    if (!valid) continue;
+                    const uint32_t wbase = sh.wordbase[wave][t];
+                    if (wbase == NONE) continue;
+                    const u64 m = make64(sh.em[wave][t][0], sh.em[wave][t][1]);
+                    const u64 g = make64(sh.gm[wave][t][0], sh.gm[wave][t][1]);
+                    const u64 bel = below64(b);
+                    uint32_t off = wbase + words_of(m & bel, g & bel, k1, k2, k3);
+                    const uint32_t tag = sh.tag[q];
+                    if (tag == DRAWTAG_BEGIN_CLIP) {
+                        ptcl[off] = CMD_BEGIN_CLIP;
+                        continue;
+                    }
+                    const uint32_t draw_flags = sh.flags[q];
+                    if (has_segs) {  // coarse.wgsl:88-110
+                        const uint32_t seg_ix = sh.segbase[wave][t] + seg_excl;
+                        tiles[tile_ix].segment_count_or_ix = ~seg_ix;
+                        const uint32_t even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u ? 1u : 0u;
+                        *reinterpret_cast<PtclWords4 *>(ptcl + off) = PtclWords4{CMD_FILL, (n_segs << 1) | even_odd, seg_ix, (uint32_t)tile.backdrop};
+                        off += 4u;
+                    } else {
+                        ptcl[off] = CMD_SOLID;
+                        off += 1u;
+                    }
+                    const uint32_t w0 = sh.w0[q], di = sh.di[q];
+                    switch (tag) {  // coarse.wgsl:377-450
+                    case DRAWTAG_FILL_COLOR: *reinterpret_cast<PtclWords2 *>(ptcl + off) = PtclWords2{CMD_COLOR, w0}; break;
+                    case DRAWTAG_FILL_IMAGE: *reinterpret_cast<PtclWords2 *>(ptcl + off) = PtclWords2{CMD_IMAGE, di + 1u}; break;
+                    case DRAWTAG_BLURRED_ROUNDED_RECT: *reinterpret_cast<PtclWords3 *>(ptcl + off) = PtclWords3{CMD_BLUR_RECT, di + 1u, w0}; break;
+                    case DRAWTAG_FILL_LIN_GRADIENT: *reinterpret_cast<PtclWords3 *>(ptcl + off) = PtclWords3{CMD_LIN_GRAD, w0, di + 1u}; break;
+                    case DRAWTAG_FILL_RAD_GRADIENT: *reinterpret_cast<PtclWords3 *>(ptcl + off) = PtclWords3{CMD_RAD_GRAD, w0, di + 1u}; break;
+                    case DRAWTAG_FILL_SWEEP_GRADIENT: *reinterpret_cast<PtclWords3 *>(ptcl + off) = PtclWords3{CMD_SWEEP_GRAD, w0, di + 1u}; break;
+                    case DRAWTAG_END_CLIP: *reinterpret_cast<PtclWords3 *>(ptcl + off) = PtclWords3{CMD_END_CLIP, w0, scene[sh.dd[q] + 1u]}; break;
+                    default: break;
+                    }
+                }
+            }
             qh = (qh + n) & (QCAP - 1u);
             qlen -= n;
-            wave_lds_sync();  // bitmaps / rec / the freed queue slots are rewritten next
-        }
-        if (more) {
-#pragma unroll
-            for (uint32_t j = 0; j < RPL; j++) d_cur[j] = d_next[j];
+            __syncthreads();  // (4) the per-batch tables and the freed queue slots are rewritten next
         }
     }
-    if (sub_x0 + tile_x < cfg.width_in_tiles && sub_y0 + tile_y < cfg.height_in_tiles) {
-        ptcl_store<true>(ptcl, cfg, st.cmd_offset, CMD_END);
+    if (wave == 0u && sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles) {
+        if (!dead) ptcl[cur] = CMD_END;
         uint32_t blend_ix = 0u;
-        if (st.max_blend_depth > BLEND_STACK_SPLIT) {
-            uint32_t scratch_size = (st.max_blend_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT;
+        if (max_blend_depth > BLEND_STACK_SPLIT) {
+            uint32_t scratch_size = (max_blend_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT;
             blend_ix = atomicAdd(&bump->blend, scratch_size);
             if (blend_ix + scratch_size > cfg.blend_size) atomicOr(&bump->failed, STAGE_COARSE);
         }
-        ptcl_store<true>(ptcl, cfg, blend_offset, blend_ix);
+        ptcl[blend_offset] = blend_ix;
     }
 }
 
@@ -621,7 +654,7 @@ void launch_coarse(const Frame &f, hipStream_t s) {
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
-    hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(64), 0, s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
+    hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), 0, s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull);
 }
 
