@@ -164,16 +164,16 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
         ev.record()
         return ev
 
-    done_events = []
-
     def render(slot):
         engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=ring[slot])
-        if done_events is not None and len(done_events) < 4096:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record(torch.cuda.ExternalStream(engine.stream(), device=dev))
-            done_events.append(ev)
 
-    pipe = FramePipeline(nif, render=render, wait_frame=engine.sync_frame, exchange=exchange if distributed else None,
+    step_done = []  # host clock when the oldest frame in flight has completed (one entry per step once the ring is full)
+
+    def local_done(slot):  # N = 1: no exchange, but the same back-pressure -- wait for the oldest frame before the next one
+        step_done.append(time.perf_counter())
+        return None
+
+    pipe = FramePipeline(nif, render=render, wait_frame=engine.sync_frame, exchange=exchange if distributed else local_done,
                          wait_exchange=lambda ev: ev.synchronize())
 
     # warm-up, with every stage under HIP events to find the dominant kernel
@@ -191,7 +191,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
 
     # timed region: exactly K steps, events only around the dominant kernel (+ one completion event per frame)
     engine.set_profiling([dominant])
-    done_events.clear()
+    step_done.clear()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
@@ -207,15 +207,8 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     if rc != 0:
         raise SystemExit(f"frame failed in the timed region: {rc} {engine.bump()}")
     dom_ms, dom_n = engine.stage_ms()[dominant]
-    # completion-to-completion intervals of consecutive frames (they finish in order: each lane's stream is a queue of
-    # whole frames and the lanes rotate)
-    intervals = []
-    for a, b in zip(done_events[:-1], done_events[1:]):
-        try:
-            intervals.append(a.elapsed_time(b))
-        except Exception:
-            pass
-    intervals = [x for x in intervals if x > 0]
+    # completion-to-completion intervals of consecutive frames (each step waits for the oldest frame in flight)
+    intervals = [(b - a) * 1e3 for a, b in zip(step_done[:-1], step_done[1:])]
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -237,7 +230,6 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     # one frame at a time: frame latency (host clock around render + wait) and the isolated per-kernel durations
     n_serial = 0 if args.timed_only else min(max(steps, 20), 200)
     engine.set_profiling([])
-    done_events = None
     serial = []
     for _ in range(n_serial):
         t1 = time.perf_counter()

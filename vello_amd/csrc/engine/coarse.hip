@@ -45,6 +45,7 @@ constexpr uint32_t NB = 64 * NW;      // draw objects per batch
 constexpr uint32_t QCAP = 512;        // queue slots: NB - 1 left over + WG new ones; power of two
 constexpr uint32_t PART_CHUNK = 256;  // bin headers (partitions of 256 draw objects) merged at a time
 constexpr uint32_t NONE = 0xffffffffu;
+constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
 constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u;  // a tile's fixed block minus the blend word and the tail
 constexpr uint32_t REGION_SLACK = 62u;  // words a new region holds beyond the batch that asked for it
 // what a draw object emits per tile: a path command (CMD_FILL 4 words / CMD_SOLID 1) + a draw command of 2 or 3 words,
@@ -74,9 +75,9 @@ struct CoarseLds {
     uint32_t cl[NW][64][2];   // backdrop-clear bits (clip pre-pass)
     uint32_t kslice[NW][64];  // 1 + slice-local index of the tile's last occluder, 0 = none
     uint32_t kinds[NW][2][2]; // per slice: which objects are BEGIN_CLIPs / END_CLIPs (clip pre-pass)
-    uint32_t S[NW][64], G[NW][64];  // words / segments the slice needs in the tile
+    uint32_t S[NW][64];             // words the slice needs in the tile
     uint32_t pend[NW][64];          // inclusive prefix over the tiles of the slice's pair counts
-    uint32_t wordbase[NW][64], segbase[NW][64];
+    uint32_t wordbase[NW][64];      // where the slice's commands for the tile start
     uint32_t part_end[PART_CHUNK];  // inclusive prefix of the element counts of the merged bin headers
     uint32_t part_off[PART_CHUNK];
     uint32_t wave_cnt[NW];
@@ -260,21 +261,35 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     };
 
     uint32_t qh = 0u, qlen = 0u;  // queue head (ring index) and length
-    uint32_t d_cur;
-    bool more = fetch_index(d_cur);
-    while (more || qlen > 0u) {
-        if (more) {
-            // ---- threads as draw objects: the record of this round's entry, the index of the next round's ----
-            CoarseEl el;
-            el.tag = DRAWTAG_NOP;
-            el.flags = 0u; el.w0 = 0u; el.dd = 0u; el.di = 0u; el.tiles = 0u; el.bbox_x = 0u; el.bbox_y = 0u;
-            if (d_cur != NONE) {
-                const uint4 *p = reinterpret_cast<const uint4 *>(coarse_el + d_cur);
-                const uint4 a = p[0], b = p[1];
-                el.tag = a.x; el.flags = a.y; el.w0 = a.z; el.dd = a.w;
-                el.di = b.x; el.tiles = b.y; el.bbox_x = b.z; el.bbox_y = b.w;
-            }
-            more = fetch_index(d_cur);
+    // The stream runs two rounds ahead of its consumer: while round r is filtered and gets its coverage masks (one
+    // memory round trip for the bit-plane windows), the records of round r + 1 and the list entries of round r + 2 are
+    // already in flight.
+    auto load_el = [&](uint32_t d) -> CoarseEl {
+        CoarseEl e;
+        e.tag = DRAWTAG_NOP;
+        e.flags = 0u; e.w0 = 0u; e.dd = 0u; e.di = 0u; e.tiles = 0u; e.bbox_x = 0u; e.bbox_y = 0u;
+        if (d != NONE) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(coarse_el + d);
+            const uint4 a = p[0], b = p[1];
+            e.tag = a.x; e.flags = a.y; e.w0 = a.z; e.dd = a.w;
+            e.di = b.x; e.tiles = b.y; e.bbox_x = b.z; e.bbox_y = b.w;
+        }
+        return e;
+    };
+    uint32_t d_next;
+    bool cur_valid = fetch_index(d_next);  // round 0
+    CoarseEl el_next = load_el(d_next);
+    bool next_valid = cur_valid ? fetch_index(d_next) : false;  // entries of round 1
+    bool more = cur_valid;
+    while (cur_valid || qlen > 0u) {
+        if (cur_valid) {
+            // ---- threads as draw objects ----
+            const CoarseEl el = el_next;
+            if (next_valid) el_next = load_el(d_next);                  // records of the next round
+            const bool nn_valid = next_valid ? fetch_index(d_next) : false;  // entries of the round after it
+            cur_valid = next_valid;
+            next_valid = nn_valid;
+            more = cur_valid;
             // keep the objects whose tile rectangle meets this quadrant, in order (coarse.wgsl:264-289)
             const int32_t bx0 = (int32_t)(el.bbox_x & 0xffffu), bx1 = (int32_t)(el.bbox_x >> 16);
             const int32_t by0 = (int32_t)(el.bbox_y & 0xffffu), by1 = (int32_t)(el.bbox_y >> 16);
@@ -481,7 +496,6 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             sh.gm[wave][lane][0] = (uint32_t)gmask; sh.gm[wave][lane][1] = (uint32_t)(gmask >> 32);
             sh.pend[wave][lane] = pair_incl;
             sh.S[wave][lane] = words_of(em, gmask, k1, k2, k3);
-            sh.G[wave][lane] = 0u;
             wave_lds_sync();
             const uint32_t n_iter = (total_pairs + 63u) / 64u;
             // pair p of the slice, tile-major: which tile, which object, does it have segments
@@ -497,30 +511,15 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 b = kth_bit64(m, k);
                 has_segs = ((make64(sh.gm[wave][t][0], sh.gm[wave][t][1]) >> b) & 1ull) != 0ull;
             };
-            // COUNT: segments per tile (the words follow from the bitmaps)
-            for (uint32_t it = 0; it < n_iter; it++) {
-                const uint32_t p = it * 64u + lane;
-                if (p < total_pairs) {
-                    uint32_t t, b;
-                    bool has_segs;
-                    pair_of(p, t, b, has_segs);
-                    if (has_segs) {
-                        const uint32_t q = (q0 + b) & (QCAP - 1u);
-                        const uint32_t tile_ix = sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W);
-                        atomicAdd(&sh.G[wave][t], tiles[tile_ix].segment_count_or_ix);
-                    }
-                }
-            }
-            __syncthreads();  // (2) S, G of all slices
-            // ALLOCATE (wave 0, lane = tile): one region per tile that needs one, one atomic per counter
+            __syncthreads();  // (2) S of all slices
+            // ALLOCATE (wave 0, lane = tile): one PTCL region per tile that needs one behind ONE atomic; the command sizes
+            // follow from the bitmaps alone, so no Tile has been read yet
             if (wave == 0u) {
-                uint32_t s_w[NW], g_w[NW], W = 0u, Gt = 0u;
+                uint32_t s_w[NW], W = 0u;
 #pragma unroll
                 for (uint32_t w = 0; w < NW; w++) {
                     s_w[w] = sh.S[w][lane];
-                    g_w[w] = sh.G[w][lane];
                     W += s_w[w];
-                    Gt += g_w[w];
                 }
                 if (tile_killed && !dead) {  // everything emitted so far is covered: restart the list in the tile's own block
                     cur = list_start;
@@ -529,15 +528,10 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 const bool need = W > room && !dead;
                 const uint32_t rsize = need ? W + 2u + REGION_SLACK : 0u;
                 const uint32_t r_incl = wave_incl_scan_u32(rsize, (int)lane);
-                const uint32_t g_incl = wave_incl_scan_u32(Gt, (int)lane);
-                const uint32_t r_total = (uint32_t)__shfl((int)r_incl, 63), g_total = (uint32_t)__shfl((int)g_incl, 63);
-                uint32_t r_base = 0u, g_base = 0u;
-                if (lane == 0u) {
-                    r_base = r_total ? atomicAdd(&bump->ptcl, r_total) : 0u;
-                    g_base = g_total ? atomicAdd(&bump->segments, g_total) : 0u;
-                }
+                const uint32_t r_total = (uint32_t)__shfl((int)r_incl, 63);
+                uint32_t r_base = 0u;
+                if (lane == 0u && r_total != 0u) r_base = atomicAdd(&bump->ptcl, r_total);
                 r_base = (uint32_t)__shfl((int)r_base, 0);
-                g_base = (uint32_t)__shfl((int)g_base, 0);
                 if (need) {
                     const uint32_t start = ptcl_dyn_start + r_base + (r_incl - rsize);
                     if (start < ptcl_dyn_start || start + rsize > cfg.ptcl_size || start + rsize < start) {
@@ -549,50 +543,63 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                         room = W + REGION_SLACK;
                     }
                 }
-                uint32_t wb = dead ? NONE : cur, sb = g_base + (g_incl - Gt);
+                uint32_t wb = dead ? NONE : cur;
 #pragma unroll
                 for (uint32_t w = 0; w < NW; w++) {
                     sh.wordbase[w][lane] = wb;
-                    sh.segbase[w][lane] = sb;
                     if (!dead) wb += s_w[w];
-                    sb += g_w[w];
                 }
                 if (!dead) {
                     cur += W;
                     room -= W;
                 }
             }
-            __syncthreads();  // (3) bases
-            // EMIT: one lane per (tile, object) pair
-            {
-                uint32_t carry_t = NONE, carry_v = 0u;  // segmented scan across iterations
-                for (uint32_t it = 0; it < n_iter; it++) {
-                    const uint32_t p = it * 64u + lane;
-                    const bool valid = p < total_pairs;
-                    uint32_t t = NONE, b = 0u;
-                    bool has_segs = false;
-                    if (valid) pair_of(p, t, b, has_segs);
-                    const uint32_t q = (q0 + b) & (QCAP - 1u);
-                    const uint32_t tile_ix = valid ? sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W) : 0u;
-                    Tile tile{0, 0u};
-                    if (has_segs) tile = tiles[tile_ix];
-                    const uint32_t n_segs = tile.segment_count_or_ix;
-                    // exclusive prefix of n_segs among the pairs of the same tile (pairs are tile-major)
-                    uint32_t v = n_segs;
+            // EMIT: one lane per (tile, object) pair, EMIT_GROUP wave steps at a time: the Tile records of the group's pairs
+            // are all requested before the first is used, their segment counts are scanned once and the wave reserves the
+            // group's segment slices with ONE atomic (a slice may sit anywhere: CMD_FILL carries its index)
+            bool bases_ready = false;
+            for (uint32_t g0 = 0; g0 < n_iter; g0 += EMIT_GROUP) {
+                uint32_t info[EMIT_GROUP], tix[EMIT_GROUP];  // t | b << 8 | has_segs << 16 | valid << 17; Tile index
+                Tile tl[EMIT_GROUP];
+                uint32_t my_segs = 0u;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t ov = (uint32_t)__shfl_up((int)v, d);
-                        const uint32_t ot = (uint32_t)__shfl_up((int)t, d);
-                        if ((int)lane >= d && ot == t) v += ov;
+                for (uint32_t u = 0; u < EMIT_GROUP; u++) {
+                    const uint32_t p = (g0 + u) * 64u + lane;
+                    info[u] = 0u;
+                    tix[u] = 0u;
+                    tl[u] = Tile{0, 0u};
+                    if (g0 + u < n_iter && p < total_pairs) {
+                        uint32_t t, b;
+                        bool has_segs;
+                        pair_of(p, t, b, has_segs);
+                        const uint32_t q = (q0 + b) & (QCAP - 1u);
+                        tix[u] = sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W);
+                        info[u] = t | (b << 8) | (has_segs ? 1u << 16 : 0u) | (1u << 17);
+                        if (has_segs) tl[u] = tiles[tix[u]];
                     }
-                    if (t == carry_t) v += carry_v;
-                    const uint32_t seg_excl = v - n_segs;
-                    // (t of the last VALID lane; invalid lanes carry NONE, which no pair matches)
-                    carry_t = (uint32_t)__shfl((int)t, 63);
-                    carry_v = (uint32_t)__shfl((int)v, 63);
-                    if (!valid) continue;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < EMIT_GROUP; u++) my_segs += tl[u].segment_count_or_ix;
+                const uint32_t seg_incl = wave_incl_scan_u32(my_segs, (int)lane);
+                const uint32_t seg_total = (uint32_t)__shfl((int)seg_incl, 63);
+                uint32_t seg_next = 0u;
+                if (lane == 0u && seg_total != 0u) seg_next = atomicAdd(&bump->segments, seg_total);
+                seg_next = (uint32_t)__shfl((int)seg_next, 0) + (seg_incl - my_segs);
+                if (!bases_ready) {
+                    __syncthreads();  // (3) wave 0 has published the word bases
+                    bases_ready = true;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < EMIT_GROUP; u++) {
+                    if ((info[u] >> 17) == 0u) continue;
+                    const uint32_t t = info[u] & 0xffu, b = (info[u] >> 8) & 0xffu;
+                    const bool has_segs = ((info[u] >> 16) & 1u) != 0u;
+                    const uint32_t n_segs = tl[u].segment_count_or_ix;
+                    const uint32_t seg_ix = seg_next;
+                    seg_next += n_segs;
                     const uint32_t wbase = sh.wordbase[wave][t];
                     if (wbase == NONE) continue;
+                    const uint32_t q = (q0 + b) & (QCAP - 1u);
                     const u64 m = make64(sh.em[wave][t][0], sh.em[wave][t][1]);
                     const u64 g = make64(sh.gm[wave][t][0], sh.gm[wave][t][1]);
                     const u64 bel = below64(b);
@@ -604,10 +611,9 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                     }
                     const uint32_t draw_flags = sh.flags[q];
                     if (has_segs) {  // coarse.wgsl:88-110
-                        const uint32_t seg_ix = sh.segbase[wave][t] + seg_excl;
-                        tiles[tile_ix].segment_count_or_ix = ~seg_ix;
+                        tiles[tix[u]].segment_count_or_ix = ~seg_ix;
                         const uint32_t even_odd = (draw_flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u ? 1u : 0u;
-                        *reinterpret_cast<PtclWords4 *>(ptcl + off) = PtclWords4{CMD_FILL, (n_segs << 1) | even_odd, seg_ix, (uint32_t)tile.backdrop};
+                        *reinterpret_cast<PtclWords4 *>(ptcl + off) = PtclWords4{CMD_FILL, (n_segs << 1) | even_odd, seg_ix, (uint32_t)tl[u].backdrop};
                         off += 4u;
                     } else {
                         ptcl[off] = CMD_SOLID;
@@ -626,6 +632,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                     }
                 }
             }
+            if (!bases_ready) __syncthreads();  // (3) for the waves whose slice emits nothing
             qh = (qh + n) & (QCAP - 1u);
             qlen -= n;
             __syncthreads();  // (4) the per-batch tables and the freed queue slots are rewritten next
