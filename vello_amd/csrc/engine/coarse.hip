@@ -67,7 +67,7 @@ struct CoarseLds {
     uint32_t di[QCAP];
     uint32_t base[QCAP];    // Tile index of quadrant-local (0, 0) in the path's tile rectangle (may lie outside it)
     uint32_t stride[QCAP];
-    uint32_t rect[QCAP];    // x0 | y0 << 4 | w << 8 | h << 12 | kind << 16, quadrant-local
+    uint32_t kind[QCAP];    // KIND_*
     uint32_t cover[QCAP][8];  // 64-bit masks over the quadrant (bit = y * 8 + x): included, occluder, has segments, backdrop clear
     // per batch: [w][t] = wave-slice w (64 objects), tile t
     uint32_t em[NW][64][2];   // objects of the slice that emit commands for the tile
@@ -290,13 +290,56 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             cur_valid = next_valid;
             next_valid = nn_valid;
             more = cur_valid;
-            // keep the objects whose tile rectangle meets this quadrant, in order (coarse.wgsl:264-289)
+            // An object matters to this quadrant if its tile rectangle meets it (coarse.wgsl:264-289) AND at least one of
+            // those tiles is included (coarse.wgsl:318-341): its 64-bit coverage masks come from <= 8 row windows of the
+            // bit planes (the reference reads a Tile per (object, tile) pair and sets LDS bits with atomics), and an
+            // object whose mask is empty -- most of a road's bounding box -- is never queued.
             const int32_t bx0 = (int32_t)(el.bbox_x & 0xffffu), bx1 = (int32_t)(el.bbox_x >> 16);
             const int32_t by0 = (int32_t)(el.bbox_y & 0xffffu), by1 = (int32_t)(el.bbox_y >> 16);
             const int32_t dx = bx0 - (int32_t)sub_x0, dy = by0 - (int32_t)sub_y0;
             const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, 0, (int32_t)SUB_W);
             const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, 0, (int32_t)SUB_W);
-            const bool keep = el.tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
+            const bool meets = el.tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
+            const uint32_t stride = (uint32_t)(bx1 - bx0);
+            const uint32_t base = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
+            u64 inc = 0ull, kil = 0ull, seg = 0ull, clr = 0ull;
+            if (meets) {
+                const uint32_t rx0 = (uint32_t)x0, ry0 = (uint32_t)y0, w = (uint32_t)(x1 - x0), h = (uint32_t)(y1 - y0);
+                const bool is_clip = (el.tag & 1u) != 0u;
+                const uint32_t BLEND_CLIP = (128u << 8) | 3u;
+                const bool is_blend = is_clip && el.w0 != BLEND_CLIP;
+                const bool even_odd = (el.flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
+                const uint32_t *plane_c = even_odd ? plane_o : plane_z;
+                const uint32_t wmask = (1u << w) - 1u;
+                u64 ws[SUB_W], wc[SUB_W];
+#pragma unroll
+                for (uint32_t r = 0; r < SUB_W; r++) {
+                    ws[r] = 0ull;
+                    wc[r] = 0ull;
+                    if (r < h) {
+                        const uint32_t b = base + stride * (ry0 + r) + rx0;
+                        ws[r] = plane_window(plane_s, b);
+                        wc[r] = plane_window(plane_c, b);
+                    }
+                }
+#pragma unroll
+                for (uint32_t r = 0; r < SUB_W; r++) {
+                    if (r < h) {
+                        const uint32_t sg = (uint32_t)ws[r] & wmask;
+                        const uint32_t clear = (uint32_t)wc[r] & wmask;  // backdrop_clear per tile of the row
+                        // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
+                        const uint32_t in = is_blend ? wmask : (sg | ((is_clip ? clear : ~clear) & wmask));
+                        const uint32_t shift = (ry0 + r) * SUB_W + rx0;
+                        inc |= (u64)in << shift;
+                        kil |= (u64)(in & ~sg) << shift;
+                        seg |= (u64)(in & sg) << shift;
+                        clr |= (u64)(in & clear) << shift;
+                    }
+                }
+                // fully covering opaque solid colour: occludes every earlier draw of the tile
+                if (!(cull && el.tag == DRAWTAG_FILL_COLOR && (el.w0 >> 24) == 0xffu)) kil = 0ull;
+            }
+            const bool keep = inc != 0ull;
             const u64 m = __ballot(keep);
             if (lane == 0u) sh.wave_cnt[wave] = popc64(m);
             __syncthreads();
@@ -307,10 +350,8 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 if (w < wave) before += c;
                 total_new += c;
             }
-            const uint32_t q_new = qh + qlen;  // (un-wrapped) slot of the first object appended this round
             if (keep) {
-                const uint32_t q = (q_new + before + popc64(m & below64(lane))) & (QCAP - 1u);
-                const uint32_t stride = (uint32_t)(bx1 - bx0);
+                const uint32_t q = (qh + qlen + before + popc64(m & below64(lane))) & (QCAP - 1u);
                 uint32_t kind = KIND_NONE;
                 switch (el.tag) {
                 case DRAWTAG_FILL_COLOR: case DRAWTAG_FILL_IMAGE: kind = KIND_PATH2; break;
@@ -325,57 +366,14 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 sh.dd[q] = el.dd;
                 sh.di[q] = el.di;
                 sh.stride[q] = stride;
-                sh.base[q] = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
-                sh.rect[q] = (uint32_t)x0 | ((uint32_t)y0 << 4) | ((uint32_t)(x1 - x0) << 8) | ((uint32_t)(y1 - y0) << 12) | (kind << 16);
-            }
-            qlen += total_new;
-            __syncthreads();
-            // coverage masks of the new objects, one object per thread: <= 8 row windows of the bit planes
-            // (coarse.wgsl:290-347 reads a Tile per (object, tile) pair and sets LDS bits with atomics)
-            if (tid < total_new) {
-                const uint32_t q = (q_new + tid) & (QCAP - 1u);
-                const uint32_t rect = sh.rect[q], tag = sh.tag[q], w0 = sh.w0[q];
-                const uint32_t rx0 = rect & 15u, ry0 = (rect >> 4) & 15u, w = (rect >> 8) & 15u, h = (rect >> 12) & 15u;
-                const uint32_t base = sh.base[q], stride = sh.stride[q];
-                const bool is_clip = (tag & 1u) != 0u;
-                const uint32_t BLEND_CLIP = (128u << 8) | 3u;
-                const bool is_blend = is_clip && w0 != BLEND_CLIP;
-                const bool even_odd = (sh.flags[q] & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
-                const uint32_t *plane_c = even_odd ? plane_o : plane_z;
-                const uint32_t wmask = (1u << w) - 1u;
-                u64 ws[SUB_W], wc[SUB_W];
-#pragma unroll
-                for (uint32_t r = 0; r < SUB_W; r++) {
-                    ws[r] = 0ull;
-                    wc[r] = 0ull;
-                    if (r < h) {
-                        const uint32_t b = base + stride * (ry0 + r) + rx0;
-                        ws[r] = plane_window(plane_s, b);
-                        wc[r] = plane_window(plane_c, b);
-                    }
-                }
-                u64 inc = 0ull, kil = 0ull, seg = 0ull, clr = 0ull;
-#pragma unroll
-                for (uint32_t r = 0; r < SUB_W; r++) {
-                    if (r < h) {
-                        const uint32_t s = (uint32_t)ws[r] & wmask;
-                        const uint32_t clear = (uint32_t)wc[r] & wmask;  // backdrop_clear per tile of the row
-                        // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
-                        const uint32_t in = is_blend ? wmask : (s | ((is_clip ? clear : ~clear) & wmask));
-                        const uint32_t shift = (ry0 + r) * SUB_W + rx0;
-                        inc |= (u64)in << shift;
-                        kil |= (u64)(in & ~s) << shift;
-                        seg |= (u64)(in & s) << shift;
-                        clr |= (u64)(in & clear) << shift;
-                    }
-                }
-                // fully covering opaque solid colour: occludes every earlier draw of the tile
-                if (!(cull && tag == DRAWTAG_FILL_COLOR && (w0 >> 24) == 0xffu)) kil = 0ull;
+                sh.base[q] = base;
+                sh.kind[q] = kind;
                 sh.cover[q][0] = (uint32_t)inc; sh.cover[q][1] = (uint32_t)(inc >> 32);
                 sh.cover[q][2] = (uint32_t)kil; sh.cover[q][3] = (uint32_t)(kil >> 32);
                 sh.cover[q][4] = (uint32_t)seg; sh.cover[q][5] = (uint32_t)(seg >> 32);
                 sh.cover[q][6] = (uint32_t)clr; sh.cover[q][7] = (uint32_t)(clr >> 32);
             }
+            qlen += total_new;
             __syncthreads();
         }
 
@@ -385,7 +383,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             const uint32_t cnt = n > wave * 64u ? minu(n - wave * 64u, 64u) : 0u;  // objects of this wave's slice
             const uint32_t q0 = qh + wave * 64u;
             // lanes as objects of the slice: which kinds are where (wave-uniform masks)
-            const uint32_t my_kind = lane < cnt ? (sh.rect[(q0 + lane) & (QCAP - 1u)] >> 16) : KIND_NONE;
+            const uint32_t my_kind = lane < cnt ? (sh.kind[(q0 + lane) & (QCAP - 1u)]) : KIND_NONE;
             const u64 k1 = __ballot(my_kind == KIND_PATH2), k2 = __ballot(my_kind == KIND_PATH3), k3 = __ballot(my_kind == KIND_BEGIN);
             const u64 k_end = has_clips ? __ballot(lane < cnt && sh.tag[(q0 + lane) & (QCAP - 1u)] == DRAWTAG_END_CLIP) : 0ull;
             // lanes as tiles: transpose the objects' masks into this tile's bitmaps over the slice
