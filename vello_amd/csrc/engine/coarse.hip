@@ -105,6 +105,23 @@ __device__ __forceinline__ uint32_t kth_bit64(u64 m, uint32_t k) {
     return pos;
 }
 
+// Transpose of a 64 x 64 bit matrix held one row per lane: afterwards bit e of lane t is what bit t of lane e was.
+// Six butterfly steps (swap the off-diagonal j x j blocks between lanes r and r ^ j), 2 shuffles each.
+__device__ __forceinline__ u64 transpose64(u64 x, uint32_t lane) {
+    const u64 masks[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull, 0x00ff00ff00ff00ffull,
+                          0x0f0f0f0f0f0f0f0full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+    for (uint32_t s = 0; s < 6u; s++) {
+        const uint32_t j = 32u >> s;
+        const u64 mask = masks[s];  // columns c with (c & j) == 0
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)x, (int)j), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), (int)j);
+        const u64 other = make64(olo, ohi);
+        if ((lane & j) == 0u) x = (x & mask) | ((other & mask) << j);
+        else x = (x & ~mask) | ((other & ~mask) >> j);
+    }
+    return x;
+}
+
 // words the objects of mask m (those of gmask with CMD_FILL) emit: FILL 4 / SOLID 1 + draw command 2 or 3; BEGIN 1
 __device__ __forceinline__ uint32_t words_of(u64 m, u64 g, u64 k1, u64 k2, u64 k3) {
     return 3u * popc64(g) + 3u * popc64(m & k1) + 4u * popc64(m & k2) + popc64(m & k3);
@@ -386,27 +403,21 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             const uint32_t my_kind = lane < cnt ? (sh.kind[(q0 + lane) & (QCAP - 1u)]) : KIND_NONE;
             const u64 k1 = __ballot(my_kind == KIND_PATH2), k2 = __ballot(my_kind == KIND_PATH3), k3 = __ballot(my_kind == KIND_BEGIN);
             const u64 k_end = has_clips ? __ballot(lane < cnt && sh.tag[(q0 + lane) & (QCAP - 1u)] == DRAWTAG_END_CLIP) : 0ull;
-            // lanes as tiles: transpose the objects' masks into this tile's bitmaps over the slice
-            u64 inc = 0ull, seg = 0ull, clr = 0ull;
-            uint32_t klast = 0u;
-            {
-                const uint32_t half = lane >> 5, sh_l = lane & 31u;
-                uint32_t inc_w[2] = {0u, 0u}, seg_w[2] = {0u, 0u}, clr_w[2] = {0u, 0u};
-#pragma unroll
-                for (uint32_t hh = 0; hh < 2u; hh++) {
-                    const uint32_t c_h = cnt > hh * 32u ? minu(cnt - hh * 32u, 32u) : 0u;
-                    for (uint32_t b = 0; b < c_h; b++) {
-                        const uint32_t *c = sh.cover[(q0 + hh * 32u + b) & (QCAP - 1u)];
-                        inc_w[hh] |= ((c[half] >> sh_l) & 1u) << b;
-                        seg_w[hh] |= ((c[4u + half] >> sh_l) & 1u) << b;
-                        if (cull && ((c[2u + half] >> sh_l) & 1u) != 0u) klast = hh * 32u + b + 1u;
-                        if (has_clips) clr_w[hh] |= ((c[6u + half] >> sh_l) & 1u) << b;
-                    }
-                }
-                inc = make64(inc_w[0], inc_w[1]);
-                seg = make64(seg_w[0], seg_w[1]);
-                clr = make64(clr_w[0], clr_w[1]);
+            // lanes as objects -> lanes as tiles: the slice's 64 coverage masks (one per object, a bit per tile) become
+            // 64 bitmaps (one per tile, a bit per object) by a 64 x 64 bit-matrix transpose in registers
+            u64 inc = 0ull, seg = 0ull, clr = 0ull, kil = 0ull;
+            if (lane < cnt) {
+                const uint32_t *c = sh.cover[(q0 + lane) & (QCAP - 1u)];
+                inc = make64(c[0], c[1]);
+                if (cull) kil = make64(c[2], c[3]);
+                seg = make64(c[4], c[5]);
+                if (has_clips) clr = make64(c[6], c[7]);
             }
+            inc = transpose64(inc, lane);
+            seg = transpose64(seg, lane);
+            if (cull) kil = transpose64(kil, lane);
+            if (has_clips) clr = transpose64(clr, lane);
+            const uint32_t klast = kil != 0ull ? 64u - (uint32_t)__clzll((long long)kil) : 0u;  // 1 + the tile's last occluder
             sh.kslice[wave][lane] = klast;
             if (has_clips) {
                 sh.em[wave][lane][0] = (uint32_t)inc; sh.em[wave][lane][1] = (uint32_t)(inc >> 32);
@@ -509,6 +520,28 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 b = kth_bit64(m, k);
                 has_segs = ((make64(sh.gm[wave][t][0], sh.gm[wave][t][1]) >> b) & 1ull) != 0ull;
             };
+            // the Tile records of a group's pairs, all requested before the first is used
+            auto load_group = [&](uint32_t g0, uint32_t (&info)[EMIT_GROUP], uint32_t (&tix)[EMIT_GROUP], Tile (&tl)[EMIT_GROUP]) {
+#pragma unroll
+                for (uint32_t u = 0; u < EMIT_GROUP; u++) {
+                    const uint32_t p = (g0 + u) * 64u + lane;
+                    info[u] = 0u;
+                    tix[u] = 0u;
+                    tl[u] = Tile{0, 0u};
+                    if (g0 + u < n_iter && p < total_pairs) {
+                        uint32_t t, b;
+                        bool has_segs;
+                        pair_of(p, t, b, has_segs);
+                        const uint32_t q = (q0 + b) & (QCAP - 1u);
+                        tix[u] = sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W);
+                        info[u] = t | (b << 8) | (has_segs ? 1u << 16 : 0u) | (1u << 17);
+                        if (has_segs) tl[u] = tiles[tix[u]];
+                    }
+                }
+            };
+            uint32_t info[EMIT_GROUP], tix[EMIT_GROUP];  // t | b << 8 | has_segs << 16 | valid << 17; Tile index
+            Tile tl[EMIT_GROUP];
+            load_group(0u, info, tix, tl);  // in flight across the barrier and wave 0's allocation
             __syncthreads();  // (2) S of all slices
             // ALLOCATE (wave 0, lane = tile): one PTCL region per tile that needs one behind ONE atomic; the command sizes
             // follow from the bitmaps alone, so no Tile has been read yet
@@ -552,30 +585,13 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                     room -= W;
                 }
             }
-            // EMIT: one lane per (tile, object) pair, EMIT_GROUP wave steps at a time: the Tile records of the group's pairs
-            // are all requested before the first is used, their segment counts are scanned once and the wave reserves the
+            // EMIT: one lane per (tile, object) pair, EMIT_GROUP wave steps at a time: the segment counts of the group's Tile
+            // records are scanned once and the wave reserves the
             // group's segment slices with ONE atomic (a slice may sit anywhere: CMD_FILL carries its index)
             bool bases_ready = false;
             for (uint32_t g0 = 0; g0 < n_iter; g0 += EMIT_GROUP) {
-                uint32_t info[EMIT_GROUP], tix[EMIT_GROUP];  // t | b << 8 | has_segs << 16 | valid << 17; Tile index
-                Tile tl[EMIT_GROUP];
+                if (g0 != 0u) load_group(g0, info, tix, tl);
                 uint32_t my_segs = 0u;
-#pragma unroll
-                for (uint32_t u = 0; u < EMIT_GROUP; u++) {
-                    const uint32_t p = (g0 + u) * 64u + lane;
-                    info[u] = 0u;
-                    tix[u] = 0u;
-                    tl[u] = Tile{0, 0u};
-                    if (g0 + u < n_iter && p < total_pairs) {
-                        uint32_t t, b;
-                        bool has_segs;
-                        pair_of(p, t, b, has_segs);
-                        const uint32_t q = (q0 + b) & (QCAP - 1u);
-                        tix[u] = sh.base[q] + sh.stride[q] * (t / SUB_W) + (t % SUB_W);
-                        info[u] = t | (b << 8) | (has_segs ? 1u << 16 : 0u) | (1u << 17);
-                        if (has_segs) tl[u] = tiles[tix[u]];
-                    }
-                }
 #pragma unroll
                 for (uint32_t u = 0; u < EMIT_GROUP; u++) my_segs += tl[u].segment_count_or_ix;
                 const uint32_t seg_incl = wave_incl_scan_u32(my_segs, (int)lane);
