@@ -25,6 +25,9 @@
  *   vello_hip_get_bump         the robust path's bump download           vello/src/lib.rs:730, :753-761
  *   vello_hip_grow_pools /     "TODO: apply logic to determine whether   vello/src/lib.rs:762-764,
  *   vello_hip_set_auto_grow    we need to rerun coarse" + pool sizes     vello_encoding/src/config.rs:398-408
+ *   vello_hip_estimate_capacities  BumpEstimator::count_path / tally      vello_encoding/src/estimate.rs:54-190
+ *   vello_hip_gather_frames /  (none upstream: one Renderer per wgpu Device;  SURVEY.md 8e
+ *   vello_hip_gather_wait      the scenes-per-GPU exchange of BASELINE config C5)
  *   vello_hip_set_debug_flags  (test seam: reference-exact coarse output)  vello_shaders/shader/coarse.wgsl:156-471
  *   vello_hip_run_stages /     CpuShaderType::Present per-stage seam     vello/src/wgpu_engine.rs:57-61, :541-553,
  *   vello_hip_{read,write}_buffer  (CpuBinding byte buffers)             vello_shaders/src/cpu.rs:58-62
@@ -184,6 +187,16 @@ int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t w
 int vello_hip_get_capacities(vello_hip_ctx *ctx, vello_hip_capacities *out);
 int vello_hip_grow_pools(vello_hip_ctx *ctx, const vello_hip_bump *demand, vello_hip_capacities *new_caps /* nullable */);
 int vello_hip_set_auto_grow(vello_hip_ctx *ctx, int enabled);
+/* vello_encoding::BumpEstimator (vello_encoding/src/estimate.rs:54-190) applied to the packed scene: conservative
+ * pool sizes for this scene at this target size, computed on the host without touching the GPU.  Lines and segments
+ * follow the reference's counting rules (Wang's formula for curves, sqrt(2)-inflated tile crossings, arc counts of
+ * round joins / caps); tiles, bin entries and PTCL words -- TODO upstream (estimate.rs:14-16) -- come from the paths'
+ * control-point bounding boxes.  blend_spill is not estimated (0).  With vello_hip_set_auto_grow the blocking
+ * vello_hip_render calls this itself when the scene is large against the current pools. */
+/* How many rounds the last blocking vello_hip_render took (1 unless robust mode had to grow pools and re-run). */
+uint32_t vello_hip_last_render_attempts(vello_hip_ctx *ctx);
+int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                                  const vello_hip_render_params *params, vello_hip_capacities *out);
 
 /* Test-seam switches (default 0).  VELLO_HIP_DEBUG_NO_CULL turns off coarse's occlusion culling (a draw hidden under a
  * later opaque full-tile cover is normally not emitted; the image is the same, but bump.segments / bump.ptcl and the
@@ -204,6 +217,15 @@ int vello_hip_sync(vello_hip_ctx *ctx);
 int vello_hip_get_bump(vello_hip_ctx *ctx, vello_hip_bump *out);
 /* The hipStream_t the context launches on (for callers that record their own events). */
 void *vello_hip_get_stream(vello_hip_ctx *ctx);
+
+/* Multi-GPU exchange for a host that owns one context per GPU in one process: the frame each context
+ * enqueued last (src_frames[i], device memory of ctxs[i]'s GPU) is copied to dst_frames[i] on `dst_device` with
+ * hipMemcpyPeerAsync on a per-context copy stream, ordered behind that frame by an event: SDMA over the peer's own xGMI
+ * link, no CUs, all peers concurrently.  Returns without waiting; vello_hip_gather_wait blocks until the copies have
+ * landed.  (One process per GPU gathers with RCCL instead: vello_amd/distributed.py, bench.py --gpus N.) */
+int vello_hip_gather_frames(vello_hip_ctx *const *ctxs, uint32_t n, int dst_device, const void *const *src_frames, void *const *dst_frames,
+                            size_t frame_bytes);
+int vello_hip_gather_wait(vello_hip_ctx *const *ctxs, uint32_t n);
 
 /* Differential-test seam: run stages [first, last] of the resident scene; read/write any buffer. */
 int vello_hip_run_stages(vello_hip_ctx *ctx, const vello_hip_render_params *params, int first_stage, int last_stage);

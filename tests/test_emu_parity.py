@@ -683,3 +683,69 @@ def test_emu_target_buffers_are_validated(emu_engine):
         emu_engine.render_resident(20, 20, BLACK, AaConfig.Area, out=small)
     with pytest.raises((ValueError, AssertionError)):
         emu_engine.render_resident(20, 20, BLACK, AaConfig.Area, out=torch.zeros((20, 20, 4), dtype=torch.float32))
+
+
+def test_emu_estimator_presizes_the_pools(built):
+    # SURVEY 8f f4, second half (vello_encoding/src/estimate.rs): the estimate covers the real demand of every pool, and
+    # with it robust mode renders from 64-element pools in ONE round instead of one round per overflowing stage
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+    from vello_amd.renderer import estimate_capacities
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        tiger = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiger_scene.npz"))
+        cases = [workloads.stroke_styles_scene().resolve() + (256, 256), workloads.clip_blend_scene().resolve() + (256, 256),
+                 workloads.random_test_scene(11, n_paths=150, size=300.0, strokes=True, clips=True).resolve() + (300, 300),
+                 workloads.heavy_strokes_scene().resolve() + (1024, 1024),
+                 (tiger["packed"], vello_amd.Layout(*[int(v) for v in tiger["layout"]]), 1024, 1024)]
+        for packed, layout, w, h in cases:
+            o = Oracle(capacity_scale=2)
+            o.set_scene(packed, layout, w, h, WHITE, int(AaConfig.Msaa8))
+            ref = o.render()
+            need = o.bump()
+            est = estimate_capacities(packed, layout, w, h)
+            assert est["lines"] >= need["lines"] and est["seg_counts"] >= need["seg_counts"] and est["segments"] >= need["segments"]
+            assert est["tiles"] >= need["tile"] and est["bin_data"] >= layout.bin_data_start + need["binning"]
+            tiny = {"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 64, "bin_data": layout.bin_data_start + 64,
+                    "ptcl": 64 * ((w + 15) // 16) * ((h + 15) // 16) + 512}
+            eng = vello_amd.Engine(capacities=tiny)
+            eng.set_auto_grow(True)
+            img, bump = eng.render(packed, layout, w, h, WHITE, AaConfig.Msaa8)
+            assert bump["failed"] == 0 and np.array_equal(img, ref)
+            assert eng.last_render_attempts() == 1, (eng.last_render_attempts(), est, need)
+    finally:
+        L._use_library(None)
+
+
+def test_emu_gather_frames_between_contexts(built):
+    # vello_hip_gather_frames (single-process form): two contexts, each frame lands in its slot of the
+    # destination; here both "GPUs" are the emulated device, on hardware the same call runs peer copies over xGMI
+    import vello_amd
+    import vello_amd._lib as L
+    from oracle.oracle import Oracle
+    from vello_amd.renderer import gather_frames
+
+    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    try:
+        scenes = [workloads.stroke_styles_scene(), workloads.clip_blend_scene()]
+        engines, srcs, refs = [], [], []
+        for sc in scenes:
+            packed, layout = sc.resolve()
+            e = vello_amd.Engine()
+            e.upload_scene(packed, layout)
+            src = np.zeros((128, 128, 4), dtype=np.uint8)
+            e._check(e._lib.vello_hip_render_resident(e._h, __import__("ctypes").byref(e._params(128, 128, BLACK, AaConfig.Msaa8)),
+                                                      src.ctypes.data, 128 * 4), "render_resident")
+            o = Oracle()
+            o.set_scene(packed, layout, 128, 128, BLACK, int(AaConfig.Msaa8))
+            refs.append(o.render())
+            engines.append(e)
+            srcs.append(src)
+        dst = np.zeros((2, 128, 128, 4), dtype=np.uint8)
+        gather_frames(engines, [s.ctypes.data for s in srcs], [dst[i].ctypes.data for i in range(2)], 128 * 128 * 4)
+        for i in range(2):
+            assert np.array_equal(dst[i], refs[i])
+    finally:
+        L._use_library(None)

@@ -587,3 +587,55 @@ def test_large_target_with_auto_grow(built):
     o.set_threads(32)
     o.set_scene(packed, layout, 6000, 6000, BLACK, int(AaConfig.Msaa8))
     assert np.array_equal(img, o.render())
+
+
+def test_estimator_gives_one_round_from_tiny_pools(built):
+    # vello_hip_estimate_capacities + robust mode: the 42k-path scene of test_auto_grow_beyond_reference_pools
+    # and a curve-heavy one render in ONE round from pools of 64 elements
+    import vello_amd
+    from oracle.oracle import Oracle
+    from vello_amd.renderer import estimate_capacities
+
+    tiger = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+    for packed, layout, w, h in (workloads.paris_like_scene(n_paths=42000, size=1000.0).resolve() + (1000, 1000),
+                                 (tiger["packed"], Layout(*[int(v) for v in tiger["layout"]]), 1024, 1024)):
+        o = Oracle(capacity_scale=4)
+        o.set_scene(packed, layout, w, h, WHITE, int(AaConfig.Msaa16))
+        ref = o.render()
+        need = o.bump()
+        est = estimate_capacities(packed, layout, w, h)
+        assert est["lines"] >= need["lines"] and est["seg_counts"] >= need["seg_counts"] and est["tiles"] >= need["tile"]
+        eng = vello_amd.Engine(device=0, capacities={"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 64,
+                                                     "bin_data": layout.bin_data_start + 64, "ptcl": 64 * ((w + 15) // 16) * ((h + 15) // 16) + 512})
+        eng.set_auto_grow(True)
+        img, bump = eng.render(packed, layout, w, h, WHITE, AaConfig.Msaa16)
+        assert bump["failed"] == 0 and np.array_equal(img, ref)
+        assert eng.last_render_attempts() == 1
+
+
+def test_gather_frames_peer_copy(built):
+    # vello_hip_gather_frames on hardware: two contexts on GPU 0 (the single-GPU form of the per-GPU contexts of a
+    # one-process host), hipMemcpyPeerAsync on per-context copy streams ordered behind the frames by events
+    import torch
+    import vello_amd
+    from oracle.oracle import Oracle
+    from vello_amd.renderer import gather_frames
+
+    scenes = [workloads.stroke_styles_scene(), workloads.clip_blend_scene(), workloads.random_test_scene(5, n_paths=200, size=256.0)]
+    engines, srcs, refs = [], [], []
+    for sc in scenes:
+        packed, layout = sc.resolve()
+        e = vello_amd.Engine(device=0)
+        e.upload_scene(packed, layout)
+        src = torch.zeros((256, 256, 4), dtype=torch.uint8, device="cuda:0")
+        e.render_resident(256, 256, BLACK, AaConfig.Msaa16, out=src)   # NOT waited for: the gather orders itself behind it
+        o = Oracle()
+        o.set_scene(packed, layout, 256, 256, BLACK, int(AaConfig.Msaa16))
+        refs.append(o.render())
+        engines.append(e)
+        srcs.append(src)
+    dst = torch.zeros((3, 256, 256, 4), dtype=torch.uint8, device="cuda:0")
+    gather_frames(engines, srcs, [dst[i] for i in range(3)], 256 * 256 * 4)
+    out = dst.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(out[i], refs[i]), i

@@ -76,7 +76,10 @@ struct vello_hip_ctx {
     uint32_t n_active = 1;  // lanes in the rotation (<= lanes.size(): shrinking keeps the buffers)
     uint32_t next_lane = 0, last_lane = 0;
     bool auto_grow = false;
+    hipStream_t copy_stream = nullptr;  // vello_hip_gather_frames: this context's peer copy
+    hipEvent_t frame_done = nullptr;
     uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
+    uint32_t last_render_attempts = 0;  // rounds the last vello_hip_render needed (robust mode)
     // last frame
     Config cfg{};
     bool have_cfg = false;
@@ -474,6 +477,8 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->frame_done) (void)hipEventDestroy(c->frame_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto &l : c->lanes)
         for (DevBuf *b : {&l.own.scene, &l.own.ramps})
             if (b->ptr) (void)hipFree(b->ptr);
@@ -726,6 +731,8 @@ int vello_hip_sync(vello_hip_ctx *c) {
     return first;
 }
 
+uint32_t vello_hip_last_render_attempts(vello_hip_ctx *c) { return c ? c->last_render_attempts : 0u; }
+
 void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
 
 int vello_hip_get_capacities(vello_hip_ctx *c, vello_hip_capacities *out) {
@@ -782,6 +789,45 @@ int vello_hip_grow_pools(vello_hip_ctx *c, const vello_hip_bump *demand, vello_h
     return VELLO_HIP_OK;
 }
 
+// The one exchange step of the path for a host that owns one context per GPU in ONE process: every
+// context's finished frame goes to `dst_device` with hipMemcpyPeerAsync on that context's own copy stream -- the SDMA
+// engines move it over the peer's own xGMI link, no CU is involved and the copies of different peers run concurrently
+// -- ordered behind the frame the context enqueued last by an event, not by a host wait.  (One process per GPU, as
+// bench.py runs, gathers with RCCL instead: vello_amd/distributed.py.)
+int vello_hip_gather_frames(vello_hip_ctx *const *ctxs, uint32_t n, int dst_device, const void *const *src_frames, void *const *dst_frames,
+                            size_t frame_bytes) {
+    if (!ctxs || !src_frames || !dst_frames || n == 0) return VELLO_HIP_E_INVALID;
+    for (uint32_t i = 0; i < n; i++) {
+        vello_hip_ctx *c = ctxs[i];
+        if (!c || !src_frames[i] || !dst_frames[i]) return VELLO_HIP_E_INVALID;
+        HIP_TRY(c, hipSetDevice(c->device));
+        if (!c->copy_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->frame_done, hipEventDisableTiming));
+            if (c->device != dst_device) {
+                hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);  // direct xGMI path; already enabled is fine
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();  // staged copies still work
+            }
+        }
+        HIP_TRY(c, hipEventRecord(c->frame_done, c->lanes[c->last_lane].stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->frame_done, 0));
+        HIP_TRY(c, hipMemcpyPeerAsync(dst_frames[i], dst_device, src_frames[i], c->device, frame_bytes, c->copy_stream));
+    }
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_gather_wait(vello_hip_ctx *const *ctxs, uint32_t n) {
+    if (!ctxs) return VELLO_HIP_E_INVALID;
+    for (uint32_t i = 0; i < n; i++) {
+        vello_hip_ctx *c = ctxs[i];
+        if (!c) return VELLO_HIP_E_INVALID;
+        if (!c->copy_stream) continue;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    }
+    return VELLO_HIP_OK;
+}
+
 int vello_hip_set_debug_flags(vello_hip_ctx *c, uint32_t flags) {
     if (!c) return VELLO_HIP_E_INVALID;
     c->debug_flags = flags;
@@ -794,16 +840,60 @@ int vello_hip_set_auto_grow(vello_hip_ctx *c, int enabled) {
     return VELLO_HIP_OK;
 }
 
+// Robust mode, before the first attempt: when the scene is large against the current pools, size them from
+// vello_hip_estimate_capacities (estimate.rs's counting rules on the packed scene) instead of finding the demand by
+// overflowing stage after stage.  The cheap test first: every path segment yields at least one line.
+static int presize_pools(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
+                         const vello_hip_render_params *params) {
+    if (!scene || !layout || !params || layout->path_tag_base > layout->path_data_base || (size_t)layout->path_data_base * 4u > scene_len)
+        return VELLO_HIP_OK;  // the upload refuses it with a message
+    const uint8_t *tags = scene + (size_t)layout->path_tag_base * 4u;
+    const size_t n_tags = ((size_t)layout->path_data_base - layout->path_tag_base) * 4u;
+    uint64_t n_seg = 0;
+    for (size_t i = 0; i < n_tags; i++) n_seg += (tags[i] & 3u) != 0u;
+    const uint64_t n_tiles = (uint64_t)((params->width + 15u) / 16u) * ((params->height + 15u) / 16u);
+    if (4u * n_seg <= c->caps.lines && 8u * n_seg <= c->caps.seg_counts && 4u * n_seg + 8u * layout->n_paths <= c->caps.tiles &&
+        160u * n_tiles + 16u * n_seg <= c->caps.ptcl)
+        return VELLO_HIP_OK;
+    vello_hip_capacities est;
+    if (vello_hip_estimate_capacities(scene, scene_len, layout, params, &est) != VELLO_HIP_OK) return VELLO_HIP_OK;
+    vello_hip_capacities d = c->caps;
+    bool grew = false;
+    auto want = [&](uint32_t &cap, uint32_t need) {
+        if (need > cap) {
+            cap = need;
+            grew = true;
+        }
+    };
+    want(d.lines, est.lines);
+    want(d.bin_data, est.bin_data);
+    want(d.tiles, est.tiles);
+    want(d.seg_counts, est.seg_counts);
+    want(d.segments, est.segments);
+    want(d.ptcl, est.ptcl);
+    if (d.segments < d.seg_counts) d.segments = d.seg_counts;
+    if (!grew) return VELLO_HIP_OK;
+    int r = sync_all(c);
+    if (r) return r;
+    c->caps = d;
+    for (auto &l : c->lanes)
+        if ((r = alloc_lane_pools(c, l))) return r;
+    return VELLO_HIP_OK;
+}
+
 int vello_hip_render(vello_hip_ctx *c, const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                      const vello_hip_render_params *params, const uint32_t *ramps, uint32_t n_ramps, void *out_rgba8, size_t out_stride,
                      int out_is_device, vello_hip_bump *bump_out) {
     if (!c || !params) return VELLO_HIP_E_INVALID;
-    int r = vello_hip_upload_scene(c, scene, scene_len, layout, ramps, n_ramps);
+    int r;
+    if (c->auto_grow && (r = presize_pools(c, scene, scene_len, layout, params))) return r;
+    r = vello_hip_upload_scene(c, scene, scene_len, layout, ramps, n_ramps);
     if (r) return r;
     int sync_r = VELLO_HIP_OK;
     // robust mode: re-run with grown pools until the frame fits (each overflowing stage hides the demand of
     // the stages behind it, so a handful of rounds at most)
     for (int attempt = 0; attempt < 8; attempt++) {
+        c->last_render_attempts = (uint32_t)attempt + 1u;
         r = vello_hip_render_resident(c, params, out_is_device ? out_rgba8 : nullptr, out_stride);
         if (r) return r;
         Lane &l = c->lanes[c->last_lane];

@@ -213,6 +213,9 @@ class Engine:
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments)."""
         self._check(self._lib.vello_hip_set_debug_flags(self._h, 1 if no_cull else 0), "set_debug_flags")
 
+    def last_render_attempts(self):
+        return int(self._lib.vello_hip_last_render_attempts(self._h))
+
     def set_frames_in_flight(self, n):
         self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
 
@@ -261,3 +264,37 @@ class Engine:
         cnt = (ctypes.c_uint32 * len(STAGES))()
         self._check(self._lib.vello_hip_get_stage_ms(self._h, ms, cnt), "get_stage_ms")
         return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES))}
+
+
+def estimate_capacities(packed, layout, width, height):
+    """vello_hip_estimate_capacities: conservative pool sizes (dict) for a packed scene at a target size (host only)."""
+    lib = load_library()
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    lay = LayoutStruct(*layout)
+    p = RenderParamsStruct(width, height, 0, 0)
+    c = Capacities()
+    r = lib.vello_hip_estimate_capacities(packed.ctypes.data, packed.nbytes, ctypes.byref(lay), ctypes.byref(p), ctypes.byref(c))
+    if r != 0:
+        raise VelloHipError(f"vello_hip_estimate_capacities failed ({r})")
+    return {k: getattr(c, k) for k, _ in Capacities._fields_}
+
+
+def gather_frames(engines, src_frames, dst_frames, frame_bytes, dst_device=0, wait=True):
+    """vello_hip_gather_frames / vello_hip_gather_wait: the frame each engine (one per GPU, one process) enqueued last is
+    copied to dst_frames[i] on dst_device by SDMA peer copies (no CUs).  src / dst: torch tensors or device pointers."""
+    lib = load_library()
+    n = len(engines)
+
+    def ptr(x):
+        return ctypes.c_void_p(x.data_ptr() if hasattr(x, "data_ptr") else int(x))
+
+    ctxs = (ctypes.c_void_p * n)(*[e._h for e in engines])
+    srcs = (ctypes.c_void_p * n)(*[ptr(x) for x in src_frames])
+    dsts = (ctypes.c_void_p * n)(*[ptr(x) for x in dst_frames])
+    r = lib.vello_hip_gather_frames(ctxs, n, dst_device, srcs, dsts, frame_bytes)
+    if r != 0:
+        raise VelloHipError(f"vello_hip_gather_frames failed ({r})")
+    if wait:
+        r = lib.vello_hip_gather_wait(ctxs, n)
+        if r != 0:
+            raise VelloHipError(f"vello_hip_gather_wait failed ({r})")
