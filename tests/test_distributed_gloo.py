@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two gloo ranks shard scenes round-robin, render (SIMT-emulated kernels stand in for
+"""N > 1 path on CPU: gloo ranks (2 and 4, uneven scene counts) shard scenes round-robin, render (SIMT-emulated kernels stand in for
 the GPU here: test infrastructure) and gather frames to rank 0, which checks every frame against the oracle."""
 import os
 import socket
@@ -77,6 +77,26 @@ def test_two_rank_scene_sharding_and_gather(built, tmp_path):
         assert np.array_equal(frames[f"f{i}"], o.render()), f"scene {i} gathered at rank 0 differs from the oracle"
 
 
+def test_four_rank_uneven_scene_counts(built, tmp_path):
+    # 6 scenes on 4 ranks: ranks 0 and 1 render two scenes, ranks 2 and 3 one and then take part in the second gather
+    # with an empty frame (the collective needs every rank); every scene still arrives at rank 0 exactly once
+    import workloads
+    from oracle.oracle import Oracle
+    from vello_amd.distributed import shard_scenes
+
+    assert [shard_scenes(6, r, 4) for r in range(4)] == [[0, 4], [1, 5], [2], [3]]
+    n_scenes, world = 6, 4
+    result = str(tmp_path / "frames4.npz")
+    mp.spawn(_worker, args=(world, _free_port(), n_scenes, result), nprocs=world, join=True)
+    frames = np.load(result)
+    assert sorted(frames.files) == [f"f{i}" for i in range(n_scenes)]
+    o = Oracle()
+    for i in range(n_scenes):
+        packed, layout = workloads.paris_like_scene(SEED0 + i, n_paths=120, size=float(SIZE)).resolve()
+        o.set_scene(packed, layout, SIZE, SIZE, 0xFFFFFFFF, 2)
+        assert np.array_equal(frames[f"f{i}"], o.render()), f"scene {i} gathered at rank 0 differs from the oracle"
+
+
 def test_frame_pipeline_exchanges_every_frame_once_in_order():
     # bench.py --gpus N keeps n frames in flight and gathers the oldest one while the younger ones render; the
     # bookkeeping is checked here with recording fakes (no GPU): order, wait ages, slot reuse only after the exchange
@@ -142,16 +162,22 @@ def _bench_worker(rank, world, port, out_path):
     torch.cuda.synchronize = lambda *a, **k: None
 
     class _Event:
+        def __init__(self, *a, **k):
+            pass
+
         def record(self, *a):
             pass
 
         def synchronize(self):
             pass
 
+        def elapsed_time(self, other):
+            return 1.0
+
     torch.cuda.Event = _Event
     real_init = dist.init_process_group
     dist.init_process_group = lambda backend=None, **kw: real_init("gloo", **kw)
-    for name in ("zeros", "tensor"):
+    for name in ("zeros", "tensor", "empty"):
         real = getattr(torch, name)
 
         def on_cpu(*a, _real=real, **kw):
@@ -167,8 +193,11 @@ def _bench_worker(rank, world, port, out_path):
     calls = {"render": 0, "sync_frame": 0}
 
     class FakeEngine:
-        def __init__(self, device=0):
+        def __init__(self, device=0, capacities=None):
             self.prof = []
+
+        def capacities(self):
+            return {"lines": 1, "tiles": 1}
 
         def upload_scene(self, packed, layout, ramps=None):
             pass
@@ -202,6 +231,8 @@ def _bench_worker(rank, world, port, out_path):
     vello_amd.Engine = FakeEngine
     real_scene = workloads.paris_like_scene
     workloads.paris_like_scene = lambda seed: real_scene(seed, n_paths=60, size=1600.0)
+    real_d2 = workloads.paris_like_scene_d2
+    workloads.paris_like_scene_d2 = lambda seed: real_d2(seed, n_paths=60, size=1600.0)
 
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "7", "--warmup", "2"]
     buf = io.StringIO()
@@ -231,6 +262,8 @@ def test_bench_two_rank_control_flow(built, tmp_path):
     # whole-job value: both ranks' frames over the max-over-ranks time
     assert abs(line["value"] - 2 * 7 / (line["ms_per_step"] * 7e-3)) / line["value"] < 1e-2
     assert line["config"]["parallelism"] == "scenes2" and line["config"]["exchange_alone_ms"] is not None
+    assert len(line["config"]["per_rank_frames_per_s"]) == 2 and all(v > 0 for v in line["config"]["per_rank_frames_per_s"])
+    assert "SURVEY 8d d2" in line["config"]["workload"] and "70 %" in line["config"]["workload"]
     assert "cpu_baseline" not in line or line["cpu_baseline"] is None or line["n_gpus"] == 1
     assert line["roofline"]["kernel"] == "k_fine"
     assert r0["calls"]["render"] >= 9 and r1["calls"]["render"] >= 9
