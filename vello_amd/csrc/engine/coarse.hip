@@ -46,7 +46,7 @@ constexpr uint32_t QCAP = 512;        // queue slots: NB - 1 left over + WG new 
 constexpr uint32_t PART_CHUNK = 256;  // bin headers (partitions of 256 draw objects) merged at a time
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
-constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u;  // a tile's fixed block minus the blend word and the tail
+constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u - 1u;  // a tile's fixed block minus the blend word, the tail and the work word
 constexpr uint32_t REGION_SLACK = 62u;  // words a new region holds beyond the batch that asked for it
 // what a draw object emits per tile: a path command (CMD_FILL 4 words / CMD_SOLID 1) + a draw command of 2 or 3 words,
 // or CMD_BEGIN_CLIP alone (coarse.wgsl:377-450)
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
 __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
                                                 const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
                                                 const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
-                                                uint32_t *ptcl, bool allow_cull) {
+                                                uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order) {
     __shared__ CoarseLds sh;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
@@ -227,6 +227,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     uint32_t cur = list_start;       // next command word of the tile's list
     uint32_t room = INITIAL_ROOM;    // words left in the current region in front of its two-word tail
     bool dead = false;               // the tile's list ran out of PTCL pool: nothing more is written
+    uint32_t words_total = 0u;       // command words of the tile's list so far
     uint32_t clip_zero_depth = 0u, clip_depth = 0u, render_blend_depth = 0u, max_blend_depth = 0u;
 
     // ---- the bin's element stream: bin headers merged PART_CHUNK partitions at a time (coarse.wgsl:218-263) ----
@@ -555,7 +556,9 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 if (tile_killed && !dead) {  // everything emitted so far is covered: restart the list in the tile's own block
                     cur = list_start;
                     room = INITIAL_ROOM;
+                    words_total = 0u;
                 }
+                words_total += W;
                 const bool need = W > room && !dead;
                 const uint32_t rsize = need ? W + 2u + REGION_SLACK : 0u;
                 const uint32_t r_incl = wave_incl_scan_u32(rsize, (int)lane);
@@ -661,6 +664,13 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             if (blend_ix + scratch_size > cfg.blend_size) atomicOr(&bump->failed, STAGE_COARSE);
         }
         ptcl[blend_offset] = blend_ix;
+        // For k_fine: the length of the list in the last word of the tile's fixed block (it arrives with fine's first
+        // window), and the tile's index in the bucket of its length class so that long lists are started first.
+        ptcl[blend_offset + PTCL_INITIAL_ALLOC - 1u] = words_total;
+        const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
+        const uint32_t bucket = minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5))));
+        const uint32_t pos = atomicAdd(&work_count[bucket], 1u);
+        if (pos < n_tiles) tile_order[bucket * n_tiles + pos] = this_tile_ix;
     }
 }
 
@@ -676,7 +686,7 @@ void launch_coarse(const Frame &f, hipStream_t s) {
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), 0, s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
-                       f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull);
+                       f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order);
 }
 
 }  // namespace vk

@@ -24,6 +24,9 @@ constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a 
 // than the scene buffer / layout hold (WebGPU's robust buffer access makes this harmless upstream; HIP has none):
 // every later stage that would index with those counts bails out, the frame reports VELLO_HIP_E_INVALID
 constexpr uint32_t FAILED_SCENE = 0x40000000u;
+constexpr uint32_t FINE_WORK_BUCKETS = 8;
+// command words from which a tile counts as long: its wave raises its issue priority (s_setprio) in k_fine
+constexpr uint32_t FINE_HEAVY_WORDS = 384;
 
 // Words of the per-frame control block (zeroed by ONE hipMemsetAsync per frame, together with
 // the bump allocators and both look-back state arrays which follow it in the same allocation).
@@ -33,8 +36,10 @@ struct Control {
     uint32_t ticket_draw;
     uint32_t heavy_count[2];  // flatten: tags queued for k_flatten_heavy: [0] fill curves, [1] strokes
     uint32_t pad[4];
+    uint32_t work_count[FINE_WORK_BUCKETS];  // coarse -> fine: tiles per bucket of command-list length (k_fine runs the long ones first)
+    uint32_t pad2[16 - FINE_WORK_BUCKETS];
 };
-static_assert(sizeof(Control) == 64, "Control");
+static_assert(sizeof(Control) == 128, "Control");
 
 struct Frame {
     Config cfg;  // host copy; kernels receive it by value
@@ -65,6 +70,7 @@ struct Frame {
     CoarseEl *coarse_el;     // coarse: one record per draw object (k_coarse_prep)
     uint32_t *tile_bits;     // coarse: three bit planes over the tile pool (segments present / backdrop zero / backdrop even)
     uint32_t tile_bits_plane_words;
+    uint32_t *tile_order;    // coarse -> fine: [bucket][n_tiles] tile indices, filled up to control->work_count[bucket]
     uint32_t *clip_stack;  // spill area for clip stacks deeper than the LDS window
     uint8_t *output;
     size_t out_stride;

@@ -54,6 +54,7 @@ struct Lane {
     DevBuf clip_stack;
     DevBuf coarse_el;                 // coarse: CoarseEl per draw object
     DevBuf tile_bits;                 // coarse: 3 bit planes over the tile pool
+    DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
     DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
     struct EvPair {
         int stage;
@@ -249,6 +250,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     uint32_t binning_wgs = (sc.layout.n_draw_objects + 255u) / 256u;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
     if (!out_device && (r = ensure(c, l.buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
+    if ((r = ensure(c, l.tile_order, (size_t)f.cfg.width_in_tiles * f.cfg.height_in_tiles * FINE_WORK_BUCKETS * 4u))) return r;
     // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
     if (upload_cfg) HIP_TRY(c, hipMemcpy(c->config.ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
     f.n_tag_words = sc.n_tag_words;
@@ -277,6 +279,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.coarse_el = (CoarseEl *)l.coarse_el.ptr;
     f.tile_bits = (uint32_t *)l.tile_bits.ptr;
     f.tile_bits_plane_words = tile_bits_plane_words(c->caps.tiles);
+    f.tile_order = (uint32_t *)l.tile_order.ptr;
     f.heavy_list = (uint32_t *)l.heavy_list.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
@@ -473,6 +476,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.clip_stack.ptr) (void)hipFree(l.clip_stack.ptr);
         if (l.coarse_el.ptr) (void)hipFree(l.coarse_el.ptr);
         if (l.tile_bits.ptr) (void)hipFree(l.tile_bits.ptr);
+        if (l.tile_order.ptr) (void)hipFree(l.tile_order.ptr);
         if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }

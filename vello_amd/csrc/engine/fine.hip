@@ -1038,15 +1038,33 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
                                              const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
-                                             uint32_t atlas_w, uint32_t atlas_h) {
+                                             uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
+                                             const uint32_t *__restrict__ tile_order) {
     __shared__ FineShared sh;
     __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
     __shared__ FineBatch bt;
     if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 3u, ly = lane >> 2;
-    const uint32_t tile_x = blockIdx.x, tile_y = blockIdx.y;
-    const uint32_t tile_ix = tile_y * cfg.width_in_tiles + tile_x;
+    // Workgroups are dispatched in index order: index -> tile through coarse's buckets of command-list length, longest
+    // lists first, so that the tile that takes longest starts first instead of wherever row-major order puts it.
+    const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
+    uint32_t tile_ix = blockIdx.x;
+    {
+        uint32_t rest = blockIdx.x;
+        bool found = false;
+#pragma unroll
+        for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
+            const uint32_t cnt = minu(work_count[b], n_tiles);
+            if (!found && rest < cnt) {
+                tile_ix = tile_order[(uint32_t)b * n_tiles + rest];
+                found = true;
+            }
+            if (!found) rest -= cnt;
+        }
+        if (!found || tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once)
+    }
+    const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
     const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
     const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
     vec4 rgba[4];
@@ -1073,6 +1091,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
         }
     };
     const uint32_t blend_offset = rd(cmd_ix);
+#ifndef VELLO_SIMT_EMU
+    // A long list is the launch's critical path: its wave issues ahead of the waves it shares the SIMD with.
+    if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
+#endif
     cmd_ix += 1u;
     Segment pre;
     pre.p0x = 0.0f; pre.p0y = 0.0f; pre.p1x = 0.0f; pre.p1y = 0.0f; pre.y_edge = 0.0f; pre.pad = 0u;
@@ -1181,14 +1203,14 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
 
 template <int AA>
 static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_lut) {
-    dim3 grid(f.cfg.width_in_tiles, f.cfg.height_in_tiles);
+    dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles);
     uint32_t stride = (uint32_t)f.out_stride;
     if (f.brushes)
         hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h);
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
     else
         hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h);
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
 }
 
 void launch_fine(const Frame &f, hipStream_t s) {
