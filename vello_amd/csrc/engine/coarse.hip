@@ -655,22 +655,37 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             __syncthreads();  // (4) the per-batch tables and the freed queue slots are rewritten next
         }
     }
-    if (wave == 0u && sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles) {
-        if (!dead) ptcl[cur] = CMD_END;
-        uint32_t blend_ix = 0u;
-        if (max_blend_depth > BLEND_STACK_SPLIT) {
-            uint32_t scratch_size = (max_blend_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT;
-            blend_ix = atomicAdd(&bump->blend, scratch_size);
-            if (blend_ix + scratch_size > cfg.blend_size) atomicOr(&bump->failed, STAGE_COARSE);
+    if (wave == 0u) {
+        const bool in_target = sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles;
+        if (in_target) {
+            if (!dead) ptcl[cur] = CMD_END;
+            uint32_t blend_ix = 0u;
+            if (max_blend_depth > BLEND_STACK_SPLIT) {
+                uint32_t scratch_size = (max_blend_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT;
+                blend_ix = atomicAdd(&bump->blend, scratch_size);
+                if (blend_ix + scratch_size > cfg.blend_size) atomicOr(&bump->failed, STAGE_COARSE);
+            }
+            ptcl[blend_offset] = blend_ix;
+            // For k_fine: the length of the list in the last word of the tile's fixed block (it arrives with fine's
+            // first window) ...
+            ptcl[blend_offset + PTCL_INITIAL_ALLOC - 1u] = words_total;
         }
-        ptcl[blend_offset] = blend_ix;
-        // For k_fine: the length of the list in the last word of the tile's fixed block (it arrives with fine's first
-        // window), and the tile's index in the bucket of its length class so that long lists are started first.
-        ptcl[blend_offset + PTCL_INITIAL_ALLOC - 1u] = words_total;
+        // ... and the tile's index in the bucket of its length class, so that long lists are started first (one atomic
+        // per bucket and workgroup: 10 000 tiles bumping eight counters one by one cost the kernel 50 us)
         const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
-        const uint32_t bucket = minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5))));
-        const uint32_t pos = atomicAdd(&work_count[bucket], 1u);
-        if (pos < n_tiles) tile_order[bucket * n_tiles + pos] = this_tile_ix;
+        const uint32_t bucket = in_target ? minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5)))) : NONE;
+        for (uint32_t bk = 0; bk < FINE_WORK_BUCKETS; bk++) {
+            const u64 m = __ballot(bucket == bk);
+            if (m == 0ull) continue;
+            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
+            uint32_t base = 0u;
+            if (lane == leader) base = atomicAdd(&work_count[bk], popc64(m));
+            base = (uint32_t)__shfl((int)base, (int)leader);
+            if (bucket == bk) {
+                const uint32_t pos = base + popc64(m & below64(lane));
+                if (pos < n_tiles) tile_order[bk * n_tiles + pos] = this_tile_ix;
+            }
+        }
     }
 }
 
