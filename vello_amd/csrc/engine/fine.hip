@@ -2,34 +2,24 @@
 // Reference: vello_shaders/shader/fine.wgsl (area AA :1005-1059, MSAA :146-709, command
 // interpreter :1064-1398), shared/blend.wgsl:147-319 (vello/src/render.rs:560-629).
 //
-// gfx950 design.  The reference workgroup is 4x16 = 64 invocations, i.e. exactly one wave64, and a tile's command list
-// is inherently sequential per pixel (src-over is not commutative, and re-associating it is not bit-exact), so the
-// launch is as slow as its longest list: measured with clock64 per tile on the road-map scene, tiles carry ~80 fills on
-// average and 300+ at the worst -- one wave spends 1.0 M cycles there while the whole launch needs 0.5 M per wave slot.
-// Three things follow:
-//  * coarse buckets the tiles by the length of their lists and fine maps workgroup index -> tile longest first;
-//  * the common case (namespace w1): ONE wave owns a tile, each lane 4 horizontally adjacent pixels; four such tiles
-//    share a 256-thread workgroup but nothing else (no barrier);
-//  * the longest lists (>= FINE_LONG_WORDS command words; namespace w4): the FOUR waves of a workgroup share ONE tile,
-//    one pixel per thread, each wave rows 4w .. 4w + 3: the per-fill work of a wave shrinks to a quarter, the batch
-//    build is done by all 256 threads, the replay is wave-private.  It costs ~2x the wave-instructions of w1 (every
-//    wave decodes the list for itself), which is why only the lists that decide the launch's duration take it.
-// Common to both:
-//  * every cross-lane step of the reference becomes a wave operation (shuffle scans, readlane command decode from a
-//    64-word register window);
-//  * MSAA fills are BATCHED: up to 12 (w4: 16) consecutive FILL commands of the window share one segment load, one
-//    count / scan and one dense pass over the pixel crossings that writes a 28-bit record per crossing to LDS; each
-//    FILL then only replays its records into the packed 8-bit winding counters -- the reference's integer arithmetic
-//    word for word, so MSAA coverage is bit-identical -- and resolves;
-//  * a workgroup's wave orders its own LDS traffic without s_barrier (wave_lds_sync);
-//  * the half-plane mask LUT is a persistent device buffer (the reference re-uploads it every frame:
-//    render.rs:583-591), read through L1/L2.
+// gfx950 design: the reference workgroup is 4x16 = 64 invocations, i.e. exactly one wave64, so one
+// wave owns one 16x16 tile and every cross-lane step of the reference becomes a wave operation:
+//  * the per-batch Hillis-Steele scan of pixel counts is a 6-step shuffle scan;
+//  * each batch of 64 segments is staged into LDS once with coalesced 24-B loads and all later
+//    passes (area loop / pixel walk) read it from LDS (the reference re-reads global memory per
+//    lane: fine.wgsl:1018, :226);
+//  * the winding accumulators (sh_samples etc.) are LDS atomics on the packed 8-bit counters of
+//    the reference, kept bit-identical so the MSAA coverage is integer-exact;
+//  * the half-plane mask LUT is a persistent device buffer (the reference re-uploads it every
+//    frame: render.rs:583-591), read through L1/L2;
+//  * each lane owns 4 horizontally adjacent pixels and stores them as one 16-byte write.
 #include "engine.h"
 
 namespace vk {
 
 namespace {
 
+constexpr uint32_t PIXELS_PER_THREAD = 4;
 constexpr int GRADIENT_WIDTH = 512;
 constexpr uint32_t LUMINANCE_MASK_LAYER = 0x10000u;
 
@@ -62,7 +52,103 @@ struct CmdFill {
     int32_t backdrop;
 };
 
+// Per-segment line setup of a batch (ms_setup), live only while ms_build_batch runs: shares its storage with the
+// staged Segment records of the one-fill-at-a-time paths (never both at once).
+struct SegSetupLds {
+    float a[64], b[64], xy0y[64], xy1y[64], mask_row[64];
+    int32_t x0i[64], y0i[64];
+    uint32_t flags[64];
+};
+struct FineShared {
+    union {
+        Segment seg[64];
+        SegSetupLds su;
+    };
+    uint32_t count[64];
+    uint32_t winding_y[4];
+    uint32_t winding_y_prefix[4];
+    uint32_t winding[64];
+};
+
+// ---------------- area AA (fine.wgsl:1005-1059) ----------------
+__device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t lane, float (&area)[4],
+                               const Segment &first) {
+    const uint32_t n_segs = fill.size_and_rule >> 1;
+    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
+    const float xy_x = (float)((lane & 3u) * PIXELS_PER_THREAD);
+    const float xy_y = (float)(lane >> 2);
+    const float backdrop_f = (float)fill.backdrop;
+#pragma unroll
+    for (int k = 0; k < 4; k++) area[k] = backdrop_f;
+    for (uint32_t base = 0; base < n_segs; base += 64u) {
+        uint32_t slice = minu(n_segs - base, 64u);
+        wave_lds_sync();
+        if (lane < slice) sh.seg[lane] = base == 0u ? first : segments[fill.seg_data + base + lane];
+        wave_lds_sync();
+        for (uint32_t i = 0; i < slice; i++) {
+            Segment sg = sh.seg[i];
+            float y = sg.p0y - xy_y;
+            float delta_x = sg.p1x - sg.p0x;
+            float delta_y = sg.p1y - sg.p0y;
+            float y0 = clampf(y, 0.0f, 1.0f);
+            float y1 = clampf(y + delta_y, 0.0f, 1.0f);
+            float dy = y0 - y1;
+            if (dy != 0.0f) {
+                float vec_y_recip = 1.0f / delta_y;
+                float t0 = (y0 - y) * vec_y_recip;
+                float t1 = (y1 - y) * vec_y_recip;
+                float startx = sg.p0x - xy_x;
+                float x0 = startx + t0 * delta_x;
+                float x1 = startx + t1 * delta_x;
+                float xmin0 = minf(x0, x1);
+                float xmax0 = maxf(x0, x1);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float i_f = (float)k;
+                    float xmin = minf(xmin0 - i_f, 1.0f) - 1.0e-6f;
+                    float xmax = xmax0 - i_f;
+                    float b = minf(xmax, 1.0f);
+                    float c = maxf(b, 0.0f);
+                    float d = maxf(xmin, 0.0f);
+                    float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
+                    area[k] += a * dy;
+                }
+            }
+            float y_edge = signf(delta_x) * clampf(xy_y - sg.y_edge + 1.0f, 0.0f, 1.0f);
+#pragma unroll
+            for (int k = 0; k < 4; k++) area[k] += y_edge;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float a = area[k];
+        if (even_odd) a = fabsf(a - 2.0f * roundf_te(0.5f * a));
+        else a = minf(fabsf(a), 1.0f);
+        area[k] = a;
+    }
+}
+
+// ---------------- MSAA (fine.wgsl:146-709) ----------------
+// The reference rasterizes one fill at a time: count pixel crossings per segment, prefix-sum, one thread per crossing
+// ("item") computes a sample mask and bumps packed winding counters in workgroup memory, then every thread resolves
+// its 4 pixels.  On the paris-like scene a tile holds ~13 fills of ~8 segments / ~30 items, so a wave64 runs the
+// 275-instruction item pass at <50 % lane use 13 times, each time behind the same chain of dependent latencies
+// (segment load -> count -> scan -> search -> LUT load -> LDS atomics -> resolve).  Here the arithmetic of fine.wgsl
+// is split into three pure pieces -- ms_item (crossing -> 28-bit record), ms_apply (record -> counter atomics),
+// ms_resolve -- and up to MS_BATCH_FILLS consecutive fills of the command list are batched: one segment load,
+// one count/scan, one dense item pass writing records to LDS; each FILL command then only replays its records
+// (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
+constexpr uint32_t MS_BATCH_FILLS = 12u;    // fills per batch (their segments must fit one 64-lane load)
+constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
 constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
+
+struct FineBatch {
+    uint32_t item[MS_ITEM_CAP];
+    uint32_t seg_slot[64];                     // fill slot of each staged segment
+    uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
+    uint32_t item_end[MS_BATCH_FILLS + 1u];    // item range of slot k = [item_end[k], item_end[k + 1])
+    uint32_t rule_backdrop[MS_BATCH_FILLS][2];
+};
 
 // fine.wgsl:222-330 computes, for every pixel crossing, the line setup of its segment and then the crossing itself.
 // The setup (one IEEE division, the robustness fix-up, the LUT row) depends on the segment alone: ms_setup runs once
@@ -155,6 +241,58 @@ __device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_i
            (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
 }
 
+template <int AA>
+__device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, bool last_pixel, bool even_odd,
+                                            const uint32_t *__restrict__ mask_lut) {
+    return ms_item_su<AA>(ms_setup<AA>(sg, even_odd), sub_ix, last_pixel, mask_lut);
+}
+
+// The counter updates of one crossing (fine.wgsl:262-270, :331-360).
+template <int AA>
+__device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *winding, uint32_t *sh_samples) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const uint32_t pix_ix = rec & 0xffu;
+    const bool is_down = (rec & REC_IS_DOWN) != 0u, is_bump = (rec & REC_IS_BUMP) != 0u;
+    if (rec & REC_DELTA_OK) {
+        if (!even_odd) {
+            uint32_t delta_pix = pix_ix + 1u;
+            uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
+            atomicAdd(&winding[delta_pix >> 2], d);
+        } else {
+            atomicXor(&winding[pix_ix >> 4], 2u << (pix_ix & 15u));
+        }
+    }
+    if (!(rec & REC_PIX_VALID)) return;
+    uint32_t mask = (rec >> 8) & FULL;
+    // sample words are stored transposed: logical word w of pixel p lives at ((p & 3) * SWPP + w) * 64 + (p >> 2),
+    // so that the words of a pixel and of its x-neighbours land in different banks
+    if (even_odd) {
+        if (is_bump) mask ^= FULL;
+        atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
+        return;
+    }
+    const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
+    constexpr uint32_t NH = MSAA16 ? 2u : 1u;
+#pragma unroll
+    for (uint32_t h = 0; h < NH; h++) {
+        uint32_t m8 = (mask >> (8u * h)) & 0xffu;
+        uint32_t m_a = m8 ^ (m8 << 7);
+        uint32_t m_b = m_a ^ (m_a << 14);
+        uint32_t e0 = m_b & 0x1010101u;
+        uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
+        uint32_t e1 = (m_b >> 4) & 0x1010101u;
+        uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
+        if (is_bump) {
+            s0 += bump_delta;
+            s1 += bump_delta;
+        }
+        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
+        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
+    }
+}
+
 // Per-segment part of the counting stage (fine.wgsl:186-215): crossing count and the row winding bump.
 __device__ __forceinline__ uint32_t ms_segment(const Segment &sg, bool even_odd, uint32_t *winding_y) {
     uint32_t count = 0u;
@@ -171,6 +309,99 @@ __device__ __forceinline__ uint32_t ms_segment(const Segment &sg, bool even_odd,
     return count;
 }
 
+__device__ __forceinline__ void ms_clear(FineShared &sh, uint32_t *sh_samples, bool even_odd, uint32_t lane, uint32_t swpp) {
+    if (!even_odd) {
+        sh.winding[lane] = 0x80808080u;
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD * swpp; i++) sh_samples[i * 64u + lane] = 0x80808080u;
+    } else {
+        if (lane < 16u) sh.winding[lane] = 0u;
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) sh_samples[i * 64u + lane] = 0u;
+    }
+}
+
+// Resolve (fine.wgsl:365-466): prefix sums of the packed counters, then per pixel the number of covered samples.
+template <int AA>
+__device__ __forceinline__ void ms_resolve(FineShared &sh, uint32_t *sh_samples, const uint32_t *winding_y, bool even_odd,
+                                           int32_t backdrop, uint32_t lane, float (&area)[4]) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    if (even_odd) {
+        uint32_t scan_x = sh.winding[ly];
+        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
+        uint32_t scan_y = winding_y[0];
+        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
+        uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
+#pragma unroll
+        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
+            uint32_t pix_ix = lane * PIXELS_PER_THREAD + i;
+            uint32_t samples = sh_samples[i * 64u + lane];
+            uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % TILE_WIDTH));
+            uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
+            area[i] = (float)__popc((samples ^ pix_mask) & FULL) * (MSAA16 ? 0.0625f : 0.125f);
+        }
+        return;
+    }
+    uint32_t packed_w = sh.winding[lane];
+    packed_w += (packed_w - 0x808080u) << 8;
+    packed_w += (packed_w - 0x8080u) << 16;
+    uint32_t packed_y = winding_y[ly >> 2];
+    packed_y += (packed_y - 0x808080u) << 8;
+    packed_y += (packed_y - 0x8080u) << 16;
+    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
+    // fine.wgsl publishes both prefixes through workgroup memory (sh_winding, sh_winding_y_prefix) and re-reads
+    // them after a barrier; one wave does it with shuffles.  Integer adds: the order of the terms is irrelevant.
+    const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
+    const uint32_t px1 = __shfl_up(prefix_x, 1), px2 = __shfl_up(prefix_x, 2), px3 = __shfl_up(prefix_x, 3);
+    if (lx >= 1u) packed_w += px1;
+    if (lx >= 2u) packed_w += px2;
+    if (lx >= 3u) packed_w += px3;
+    // wind_y of rows 3, 7, 11 (any lane of the row holds it)
+    const uint32_t wy3 = __shfl(wind_y, 12), wy7 = __shfl(wind_y, 28), wy11 = __shfl(wind_y, 44);
+    if (ly >= 4u) wind_y += wy3;
+    if (ly >= 8u) wind_y += wy7;
+    if (ly >= 12u) wind_y += wy11;
+#pragma unroll
+    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
+        uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
+        if (expected_zero >= 256u) {
+            area[i] = 1.0f;
+        } else if (!MSAA16) {
+            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
+            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
+            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+            uint32_t xored0_2 = xored0 | (xored0 * 2u);
+            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+            uint32_t xored1_2 = xored1 | (xored1 >> 1);
+            uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            uint32_t xored4 = xored2 | (xored2 * 4u);
+            uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__popc(xored8 & 0xC0C0C0C0u) * 0.125f;
+        } else {
+            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
+            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
+            uint32_t samples2 = sh_samples[(i * SWPP + 2u) * 64u + lane];
+            uint32_t samples3 = sh_samples[(i * SWPP + 3u) * 64u + lane];
+            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
+            uint32_t xored0_2 = xored0 | (xored0 * 2u);
+            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
+            uint32_t xored1_2 = xored1 | (xored1 >> 1);
+            uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+            uint32_t xored01_4 = xored01 | (xored01 * 4u);
+            uint32_t xored2 = (expected_zero * 0x1010101u) ^ samples2;
+            uint32_t xored2_2 = xored2 | (xored2 * 2u);
+            uint32_t xored3 = (expected_zero * 0x1010101u) ^ samples3;
+            uint32_t xored3_2 = xored3 | (xored3 >> 1);
+            uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
+            uint32_t xored23_4 = xored23 | (xored23 >> 2);
+            uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
+            uint32_t xored8 = xored4 | (xored4 * 16u);
+            area[i] = (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
+        }
+    }
+}
+
 // Index of the segment that owns item i: largest el with count[el - 1] <= i (count = inclusive scan in LDS).
 __device__ __forceinline__ uint32_t ms_find_segment(const uint32_t *count, uint32_t n, uint32_t i) {
     uint32_t lo = 0u, hi = n;
@@ -179,6 +410,162 @@ __device__ __forceinline__ uint32_t ms_find_segment(const uint32_t *count, uint3
         if (i >= count[mid - 1u]) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// One fill on its own, any number of segments: the reference's loop over batches of 64 segments.  Used for fills that
+// do not fit a batch.
+template <int AA>
+__device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
+                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4]) {
+    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
+    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
+    const uint32_t n_segs = fill.size_and_rule >> 1;
+    wave_lds_sync();
+    if (lane < 4u) sh.winding_y[lane] = even_odd ? 0u : 0x80808080u;
+    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
+    wave_lds_sync();
+    const uint32_t n_batch = (n_segs + 63u) / 64u;
+    for (uint32_t batch = 0; batch < n_batch; batch++) {
+        const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
+        uint32_t count = 0u;
+        if (lane < slice_size) {
+            Segment sg = segments[fill.seg_data + batch * 64u + lane];
+            sh.seg[lane] = sg;
+            count = ms_segment(sg, even_odd, sh.winding_y);
+        }
+        uint32_t incl = wave_incl_scan_u32(count, (int)lane);
+        sh.count[lane] = incl;
+        uint32_t total = __shfl(incl, 63);
+        wave_lds_sync();
+        for (uint32_t i = lane; i < total; i += 64u) {
+            const uint32_t el_ix = ms_find_segment(sh.count, slice_size, i);
+            const bool last_pixel = i + 1u == sh.count[el_ix];
+            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+            Segment sg = sh.seg[el_ix];
+            ms_apply<AA>(ms_item<AA>(sg, sub_ix, last_pixel, even_odd, mask_lut), even_odd, sh.winding, sh_samples);
+        }
+        wave_lds_sync();
+    }
+    ms_resolve<AA>(sh, sh_samples, sh.winding_y, even_odd, fill.backdrop, lane, area);
+}
+
+// Stage a batch: starting at the FILL command at cmd_ix, collect the following FILL commands visible in the command
+// window (any other commands in between are skipped over: coverage does not depend on them), load all their segments
+// with one instruction, count, scan, and write one record per crossing.  Returns the number of fills staged (0 when
+// the first fill alone does not fit: > 64 segments or > MS_ITEM_CAP crossings).
+template <int AA>
+__device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
+                                   const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
+                                   uint32_t lane) {
+    auto rd = [&](uint32_t ix) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
+    };
+    // scalar scan over the window; lane k keeps the parameters of fill slot k
+    uint32_t n = 0u, tot_segs = 0u;
+    uint32_t my_seg_data = 0u, my_seg_start = 0u, my_rule_n = 0u, my_backdrop = 0u;
+    uint32_t ix = cmd_ix;
+    const uint32_t win_end = win_base + 64u;
+    while (n < MS_BATCH_FILLS && ix + 4u <= win_end) {
+        const uint32_t tag = rd(ix);
+        if (tag == CMD_FILL) {
+            const uint32_t size_and_rule = rd(ix + 1u);
+            const uint32_t n_segs = size_and_rule >> 1;
+            if (tot_segs + n_segs > 64u) break;
+            const uint32_t seg_data_w = rd(ix + 2u), backdrop_w = rd(ix + 3u);
+            if (lane == n) {
+                my_seg_data = seg_data_w;
+                my_backdrop = backdrop_w;
+                my_rule_n = size_and_rule;
+                my_seg_start = tot_segs;
+            }
+            tot_segs += n_segs;
+            n += 1u;
+            ix += 4u;
+        } else if (tag == CMD_COLOR || tag == CMD_IMAGE) {
+            ix += 2u;
+        } else if (tag == CMD_SOLID || tag == CMD_BEGIN_CLIP) {
+            ix += 1u;
+        } else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
+            ix += 3u;
+        } else {
+            break;  // END, JUMP: the list continues elsewhere
+        }
+    }
+    if (n == 0u) return 0u;
+    wave_lds_sync();
+    if (lane < n) {
+        const bool eo = (my_rule_n & 1u) != 0u;
+        bt.rule_backdrop[lane][0] = my_rule_n;
+        bt.rule_backdrop[lane][1] = my_backdrop;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
+    }
+    // which slot does staged segment `lane` belong to
+    uint32_t slot = 0u, seg_data = 0u, seg_start = 0u, rule = 0u;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_start, (int)k);
+        const uint32_t sd_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_data, (int)k);
+        const uint32_t rl_k = (uint32_t)__builtin_amdgcn_readlane((int)my_rule_n, (int)k);
+        if (lane >= st_k) {
+            slot = k;
+            seg_data = sd_k;
+            seg_start = st_k;
+            rule = rl_k;
+        }
+    }
+    wave_lds_sync();
+    uint32_t count = 0u;
+    if (lane < tot_segs) {
+        Segment sg = segments[seg_data + (lane - seg_start)];
+        bt.seg_slot[lane] = slot;
+        count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
+        const MsSetup su = ms_setup<AA>(sg, (rule & 1u) != 0u);
+        sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.xy0y[lane] = su.xy0y; sh.su.xy1y[lane] = su.xy1y;
+        sh.su.mask_row[lane] = su.mask_row; sh.su.x0i[lane] = su.x0i; sh.su.y0i[lane] = su.y0i; sh.su.flags[lane] = su.flags;
+    }
+    uint32_t incl = wave_incl_scan_u32(count, (int)lane);
+    sh.count[lane] = incl;
+    // item range ends per slot: the inclusive count at the slot's last segment (or the previous end for empty fills)
+    {
+        const uint32_t last_seg = my_seg_start + (my_rule_n >> 1);  // one past the slot's last staged segment (0 for lanes >= n)
+        const uint32_t end = (uint32_t)__shfl(incl, (int)(last_seg ? last_seg - 1u : 0u));
+        if (lane < n) bt.item_end[lane + 1u] = last_seg ? end : 0u;
+        if (lane == 0u) bt.item_end[0] = 0u;
+    }
+    wave_lds_sync();
+    // keep only the fills whose records fit
+    uint32_t n_fit = 0u;
+    for (uint32_t k = 0; k < n; k++)
+        if (bt.item_end[k + 1u] <= MS_ITEM_CAP) n_fit = k + 1u;
+    if (n_fit == 0u) return 0u;
+    const uint32_t total = bt.item_end[n_fit];
+    const uint32_t n_staged = tot_segs;
+    for (uint32_t i = lane; i < total; i += 64u) {
+        const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
+        const bool last_pixel = i + 1u == sh.count[el_ix];
+        const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+        MsSetup su;
+        su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
+        su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
+        bt.item[i] = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
+    }
+    wave_lds_sync();
+    return n_fit;
+}
+
+// A FILL command whose crossings were staged by ms_build_batch: replay its records and resolve.
+template <int AA>
+__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4]) {
+    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
+    const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
+    const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
+    const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
+    wave_lds_sync();
+    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
+    wave_lds_sync();
+    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], even_odd, sh.winding, sh_samples);
+    wave_lds_sync();
+    ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, lane, area);
 }
 
 // ---------------- blend (shared/blend.wgsl) ----------------
@@ -447,408 +834,7 @@ __device__ __attribute__((noinline)) float blur_rect_alpha(const uint32_t *__res
     return scale * (erf7(inv_std_dev * (min_edge + d)) - erf7(inv_std_dev * d));
 }
 
-
-namespace w1 {
-
-constexpr uint32_t PIXELS_PER_THREAD = 4;
-
-// Per-segment line setup of a batch (ms_setup), live only while ms_build_batch runs: shares its storage with the
-// staged Segment records of the one-fill-at-a-time paths (never both at once).
-struct SegSetupLds {
-    float a[64], b[64], xy0y[64], xy1y[64], mask_row[64];
-    int32_t x0i[64], y0i[64];
-    uint32_t flags[64];
-};
-struct FineShared {
-    union {
-        Segment seg[64];
-        SegSetupLds su;
-    };
-    uint32_t count[64];
-    uint32_t winding_y[4];
-    uint32_t winding_y_prefix[4];
-    uint32_t winding[64];
-};
-
-// ---------------- area AA (fine.wgsl:1005-1059) ----------------
-__device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t lane, float (&area)[4],
-                               const Segment &first) {
-    const uint32_t n_segs = fill.size_and_rule >> 1;
-    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
-    const float xy_x = (float)((lane & 3u) * PIXELS_PER_THREAD);
-    const float xy_y = (float)(lane >> 2);
-    const float backdrop_f = (float)fill.backdrop;
-#pragma unroll
-    for (int k = 0; k < 4; k++) area[k] = backdrop_f;
-    for (uint32_t base = 0; base < n_segs; base += 64u) {
-        uint32_t slice = minu(n_segs - base, 64u);
-        wave_lds_sync();
-        if (lane < slice) sh.seg[lane] = base == 0u ? first : segments[fill.seg_data + base + lane];
-        wave_lds_sync();
-        for (uint32_t i = 0; i < slice; i++) {
-            Segment sg = sh.seg[i];
-            float y = sg.p0y - xy_y;
-            float delta_x = sg.p1x - sg.p0x;
-            float delta_y = sg.p1y - sg.p0y;
-            float y0 = clampf(y, 0.0f, 1.0f);
-            float y1 = clampf(y + delta_y, 0.0f, 1.0f);
-            float dy = y0 - y1;
-            if (dy != 0.0f) {
-                float vec_y_recip = 1.0f / delta_y;
-                float t0 = (y0 - y) * vec_y_recip;
-                float t1 = (y1 - y) * vec_y_recip;
-                float startx = sg.p0x - xy_x;
-                float x0 = startx + t0 * delta_x;
-                float x1 = startx + t1 * delta_x;
-                float xmin0 = minf(x0, x1);
-                float xmax0 = maxf(x0, x1);
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    float i_f = (float)k;
-                    float xmin = minf(xmin0 - i_f, 1.0f) - 1.0e-6f;
-                    float xmax = xmax0 - i_f;
-                    float b = minf(xmax, 1.0f);
-                    float c = maxf(b, 0.0f);
-                    float d = maxf(xmin, 0.0f);
-                    float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                    area[k] += a * dy;
-                }
-            }
-            float y_edge = signf(delta_x) * clampf(xy_y - sg.y_edge + 1.0f, 0.0f, 1.0f);
-#pragma unroll
-            for (int k = 0; k < 4; k++) area[k] += y_edge;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        float a = area[k];
-        if (even_odd) a = fabsf(a - 2.0f * roundf_te(0.5f * a));
-        else a = minf(fabsf(a), 1.0f);
-        area[k] = a;
-    }
-}
-
-// ---------------- MSAA (fine.wgsl:146-709) ----------------
-// The reference rasterizes one fill at a time: count pixel crossings per segment, prefix-sum, one thread per crossing
-// ("item") computes a sample mask and bumps packed winding counters in workgroup memory, then every thread resolves
-// its 4 pixels.  On the paris-like scene a tile holds ~13 fills of ~8 segments / ~30 items, so a wave64 runs the
-// 275-instruction item pass at <50 % lane use 13 times, each time behind the same chain of dependent latencies
-// (segment load -> count -> scan -> search -> LUT load -> LDS atomics -> resolve).  Here the arithmetic of fine.wgsl
-// is split into three pure pieces -- ms_item (crossing -> 28-bit record), ms_apply (record -> counter atomics),
-// ms_resolve -- and up to MS_BATCH_FILLS consecutive fills of the command list are batched: one segment load,
-// one count/scan, one dense item pass writing records to LDS; each FILL command then only replays its records
-// (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
-constexpr uint32_t MS_BATCH_FILLS = 12u;    // fills per batch (their segments must fit one 64-lane load)
-constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
-struct FineBatch {
-    uint32_t item[MS_ITEM_CAP];
-    uint32_t seg_slot[64];                     // fill slot of each staged segment
-    uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
-    uint32_t item_end[MS_BATCH_FILLS + 1u];    // item range of slot k = [item_end[k], item_end[k + 1])
-    uint32_t rule_backdrop[MS_BATCH_FILLS][2];
-};
-
-template <int AA>
-__device__ __forceinline__ uint32_t ms_item(const Segment &sg, uint32_t sub_ix, bool last_pixel, bool even_odd,
-                                            const uint32_t *__restrict__ mask_lut) {
-    return ms_item_su<AA>(ms_setup<AA>(sg, even_odd), sub_ix, last_pixel, mask_lut);
-}
-
-// The counter updates of one crossing (fine.wgsl:262-270, :331-360).
-template <int AA>
-__device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *winding, uint32_t *sh_samples) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const uint32_t pix_ix = rec & 0xffu;
-    const bool is_down = (rec & REC_IS_DOWN) != 0u, is_bump = (rec & REC_IS_BUMP) != 0u;
-    if (rec & REC_DELTA_OK) {
-        if (!even_odd) {
-            uint32_t delta_pix = pix_ix + 1u;
-            uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
-            atomicAdd(&winding[delta_pix >> 2], d);
-        } else {
-            atomicXor(&winding[pix_ix >> 4], 2u << (pix_ix & 15u));
-        }
-    }
-    if (!(rec & REC_PIX_VALID)) return;
-    uint32_t mask = (rec >> 8) & FULL;
-    // sample words are stored transposed: logical word w of pixel p lives at ((p & 3) * SWPP + w) * 64 + (p >> 2),
-    // so that the words of a pixel and of its x-neighbours land in different banks
-    if (even_odd) {
-        if (is_bump) mask ^= FULL;
-        atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
-        return;
-    }
-    const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
-    constexpr uint32_t NH = MSAA16 ? 2u : 1u;
-#pragma unroll
-    for (uint32_t h = 0; h < NH; h++) {
-        uint32_t m8 = (mask >> (8u * h)) & 0xffu;
-        uint32_t m_a = m8 ^ (m8 << 7);
-        uint32_t m_b = m_a ^ (m_a << 14);
-        uint32_t e0 = m_b & 0x1010101u;
-        uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
-        uint32_t e1 = (m_b >> 4) & 0x1010101u;
-        uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
-        if (is_bump) {
-            s0 += bump_delta;
-            s1 += bump_delta;
-        }
-        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
-        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
-    }
-}
-
-__device__ __forceinline__ void ms_clear(FineShared &sh, uint32_t *sh_samples, bool even_odd, uint32_t lane, uint32_t swpp) {
-    if (!even_odd) {
-        sh.winding[lane] = 0x80808080u;
-        for (uint32_t i = 0; i < PIXELS_PER_THREAD * swpp; i++) sh_samples[i * 64u + lane] = 0x80808080u;
-    } else {
-        if (lane < 16u) sh.winding[lane] = 0u;
-        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) sh_samples[i * 64u + lane] = 0u;
-    }
-}
-
-// Resolve (fine.wgsl:365-466): prefix sums of the packed counters, then per pixel the number of covered samples.
-template <int AA>
-__device__ __forceinline__ void ms_resolve(FineShared &sh, uint32_t *sh_samples, const uint32_t *winding_y, bool even_odd,
-                                           int32_t backdrop, uint32_t lane, float (&area)[4]) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const uint32_t lx = lane & 3u, ly = lane >> 2;
-    if (even_odd) {
-        uint32_t scan_x = sh.winding[ly];
-        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
-        uint32_t scan_y = winding_y[0];
-        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
-        uint32_t row_parity = (scan_y >> ly) ^ (uint32_t)backdrop;
-#pragma unroll
-        for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
-            uint32_t pix_ix = lane * PIXELS_PER_THREAD + i;
-            uint32_t samples = sh_samples[i * 64u + lane];
-            uint32_t pix_parity = row_parity ^ (scan_x >> (pix_ix % TILE_WIDTH));
-            uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
-            area[i] = (float)__popc((samples ^ pix_mask) & FULL) * (MSAA16 ? 0.0625f : 0.125f);
-        }
-        return;
-    }
-    uint32_t packed_w = sh.winding[lane];
-    packed_w += (packed_w - 0x808080u) << 8;
-    packed_w += (packed_w - 0x8080u) << 16;
-    uint32_t packed_y = winding_y[ly >> 2];
-    packed_y += (packed_y - 0x808080u) << 8;
-    packed_y += (packed_y - 0x8080u) << 16;
-    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
-    // fine.wgsl publishes both prefixes through workgroup memory (sh_winding, sh_winding_y_prefix) and re-reads
-    // them after a barrier; one wave does it with shuffles.  Integer adds: the order of the terms is irrelevant.
-    const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
-    const uint32_t px1 = __shfl_up(prefix_x, 1), px2 = __shfl_up(prefix_x, 2), px3 = __shfl_up(prefix_x, 3);
-    if (lx >= 1u) packed_w += px1;
-    if (lx >= 2u) packed_w += px2;
-    if (lx >= 3u) packed_w += px3;
-    // wind_y of rows 3, 7, 11 (any lane of the row holds it)
-    const uint32_t wy3 = __shfl(wind_y, 12), wy7 = __shfl(wind_y, 28), wy11 = __shfl(wind_y, 44);
-    if (ly >= 4u) wind_y += wy3;
-    if (ly >= 8u) wind_y += wy7;
-    if (ly >= 12u) wind_y += wy11;
-#pragma unroll
-    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
-        uint32_t expected_zero = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
-        if (expected_zero >= 256u) {
-            area[i] = 1.0f;
-        } else if (!MSAA16) {
-            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
-            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
-            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
-            uint32_t xored0_2 = xored0 | (xored0 * 2u);
-            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
-            uint32_t xored1_2 = xored1 | (xored1 >> 1);
-            uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-            uint32_t xored4 = xored2 | (xored2 * 4u);
-            uint32_t xored8 = xored4 | (xored4 * 16u);
-            area[i] = (float)__popc(xored8 & 0xC0C0C0C0u) * 0.125f;
-        } else {
-            uint32_t samples0 = sh_samples[(i * SWPP + 0u) * 64u + lane];
-            uint32_t samples1 = sh_samples[(i * SWPP + 1u) * 64u + lane];
-            uint32_t samples2 = sh_samples[(i * SWPP + 2u) * 64u + lane];
-            uint32_t samples3 = sh_samples[(i * SWPP + 3u) * 64u + lane];
-            uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
-            uint32_t xored0_2 = xored0 | (xored0 * 2u);
-            uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
-            uint32_t xored1_2 = xored1 | (xored1 >> 1);
-            uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-            uint32_t xored01_4 = xored01 | (xored01 * 4u);
-            uint32_t xored2 = (expected_zero * 0x1010101u) ^ samples2;
-            uint32_t xored2_2 = xored2 | (xored2 * 2u);
-            uint32_t xored3 = (expected_zero * 0x1010101u) ^ samples3;
-            uint32_t xored3_2 = xored3 | (xored3 >> 1);
-            uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
-            uint32_t xored23_4 = xored23 | (xored23 >> 2);
-            uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
-            uint32_t xored8 = xored4 | (xored4 * 16u);
-            area[i] = (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
-        }
-    }
-}
-
-// One fill on its own, any number of segments: the reference's loop over batches of 64 segments.  Used for fills that
-// do not fit a batch.
-template <int AA>
-__device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment *__restrict__ segments,
-                             const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t lane, float (&area)[4]) {
-    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
-    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
-    const uint32_t n_segs = fill.size_and_rule >> 1;
-    wave_lds_sync();
-    if (lane < 4u) sh.winding_y[lane] = even_odd ? 0u : 0x80808080u;
-    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
-    wave_lds_sync();
-    const uint32_t n_batch = (n_segs + 63u) / 64u;
-    for (uint32_t batch = 0; batch < n_batch; batch++) {
-        const uint32_t slice_size = minu(n_segs - batch * 64u, 64u);
-        uint32_t count = 0u;
-        if (lane < slice_size) {
-            Segment sg = segments[fill.seg_data + batch * 64u + lane];
-            sh.seg[lane] = sg;
-            count = ms_segment(sg, even_odd, sh.winding_y);
-        }
-        uint32_t incl = wave_incl_scan_u32(count, (int)lane);
-        sh.count[lane] = incl;
-        uint32_t total = __shfl(incl, 63);
-        wave_lds_sync();
-        for (uint32_t i = lane; i < total; i += 64u) {
-            const uint32_t el_ix = ms_find_segment(sh.count, slice_size, i);
-            const bool last_pixel = i + 1u == sh.count[el_ix];
-            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-            Segment sg = sh.seg[el_ix];
-            ms_apply<AA>(ms_item<AA>(sg, sub_ix, last_pixel, even_odd, mask_lut), even_odd, sh.winding, sh_samples);
-        }
-        wave_lds_sync();
-    }
-    ms_resolve<AA>(sh, sh_samples, sh.winding_y, even_odd, fill.backdrop, lane, area);
-}
-
-// Stage a batch: starting at the FILL command at cmd_ix, collect the following FILL commands visible in the command
-// window (any other commands in between are skipped over: coverage does not depend on them), load all their segments
-// with one instruction, count, scan, and write one record per crossing.  Returns the number of fills staged (0 when
-// the first fill alone does not fit: > 64 segments or > MS_ITEM_CAP crossings).
-template <int AA>
-__device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
-                                   const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t lane) {
-    auto rd = [&](uint32_t ix) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
-    };
-    // scalar scan over the window; lane k keeps the parameters of fill slot k
-    uint32_t n = 0u, tot_segs = 0u;
-    uint32_t my_seg_data = 0u, my_seg_start = 0u, my_rule_n = 0u, my_backdrop = 0u;
-    uint32_t ix = cmd_ix;
-    const uint32_t win_end = win_base + 64u;
-    while (n < MS_BATCH_FILLS && ix + 4u <= win_end) {
-        const uint32_t tag = rd(ix);
-        if (tag == CMD_FILL) {
-            const uint32_t size_and_rule = rd(ix + 1u);
-            const uint32_t n_segs = size_and_rule >> 1;
-            if (tot_segs + n_segs > 64u) break;
-            const uint32_t seg_data_w = rd(ix + 2u), backdrop_w = rd(ix + 3u);
-            if (lane == n) {
-                my_seg_data = seg_data_w;
-                my_backdrop = backdrop_w;
-                my_rule_n = size_and_rule;
-                my_seg_start = tot_segs;
-            }
-            tot_segs += n_segs;
-            n += 1u;
-            ix += 4u;
-        } else if (tag == CMD_COLOR || tag == CMD_IMAGE) {
-            ix += 2u;
-        } else if (tag == CMD_SOLID || tag == CMD_BEGIN_CLIP) {
-            ix += 1u;
-        } else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
-            ix += 3u;
-        } else {
-            break;  // END, JUMP: the list continues elsewhere
-        }
-    }
-    if (n == 0u) return 0u;
-    wave_lds_sync();
-    if (lane < n) {
-        const bool eo = (my_rule_n & 1u) != 0u;
-        bt.rule_backdrop[lane][0] = my_rule_n;
-        bt.rule_backdrop[lane][1] = my_backdrop;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
-    }
-    // which slot does staged segment `lane` belong to
-    uint32_t slot = 0u, seg_data = 0u, seg_start = 0u, rule = 0u;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_start, (int)k);
-        const uint32_t sd_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_data, (int)k);
-        const uint32_t rl_k = (uint32_t)__builtin_amdgcn_readlane((int)my_rule_n, (int)k);
-        if (lane >= st_k) {
-            slot = k;
-            seg_data = sd_k;
-            seg_start = st_k;
-            rule = rl_k;
-        }
-    }
-    wave_lds_sync();
-    uint32_t count = 0u;
-    if (lane < tot_segs) {
-        Segment sg = segments[seg_data + (lane - seg_start)];
-        bt.seg_slot[lane] = slot;
-        count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
-        const MsSetup su = ms_setup<AA>(sg, (rule & 1u) != 0u);
-        sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.xy0y[lane] = su.xy0y; sh.su.xy1y[lane] = su.xy1y;
-        sh.su.mask_row[lane] = su.mask_row; sh.su.x0i[lane] = su.x0i; sh.su.y0i[lane] = su.y0i; sh.su.flags[lane] = su.flags;
-    }
-    uint32_t incl = wave_incl_scan_u32(count, (int)lane);
-    sh.count[lane] = incl;
-    // item range ends per slot: the inclusive count at the slot's last segment (or the previous end for empty fills)
-    {
-        const uint32_t last_seg = my_seg_start + (my_rule_n >> 1);  // one past the slot's last staged segment (0 for lanes >= n)
-        const uint32_t end = (uint32_t)__shfl(incl, (int)(last_seg ? last_seg - 1u : 0u));
-        if (lane < n) bt.item_end[lane + 1u] = last_seg ? end : 0u;
-        if (lane == 0u) bt.item_end[0] = 0u;
-    }
-    wave_lds_sync();
-    // keep only the fills whose records fit
-    uint32_t n_fit = 0u;
-    for (uint32_t k = 0; k < n; k++)
-        if (bt.item_end[k + 1u] <= MS_ITEM_CAP) n_fit = k + 1u;
-    if (n_fit == 0u) return 0u;
-    const uint32_t total = bt.item_end[n_fit];
-    const uint32_t n_staged = tot_segs;
-    for (uint32_t i = lane; i < total; i += 64u) {
-        const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
-        const bool last_pixel = i + 1u == sh.count[el_ix];
-        const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-        MsSetup su;
-        su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
-        su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
-        bt.item[i] = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
-    }
-    wave_lds_sync();
-    return n_fit;
-}
-
-// A FILL command whose crossings were staged by ms_build_batch: replay its records and resolve.
-template <int AA>
-__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4]) {
-    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
-    const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
-    const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
-    const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
-    wave_lds_sync();
-    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
-    wave_lds_sync();
-    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], even_odd, sh.winding, sh_samples);
-    wave_lds_sync();
-    ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, lane, area);
-}
-
+}  // namespace
 
 // Everything except FILL / SOLID / COLOR / JUMP / END: clip layers (blend stack) and, when BRUSHES, the gradient,
 // image and blur arms.  Out of line on purpose: inlined into the interpreter loop these arms cost the hot
@@ -1044,23 +1030,40 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
     st.cmd_ix = cmd_ix;
 }
 
-
-// One tile by ONE wave (lane = 4 horizontally adjacent pixels): the path of all but the longest command lists.
-template <int AA>
-struct TileLds {
-    FineShared sh;
-    uint32_t samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
-    FineBatch bt;
-};
+// BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
+// on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
+// solid-colour interpreter does not pay their registers.
 template <int AA, bool BRUSHES>
-__device__ void run_tile(TileLds<AA> &lds, const Config &cfg, uint32_t tile_ix, uint32_t lane, const Segment *__restrict__ segments,
-                         const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
-                         uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps, const uint32_t *__restrict__ mask_lut,
-                         const uint32_t *__restrict__ atlas_texels, uint32_t atlas_w, uint32_t atlas_h) {
-    FineShared &sh = lds.sh;
-    uint32_t *sh_samples = lds.samples;
-    FineBatch &bt = lds.bt;
+__global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+                                             const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
+                                             uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
+                                             const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
+                                             uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
+                                             const uint32_t *__restrict__ tile_order) {
+    __shared__ FineShared sh;
+    __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
+    __shared__ FineBatch bt;
+    if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
+    const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 3u, ly = lane >> 2;
+    // Workgroups are dispatched in index order: index -> tile through coarse's buckets of command-list length, longest
+    // lists first, so that the tile that takes longest starts first instead of wherever row-major order puts it.
+    const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
+    uint32_t tile_ix = blockIdx.x;
+    {
+        uint32_t rest = blockIdx.x;
+        bool found = false;
+#pragma unroll
+        for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
+            const uint32_t cnt = minu(work_count[b], n_tiles);
+            if (!found && rest < cnt) {
+                tile_ix = tile_order[(uint32_t)b * n_tiles + rest];
+                found = true;
+            }
+            if (!found) rest -= cnt;
+        }
+        if (!found || tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once)
+    }
     const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
     const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
     const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
@@ -1198,768 +1201,15 @@ __device__ void run_tile(TileLds<AA> &lds, const Config &cfg, uint32_t tile_ix, 
     }
 }
 
-}  // namespace w1
-
-namespace w4 {
-
-constexpr uint32_t FINE_WG = 256;
-
-constexpr uint32_t MS_BATCH_FILLS = 16u;   // fills per batch
-constexpr uint32_t MS_BATCH_SEGS = 128u;   // their segments, loaded with one instruction by threads 0 .. 127
-constexpr uint32_t MS_ITEM_CAP = 768u;     // crossing records per batch (3 KB of LDS)
-
-// Per-segment line setup of a batch (ms_setup), live only while a batch is built: shares its storage with the
-// staged Segment records of the area path (never both at once).
-struct SegSetupLds {
-    float a[MS_BATCH_SEGS], b[MS_BATCH_SEGS], xy0y[MS_BATCH_SEGS], xy1y[MS_BATCH_SEGS], mask_row[MS_BATCH_SEGS];
-    int32_t x0i[MS_BATCH_SEGS], y0i[MS_BATCH_SEGS];
-    uint32_t flags[MS_BATCH_SEGS];
-};
-struct FineShared {
-    union {
-        Segment seg[MS_BATCH_SEGS];
-        SegSetupLds su;
-    };
-    uint32_t count[MS_BATCH_SEGS];  // inclusive crossing counts of the staged segments
-    uint32_t wave_tot[4];
-    uint32_t winding_y[4];          // one-fill-at-a-time path (fills too large for a batch)
-    uint32_t winding[64];           // packed x-winding deltas, 4 pixels per word (nonzero) / one row per word (even-odd)
-};
-
-// ---------------- area AA (fine.wgsl:1005-1059) ----------------
-// All 256 threads stage up to 128 segments at a time and every thread accumulates its own pixel.
-__device__ float fill_path_area(FineShared &sh, const Segment *__restrict__ segments, CmdFill fill, uint32_t tid) {
-    const uint32_t n_segs = fill.size_and_rule >> 1;
-    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
-    // the reference's invocation owns four pixels x0 .. x0 + 3 and computes pixel i as (.. - x0) - i: same operations here
-    const float xy_x = (float)(tid & 12u);
-    const float i_f = (float)(tid & 3u);
-    const float xy_y = (float)(tid >> 4);
-    float area = (float)fill.backdrop;
-    for (uint32_t base = 0; base < n_segs; base += MS_BATCH_SEGS) {
-        const uint32_t slice = minu(n_segs - base, MS_BATCH_SEGS);
-        __syncthreads();
-        if (tid < slice) sh.seg[tid] = segments[fill.seg_data + base + tid];
-        __syncthreads();
-        for (uint32_t i = 0; i < slice; i++) {
-            const Segment sg = sh.seg[i];
-            const float y = sg.p0y - xy_y;
-            const float delta_x = sg.p1x - sg.p0x;
-            const float delta_y = sg.p1y - sg.p0y;
-            const float y0 = clampf(y, 0.0f, 1.0f);
-            const float y1 = clampf(y + delta_y, 0.0f, 1.0f);
-            const float dy = y0 - y1;
-            if (dy != 0.0f) {
-                const float vec_y_recip = 1.0f / delta_y;
-                const float t0 = (y0 - y) * vec_y_recip;
-                const float t1 = (y1 - y) * vec_y_recip;
-                const float startx = sg.p0x - xy_x;
-                const float x0 = startx + t0 * delta_x;
-                const float x1 = startx + t1 * delta_x;
-                const float xmin0 = minf(x0, x1);
-                const float xmax0 = maxf(x0, x1);
-                const float xmin = minf(xmin0 - i_f, 1.0f) - 1.0e-6f;
-                const float xmax = xmax0 - i_f;
-                const float b = minf(xmax, 1.0f);
-                const float c = maxf(b, 0.0f);
-                const float d = maxf(xmin, 0.0f);
-                const float a = (b + 0.5f * (d * d - c * c) - xmin) / (xmax - xmin);
-                area += a * dy;
-            }
-            const float y_edge = signf(delta_x) * clampf(xy_y - sg.y_edge + 1.0f, 0.0f, 1.0f);
-            area += y_edge;
-        }
-    }
-    if (even_odd) area = fabsf(area - 2.0f * roundf_te(0.5f * area));
-    else area = minf(fabsf(area), 1.0f);
-    return area;
-}
-
-struct FineBatch {
-    uint32_t item[MS_ITEM_CAP];
-    uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
-    uint32_t item_end[MS_BATCH_FILLS + 1u];    // item range of slot k = [item_end[k], item_end[k + 1])
-    uint32_t rule_backdrop[MS_BATCH_FILLS][2];
-};
-
-// The counter updates of one crossing (fine.wgsl:262-270, :331-360).  Sample word w of pixel p lives at w * 256 + p.
-template <int AA>
-__device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *winding, uint32_t *sh_samples) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const uint32_t pix_ix = rec & 0xffu;
-    const bool is_down = (rec & REC_IS_DOWN) != 0u, is_bump = (rec & REC_IS_BUMP) != 0u;
-    if (rec & REC_DELTA_OK) {
-        if (!even_odd) {
-            uint32_t delta_pix = pix_ix + 1u;
-            uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
-            atomicAdd(&winding[delta_pix >> 2], d);
-        } else {
-            atomicXor(&winding[pix_ix >> 4], 2u << (pix_ix & 15u));
-        }
-    }
-    uint32_t mask = (rec >> 8) & FULL;
-    if (even_odd) {
-        if (is_bump) mask ^= FULL;
-        atomicXor(&sh_samples[pix_ix], mask);
-        return;
-    }
-    const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
-    constexpr uint32_t NH = MSAA16 ? 2u : 1u;
-#pragma unroll
-    for (uint32_t h = 0; h < NH; h++) {
-        uint32_t m8 = (mask >> (8u * h)) & 0xffu;
-        uint32_t m_a = m8 ^ (m8 << 7);
-        uint32_t m_b = m_a ^ (m_a << 14);
-        uint32_t e0 = m_b & 0x1010101u;
-        uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
-        uint32_t e1 = (m_b >> 4) & 0x1010101u;
-        uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
-        if (is_bump) {
-            s0 += bump_delta;
-            s1 += bump_delta;
-        }
-        atomicAdd(&sh_samples[(2u * h) * 256u + pix_ix], s0);
-        atomicAdd(&sh_samples[(2u * h + 1u) * 256u + pix_ix], s1);
-    }
-}
-
-// A wave resets its own rows: the sample words of its 64 pixels and its slice of the x-winding words.
-template <int AA>
-__device__ __forceinline__ void ms_clear(FineShared &sh, uint32_t *sh_samples, bool even_odd, uint32_t tid) {
-    constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    if (!even_odd) {
-        if (lane < 16u) sh.winding[wave * 16u + lane] = 0x80808080u;
-#pragma unroll
-        for (uint32_t w = 0; w < SWPP; w++) sh_samples[w * 256u + tid] = 0x80808080u;
-    } else {
-        if (lane < 4u) sh.winding[wave * 4u + lane] = 0u;
-        sh_samples[tid] = 0u;
-    }
-}
-
-// Resolve of ONE pixel (fine.wgsl:365-466): prefix sums of the packed counters, then the number of covered samples.
-template <int AA>
-__device__ __forceinline__ float ms_resolve(const FineShared &sh, const uint32_t *sh_samples, const uint32_t *winding_y, bool even_odd,
-                                            int32_t backdrop, uint32_t tid) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const uint32_t px = tid & 15u, py = tid >> 4;
-    if (even_odd) {
-        uint32_t scan_x = sh.winding[py];
-        scan_x ^= scan_x << 1; scan_x ^= scan_x << 2; scan_x ^= scan_x << 4; scan_x ^= scan_x << 8;
-        uint32_t scan_y = winding_y[0];
-        scan_y ^= scan_y << 1; scan_y ^= scan_y << 2; scan_y ^= scan_y << 4; scan_y ^= scan_y << 8;
-        const uint32_t row_parity = (scan_y >> py) ^ (uint32_t)backdrop;
-        const uint32_t samples = sh_samples[tid];
-        const uint32_t pix_parity = row_parity ^ (scan_x >> px);
-        const uint32_t pix_mask = (uint32_t)(-(int32_t)(pix_parity & 1u));
-        return (float)__popc((samples ^ pix_mask) & FULL) * (MSAA16 ? 0.0625f : 0.125f);
-    }
-    // x: the four packed words of the row; each word's bytes become prefixes within the word, the words before the
-    // pixel's own contribute their totals (top byte) -- the reference's invocation does the same with its neighbours'
-    // words through workgroup memory (fine.wgsl:380-410); integer adds, the order of the terms is irrelevant
-    const uint32_t wx = px >> 2;
-    uint32_t packed_w = 0u, prefix_x = 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++) {
-        uint32_t w = sh.winding[py * 4u + j];
-        w += (w - 0x808080u) << 8;
-        w += (w - 0x8080u) << 16;
-        if (j == wx) packed_w = w;
-        if (j < wx) prefix_x += ((w >> 24) - 0x80u) * 0x1010101u;
-    }
-    packed_w += prefix_x;
-    // y: the word of the pixel's row group, and the totals of the row groups above it
-    const uint32_t wy = py >> 2;
-    uint32_t wind_y = 0u;
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++) {
-        uint32_t w = winding_y[j];
-        w += (w - 0x808080u) << 8;
-        w += (w - 0x8080u) << 16;
-        if (j == wy) wind_y += (w >> ((py & 3u) << 3)) - 0x80u;
-        if (j < wy) wind_y += (w >> 24) - 0x80u;
-    }
-    const uint32_t expected_zero = (((packed_w >> ((px & 3u) * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
-    if (expected_zero >= 256u) return 1.0f;
-    if (!MSAA16) {
-        const uint32_t samples0 = sh_samples[tid];
-        const uint32_t samples1 = sh_samples[256u + tid];
-        const uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
-        const uint32_t xored0_2 = xored0 | (xored0 * 2u);
-        const uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
-        const uint32_t xored1_2 = xored1 | (xored1 >> 1);
-        const uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-        const uint32_t xored4 = xored2 | (xored2 * 4u);
-        const uint32_t xored8 = xored4 | (xored4 * 16u);
-        return (float)__popc(xored8 & 0xC0C0C0C0u) * 0.125f;
-    }
-    const uint32_t samples0 = sh_samples[tid];
-    const uint32_t samples1 = sh_samples[256u + tid];
-    const uint32_t samples2 = sh_samples[512u + tid];
-    const uint32_t samples3 = sh_samples[768u + tid];
-    const uint32_t xored0 = (expected_zero * 0x1010101u) ^ samples0;
-    const uint32_t xored0_2 = xored0 | (xored0 * 2u);
-    const uint32_t xored1 = (expected_zero * 0x1010101u) ^ samples1;
-    const uint32_t xored1_2 = xored1 | (xored1 >> 1);
-    const uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
-    const uint32_t xored01_4 = xored01 | (xored01 * 4u);
-    const uint32_t xored2 = (expected_zero * 0x1010101u) ^ samples2;
-    const uint32_t xored2_2 = xored2 | (xored2 * 2u);
-    const uint32_t xored3 = (expected_zero * 0x1010101u) ^ samples3;
-    const uint32_t xored3_2 = xored3 | (xored3 >> 1);
-    const uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
-    const uint32_t xored23_4 = xored23 | (xored23 >> 2);
-    const uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
-    const uint32_t xored8 = xored4 | (xored4 * 16u);
-    return (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
-}
-
-// Inclusive scan of `v` over threads 0 .. 255 (sh.wave_tot is the cross-wave hop); *total = the workgroup sum.
-__device__ __forceinline__ uint32_t wg_incl_scan(FineShared &sh, uint32_t v, uint32_t tid, uint32_t *total) {
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const uint32_t s = wave_incl_scan_u32(v, (int)lane);
-    __syncthreads();  // protect wave_tot from a previous use
-    if (lane == 63u) sh.wave_tot[wave] = s;
-    __syncthreads();
-    const uint32_t s0 = sh.wave_tot[0], s1 = sh.wave_tot[1], s2 = sh.wave_tot[2], s3 = sh.wave_tot[3];
-    *total = s0 + s1 + s2 + s3;
-    return s + (wave > 0u ? s0 : 0u) + (wave > 1u ? s1 : 0u) + (wave > 2u ? s2 : 0u);
-}
-
-// The staged segment `el_ix`'s setup back from LDS.
-__device__ __forceinline__ MsSetup load_setup(const FineShared &sh, uint32_t el_ix) {
-    MsSetup su;
-    su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
-    su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
-    return su;
-}
-__device__ __forceinline__ void store_setup(FineShared &sh, uint32_t el_ix, const MsSetup &su) {
-    sh.su.a[el_ix] = su.a; sh.su.b[el_ix] = su.b; sh.su.xy0y[el_ix] = su.xy0y; sh.su.xy1y[el_ix] = su.xy1y;
-    sh.su.mask_row[el_ix] = su.mask_row; sh.su.x0i[el_ix] = su.x0i; sh.su.y0i[el_ix] = su.y0i; sh.su.flags[el_ix] = su.flags;
-}
-
-// One fill on its own, any number of segments (fills that do not fit a batch): the reference's loop over batches of
-// segments, cooperatively -- 128 segments staged at a time, their crossings computed by all 256 threads MS_ITEM_CAP at a
-// time, every wave applying the records of its own rows.
-template <int AA>
-__device__ float fill_path_ms(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, const Segment *__restrict__ segments,
-                              const uint32_t *__restrict__ mask_lut, CmdFill fill, uint32_t tid) {
-    const bool even_odd = (fill.size_and_rule & 1u) != 0u;
-    const uint32_t n_segs = fill.size_and_rule >> 1;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    __syncthreads();
-    if (tid < 4u) sh.winding_y[tid] = even_odd ? 0u : 0x80808080u;
-    ms_clear<AA>(sh, sh_samples, even_odd, tid);
-    __syncthreads();
-    for (uint32_t base = 0; base < n_segs; base += MS_BATCH_SEGS) {
-        const uint32_t slice = minu(n_segs - base, MS_BATCH_SEGS);
-        uint32_t count = 0u;
-        if (tid < slice) {
-            const Segment sg = segments[fill.seg_data + base + tid];
-            count = ms_segment(sg, even_odd, sh.winding_y);
-            store_setup(sh, tid, ms_setup<AA>(sg, even_odd));
-        }
-        uint32_t total;
-        const uint32_t incl = wg_incl_scan(sh, count, tid, &total);
-        if (tid < MS_BATCH_SEGS) sh.count[tid] = incl;
-        __syncthreads();
-        for (uint32_t item0 = 0; item0 < total; item0 += MS_ITEM_CAP) {
-            const uint32_t m = minu(total - item0, MS_ITEM_CAP);
-            for (uint32_t k = tid; k < m; k += FINE_WG) {
-                const uint32_t i = item0 + k;
-                const uint32_t el_ix = ms_find_segment(sh.count, slice, i);
-                const bool last_pixel = i + 1u == sh.count[el_ix];
-                const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-                bt.item[k] = ms_item_su<AA>(load_setup(sh, el_ix), sub_ix, last_pixel, mask_lut);
-            }
-            __syncthreads();
-            for (uint32_t k = lane; k < m; k += 64u) {
-                const uint32_t rec = bt.item[k];
-                if ((rec & REC_PIX_VALID) != 0u && ((rec & 0xffu) >> 6) == wave) ms_apply<AA>(rec, even_odd, sh.winding, sh_samples);
-            }
-            __syncthreads();
-        }
-    }
-    return ms_resolve<AA>(sh, sh_samples, sh.winding_y, even_odd, fill.backdrop, tid);
-}
-
-// Stage a batch: starting at the FILL command at cmd_ix, collect the following FILL commands visible in the command
-// window (any other commands in between are skipped over: coverage does not depend on them), load all their segments
-// with one instruction, count, scan, and write one record per crossing.  Returns the number of fills staged (0 when
-// the first fill alone does not fit: > MS_BATCH_SEGS segments or > MS_ITEM_CAP crossings).  Called by the whole workgroup.
-template <int AA>
-__device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
-                                   const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t tid) {
-    const uint32_t lane = tid & 63u;
-    auto rd = [&](uint32_t ix) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
-    };
-    // scalar scan over the window (every wave for itself); lane k keeps the parameters of fill slot k
-    uint32_t n = 0u, tot_segs = 0u;
-    uint32_t my_seg_data = 0u, my_seg_start = 0u, my_rule_n = 0u, my_backdrop = 0u;
-    uint32_t ix = cmd_ix;
-    const uint32_t win_end = win_base + 64u;
-    while (n < MS_BATCH_FILLS && ix + 4u <= win_end) {
-        const uint32_t tag = rd(ix);
-        if (tag == CMD_FILL) {
-            const uint32_t size_and_rule = rd(ix + 1u);
-            const uint32_t n_segs = size_and_rule >> 1;
-            if (tot_segs + n_segs > MS_BATCH_SEGS) break;
-            const uint32_t seg_data_w = rd(ix + 2u), backdrop_w = rd(ix + 3u);
-            if (lane == n) {
-                my_seg_data = seg_data_w;
-                my_backdrop = backdrop_w;
-                my_rule_n = size_and_rule;
-                my_seg_start = tot_segs;
-            }
-            tot_segs += n_segs;
-            n += 1u;
-            ix += 4u;
-        } else if (tag == CMD_COLOR || tag == CMD_IMAGE) {
-            ix += 2u;
-        } else if (tag == CMD_SOLID || tag == CMD_BEGIN_CLIP) {
-            ix += 1u;
-        } else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
-            ix += 3u;
-        } else {
-            break;  // END, JUMP: the list continues elsewhere
-        }
-    }
-    if (n == 0u) return 0u;
-    __syncthreads();  // every wave has finished replaying the previous batch
-    if (tid < n) {
-        const bool eo = (my_rule_n & 1u) != 0u;
-        bt.rule_backdrop[tid][0] = my_rule_n;
-        bt.rule_backdrop[tid][1] = my_backdrop;
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) bt.winding_y[tid][k] = eo ? 0u : 0x80808080u;
-    }
-    // which slot does staged segment `tid` belong to
-    uint32_t slot = 0u, seg_data = 0u, seg_start = 0u, rule = 0u;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_start, (int)k);
-        const uint32_t sd_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_data, (int)k);
-        const uint32_t rl_k = (uint32_t)__builtin_amdgcn_readlane((int)my_rule_n, (int)k);
-        if (tid >= st_k) {
-            slot = k;
-            seg_data = sd_k;
-            seg_start = st_k;
-            rule = rl_k;
-        }
-    }
-    __syncthreads();  // winding_y initialised before the segments bump it
-    uint32_t count = 0u;
-    if (tid < tot_segs) {
-        const Segment sg = segments[seg_data + (tid - seg_start)];
-        count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
-        store_setup(sh, tid, ms_setup<AA>(sg, (rule & 1u) != 0u));
-    }
-    uint32_t total_all;
-    const uint32_t incl = wg_incl_scan(sh, count, tid, &total_all);
-    if (tid < MS_BATCH_SEGS) sh.count[tid] = incl;
-    __syncthreads();
-    // item range ends per slot: the inclusive count at the slot's last segment (the previous end for empty fills)
-    if (tid < n) {
-        const uint32_t last_seg = my_seg_start + (my_rule_n >> 1);  // one past the slot's last staged segment
-        bt.item_end[tid + 1u] = last_seg ? sh.count[last_seg - 1u] : 0u;
-    }
-    if (tid == 0u) bt.item_end[0] = 0u;
-    __syncthreads();
-    // keep only the fills whose records fit
-    uint32_t n_fit = 0u;
-    for (uint32_t k = 0; k < n; k++)
-        if (bt.item_end[k + 1u] <= MS_ITEM_CAP) n_fit = k + 1u;
-    if (n_fit == 0u) return 0u;
-    const uint32_t total = bt.item_end[n_fit];
-    for (uint32_t i = tid; i < total; i += FINE_WG) {
-        const uint32_t el_ix = ms_find_segment(sh.count, tot_segs, i);
-        const bool last_pixel = i + 1u == sh.count[el_ix];
-        const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-        bt.item[i] = ms_item_su<AA>(load_setup(sh, el_ix), sub_ix, last_pixel, mask_lut);
-    }
-    __syncthreads();
-    return n_fit;
-}
-
-// A FILL command whose crossings were staged by ms_build_batch: the wave replays the records of its own rows into its
-// own counters and every thread resolves its pixel.  No workgroup barrier: nothing here is shared between waves but
-// the read-only batch.
-template <int AA>
-__device__ float ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t tid) {
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
-    const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
-    const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
-    wave_lds_sync();
-    ms_clear<AA>(sh, sh_samples, even_odd, tid);
-    wave_lds_sync();
-    for (uint32_t i = begin + lane; i < end; i += 64u) {
-        const uint32_t rec = bt.item[i];
-        if ((rec & REC_PIX_VALID) != 0u && ((rec & 0xffu) >> 6) == wave) ms_apply<AA>(rec, even_odd, sh.winding, sh_samples);
-    }
-    wave_lds_sync();
-    return ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, tid);
-}
-
-
-// Everything except FILL / SOLID / COLOR / JUMP / END: clip layers (blend stack) and, when BRUSHES, the gradient,
-// image and blur arms.  Out of line on purpose: inlined into the interpreter loop these arms cost the hot
-// FILL+COLOR path registers and instructions at the loop's join points.  The pixel state crosses the call through
-// RareState; the blend stack lives in scratch / registers of the caller, only these commands touch it.
-struct RareState {
-    vec4 rgba;
-    float area;
-    uint32_t clip_depth;
-    uint32_t cmd_ix;
-};
-// `tid` = the pixel's index in the tile (y * 16 + x); xy_x / xy_y its coordinates in the target.
-template <bool BRUSHES>
-__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t *blend_stack, uint32_t tag, uint32_t ptcl_size,
-                                                       uint32_t blend_size,
-                                                       const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
-                                                       uint32_t *blend_spill, uint32_t blend_offset, uint32_t tid, float xy_x,
-                                                       float xy_y, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
-                                                       const uint32_t *__restrict__ atlas_texels, uint32_t atlas_w, uint32_t atlas_h) {
-    vec4 rgba = st.rgba;
-    const float area = st.area;
-    uint32_t clip_depth = st.clip_depth;
-    uint32_t cmd_ix = st.cmd_ix;
-    auto rd = [&](uint32_t ix) -> uint32_t { return ix < ptcl_size ? ptcl[ix] : 0u; };
-    if (tag == CMD_BEGIN_CLIP) {
-        const uint32_t packed = pack4x8unorm(rgba);
-        if (clip_depth < BLEND_STACK_SPLIT) {
-            blend_stack[clip_depth] = packed;
-        } else {
-            const uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + tid;
-            if (ix < blend_size) blend_spill[ix] = packed;
-        }
-        rgba = vec4{0.0f, 0.0f, 0.0f, 0.0f};
-        clip_depth += 1u;
-        cmd_ix += 1u;
-    } else if (tag == CMD_END_CLIP) {
-        const uint32_t blend = rd(cmd_ix + 1u);
-        const float alpha = __uint_as_float(rd(cmd_ix + 2u));
-        clip_depth -= 1u;
-        uint32_t bg_rgba = 0u;
-        if (clip_depth < BLEND_STACK_SPLIT) {
-            bg_rgba = blend_stack[clip_depth];
-        } else {
-            const uint32_t ix = blend_offset + (clip_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT + tid;
-            bg_rgba = ix < blend_size ? blend_spill[ix] : 0u;
-        }
-        const vec4 bg = unpack4x8unorm(bg_rgba);
-        const vec4 fg = (rgba * area) * alpha;
-        if (blend == LUMINANCE_MASK_LAYER) {
-            if (area == 0.0f) {
-                rgba = bg;
-            } else {
-                float luminance = clampf(svg_lum(unpremultiply(fg)) * fg.w, 0.0f, 1.0f);
-                rgba = bg * luminance;
-            }
-        } else {
-            rgba = blend_mix_compose(bg, fg, blend);
-        }
-        cmd_ix += 3u;
-    } else if (BRUSHES && tag == CMD_LIN_GRAD) {
-        const uint32_t index_mode = rd(cmd_ix + 1u);
-        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-        const uint32_t io = rd(cmd_ix + 2u);
-        const float line_x = __uint_as_float(info[io]), line_y = __uint_as_float(info[io + 1u]), line_c = __uint_as_float(info[io + 2u]);
-        // the reference's invocation evaluates d at the first of its four pixels and steps by line_x (fine.wgsl:1233-1237)
-        const float base_x = xy_x - (float)(tid & 3u);
-        const float d = line_x * base_x + line_y * xy_y + line_c;
-        const float my_d = d + line_x * (float)(tid & 3u);
-        const int32_t x = f2i(roundf_te(extend_mode_normalized(my_d, extend) * (float)(GRADIENT_WIDTH - 1)));
-        src_over(rgba, ramp_load(ramps, n_ramps, x, index), area);
-        cmd_ix += 3u;
-    } else if (BRUSHES && tag == CMD_RAD_GRAD) {
-        const uint32_t index_mode = rd(cmd_ix + 1u);
-        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-        const uint32_t io = rd(cmd_ix + 2u);
-        const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
-                    m3 = __uint_as_float(info[io + 3u]);
-        const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
-        const float focal_x = __uint_as_float(info[io + 6u]), radius = __uint_as_float(info[io + 7u]);
-        const uint32_t flags_kind = info[io + 8u];
-        const uint32_t flags = flags_kind >> 3, kind = flags_kind & 7u;
-        const bool is_strip = kind == RAD_GRAD_KIND_STRIP, is_circular = kind == RAD_GRAD_KIND_CIRCULAR;
-        const bool is_focal_on_circle = kind == RAD_GRAD_KIND_FOCAL_ON_CIRCLE;
-        const bool is_swapped = (flags & RAD_GRAD_SWAPPED) != 0u;
-        const float r1_recip = is_circular ? 0.0f : 1.0f / radius;
-        const float less_scale = (is_swapped || (1.0f - focal_x) < 0.0f) ? -1.0f : 1.0f;
-        const float t_sign = signf(1.0f - focal_x);
-        {
-            const float mx = xy_x, my = xy_y;
-            const float x = m0 * mx + m2 * my + xl0;
-            const float y = m1 * mx + m3 * my + xl1;
-            const float xx = x * x, yy = y * y;
-            float t = 0.0f;
-            bool is_valid = true;
-            if (is_strip) {
-                float a = radius - yy;
-                t = sqrtf(a) + x;
-                is_valid = a >= 0.0f;
-            } else if (is_focal_on_circle) {
-                t = (xx + yy) / x;
-                is_valid = t >= 0.0f && x != 0.0f;
-            } else if (radius > 1.0f) {
-                t = sqrtf(xx + yy) - x * r1_recip;
-            } else {
-                float a = xx - yy;
-                t = less_scale * sqrtf(a) - x * r1_recip;
-                is_valid = a >= 0.0f && t >= 0.0f;
-            }
-            if (is_valid) {
-                t = extend_mode_normalized(focal_x + t_sign * t, extend);
-                if (is_swapped) t = 1.0f - t;
-                const int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
-                src_over(rgba, ramp_load(ramps, n_ramps, rx, index), area);
-            }
-        }
-        cmd_ix += 3u;
-    } else if (BRUSHES && tag == CMD_SWEEP_GRAD) {
-        const uint32_t index_mode = rd(cmd_ix + 1u);
-        const uint32_t index = index_mode >> 2, extend = index_mode & 3u;
-        const uint32_t io = rd(cmd_ix + 2u);
-        const float m0 = __uint_as_float(info[io]), m1 = __uint_as_float(info[io + 1u]), m2 = __uint_as_float(info[io + 2u]),
-                    m3 = __uint_as_float(info[io + 3u]);
-        const float xl0 = __uint_as_float(info[io + 4u]), xl1 = __uint_as_float(info[io + 5u]);
-        const float t0 = __uint_as_float(info[io + 6u]), t1 = __uint_as_float(info[io + 7u]);
-        const float scale = 1.0f / (t1 - t0);
-        {
-            const float mx = xy_x, my = xy_y;
-            const float x = m0 * mx + m2 * my + xl0;
-            const float y = m1 * mx + m3 * my + xl1;
-            const float xabs = fabsf(x), yabs = fabsf(y);
-            const float slope = minf(xabs, yabs) / maxf(xabs, yabs);
-            const float s = slope * slope;
-            float phi = slope * (0.15912117063999176025390625f +
-                                 s * (-5.185396969318389892578125e-2f +
-                                      s * (2.476101927459239959716796875e-2f + s * (-7.0547382347285747528076171875e-3f))));
-            if (xabs < yabs) phi = 1.0f / 4.0f - phi;
-            if (x < 0.0f) phi = 1.0f / 2.0f - phi;
-            if (y < 0.0f) phi = 1.0f - phi;
-            if (phi != phi) phi = 0.0f;
-            phi = (phi - t0) * scale;
-            const float t = extend_mode_normalized(phi, extend);
-            const int32_t rx = f2i(roundf_te(t * (float)(GRADIENT_WIDTH - 1)));
-            src_over(rgba, ramp_load(ramps, n_ramps, rx, index), area);
-        }
-        cmd_ix += 3u;
-    } else if (BRUSHES && tag == CMD_IMAGE) {
-        const uint32_t io = rd(cmd_ix + 1u);
-        const uint32_t sample_alpha = info[io + 8u];
-        const float alpha = (float)(sample_alpha & 0xFFu) / 255.0f;
-        const bool bgra = (sample_alpha >> 15) == 1u;
-        const Atlas at{atlas_texels, atlas_w, atlas_h};
-        if (area != 0.0f) {
-            vec4 fg = image_sample(at, info, io, xy_x + 0.5f, xy_y + 0.5f);
-            vec4 fg_i = fg * area * alpha;
-            if (bgra) fg_i = vec4{fg_i.z, fg_i.y, fg_i.x, fg_i.w};  // pixel_format: .bgra
-            rgba = rgba * (1.0f - fg_i.w) + fg_i;
-        }
-        cmd_ix += 2u;
-    } else if (BRUSHES && tag == CMD_BLUR_RECT) {
-        const uint32_t io = rd(cmd_ix + 1u);
-        const vec4 blur_rgba = unpack4x8unorm(rd(cmd_ix + 2u));
-        const float alpha = blur_rect_alpha(info, io, xy_x, xy_y);
-        src_over(rgba, blur_rgba * alpha, area);
-        cmd_ix += 3u;
-    } else if (tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
-        cmd_ix += 3u;  // !BRUSHES: unreachable by construction; keeps the stream in step if the contract is broken
-    } else if (tag == CMD_IMAGE) {
-        cmd_ix += 2u;
-    } else {
-        cmd_ix += 1u;
-    }
-    st.rgba = rgba;
-    st.clip_depth = clip_depth;
-    st.cmd_ix = cmd_ix;
-}
-
-
-// One tile by FOUR waves (thread = pixel): the path of the longest command lists.
-template <int AA>
-struct TileLds {
-    FineShared sh;
-    uint32_t samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
-    FineBatch bt;
-};
-template <int AA, bool BRUSHES>
-__device__ void run_tile(TileLds<AA> &lds, const Config &cfg, uint32_t tile_ix, uint32_t tid, const Segment *__restrict__ segments,
-                         const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
-                         uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps, const uint32_t *__restrict__ mask_lut,
-                         const uint32_t *__restrict__ atlas_texels, uint32_t atlas_w, uint32_t atlas_h) {
-    FineShared &sh = lds.sh;
-    uint32_t *sh_samples = lds.samples;
-    FineBatch &bt = lds.bt;
-    const uint32_t lane = tid & 63u;
-    const uint32_t px = tid & 15u, py = tid >> 4;
-    const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
-    const float xy_x = (float)(tile_x * TILE_WIDTH + px);
-    const float xy_y = (float)(tile_y * TILE_HEIGHT + py);
-    vec4 rgba = unpack4x8unorm(cfg.base_color);
-    uint32_t blend_stack[BLEND_STACK_SPLIT];
-    uint32_t clip_depth = 0u;
-    float area = 0.0f;
-    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
-    // The command stream is read 64 words at a time by each wave (one 256-B transaction; the tile's initial PTCL block
-    // is exactly one window) and decoded with readlane, instead of a dependent scalar load per word.
-    uint32_t win_base = cmd_ix;
-    uint32_t win = ptcl[win_base + lane];
-    auto rd = [&](uint32_t ix) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
-    };
-    auto ensure = [&](uint32_t ix, uint32_t n_words) {
-        if (ix + n_words > win_base + 64u) {
-            win_base = ix;
-            uint32_t a = win_base + lane;
-            win = a < cfg.ptcl_size ? ptcl[a] : 0u;
-        }
-    };
-    const uint32_t blend_offset = rd(cmd_ix);
-    cmd_ix += 1u;
-    uint32_t batch_n = 0u, batch_pos = 0u;  // MSAA: fills staged by ms_build_batch / already consumed
-    for (;;) {
-        ensure(cmd_ix, 4u);
-        const uint32_t tag = rd(cmd_ix);
-        if (tag == CMD_END) break;
-        if (tag == CMD_FILL) {
-            if constexpr (AA == 0) {
-                CmdFill fill;
-                fill.size_and_rule = rd(cmd_ix + 1u);
-                fill.seg_data = rd(cmd_ix + 2u);
-                fill.backdrop = (int32_t)rd(cmd_ix + 3u);
-                area = fill_path_area(sh, segments, fill, tid);
-            } else {
-                if (batch_pos == batch_n) {
-                    // the scan wants to see as far ahead as possible: restart the window at this command
-                    if (cmd_ix != win_base) {
-                        win_base = cmd_ix;
-                        uint32_t a = win_base + lane;
-                        win = a < cfg.ptcl_size ? ptcl[a] : 0u;
-                    }
-                    batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, tid));
-                    batch_pos = 0u;
-                }
-                if (batch_n != 0u) {
-                    area = ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, tid);
-                    batch_pos += 1u;
-                } else {
-                    CmdFill fill;
-                    fill.size_and_rule = rd(cmd_ix + 1u);
-                    fill.seg_data = rd(cmd_ix + 2u);
-                    fill.backdrop = (int32_t)rd(cmd_ix + 3u);
-                    area = fill_path_ms<AA>(sh, bt, sh_samples, segments, mask_lut, fill, tid);
-                }
-            }
-            cmd_ix += 4u;
-        } else if (tag == CMD_SOLID) {
-            area = 1.0f;
-            cmd_ix += 1u;
-        } else if (tag == CMD_COLOR) {
-            const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
-            src_over(rgba, fg, area);
-            cmd_ix += 2u;
-        } else if (tag == CMD_JUMP) {
-            cmd_ix = rd(cmd_ix + 1u);
-        } else {
-            RareState st;
-            st.rgba = rgba;
-            st.area = area;
-            st.clip_depth = clip_depth;
-            st.cmd_ix = cmd_ix;
-            rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, tid, xy_x, xy_y, ramps, n_ramps,
-                                  atlas_texels, atlas_w, atlas_h);
-            rgba = st.rgba;
-            clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
-            cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
-        }
-    }
-    // fine.wgsl:1386-1397: un-premultiplied RGBA8
-    const uint32_t gx = tile_x * TILE_WIDTH + px;
-    const uint32_t gy = tile_y * TILE_HEIGHT + py;
-    if (gy < cfg.target_height && gx < cfg.target_width) {
-        const float a_inv = 1.0f / maxf(rgba.w, 1e-6f);
-        const uint32_t packed = pack4x8unorm(vec4{rgba.x * a_inv, rgba.y * a_inv, rgba.z * a_inv, rgba.w});
-        uint8_t *row = output + (size_t)gy * out_stride + (size_t)gx * 4u;
-        *reinterpret_cast<uint32_t *>(row) = packed;
-    }
-}
-
-}  // namespace w4
-
-}  // namespace
-
-constexpr uint32_t FINE_LONG_BUCKET = 6;     // buckets >= this (lists of >= 1024 command words) take the four-wave path
-constexpr uint32_t FINE_LONG_MAX_WGS = 2048; // at most this many four-wave workgroups per launch (the rest run as w1)
-
-template <int AA>
-union FineLds {
-    w1::TileLds<AA> one[4];  // four independent tiles, one per wave
-    w4::TileLds<AA> four;    // one tile shared by the four waves
-};
-
-// BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
-// on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
-// solid-colour interpreter does not pay their registers.
-template <int AA, bool BRUSHES>
-__global__ void __launch_bounds__(256, BRUSHES ? 3 : 4) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
-                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
-                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
-                                              const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
-                                              uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
-                                              const uint32_t *__restrict__ tile_order) {
-    __shared__ FineLds<AA> lds;
-    if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
-    const uint32_t tid = threadIdx.x;
-    // Workgroups are dispatched in index order: index -> tile(s) through coarse's buckets of command-list length, longest
-    // lists first, so that the tile that takes longest starts first instead of wherever row-major order puts it.
-    const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
-    uint32_t cnt[FINE_WORK_BUCKETS];
-    uint32_t n_long = 0u;
-#pragma unroll
-    for (uint32_t b = 0; b < FINE_WORK_BUCKETS; b++) {
-        cnt[b] = minu(work_count[b], n_tiles);
-        if (b >= FINE_LONG_BUCKET) n_long += cnt[b];
-    }
-    n_long = minu(n_long, FINE_LONG_MAX_WGS);
-    // position in the longest-first order: the first n_long tiles get a workgroup each, the others a wave each
-    const bool four_wave = blockIdx.x < n_long;
-    uint32_t rest = four_wave ? blockIdx.x : n_long + (blockIdx.x - n_long) * 4u + (tid >> 6);
-    uint32_t tile_ix = 0xffffffffu;
-#pragma unroll
-    for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
-        if (tile_ix == 0xffffffffu) {
-            if (rest < cnt[b]) tile_ix = tile_order[(uint32_t)b * n_tiles + rest] & 0x7fffffffu;
-            else rest -= cnt[b];
-        }
-    }
-    if (tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once; a wave past the last tile has none)
-    if (four_wave)
-        w4::run_tile<AA, BRUSHES>(lds.four, cfg, tile_ix, tid, segments, ptcl, info, blend_spill, output, out_stride, ramps, n_ramps, mask_lut,
-                                  atlas_texels, atlas_w, atlas_h);
-    else
-        w1::run_tile<AA, BRUSHES>(lds.one[tid >> 6], cfg, tile_ix, tid & 63u, segments, ptcl, info, blend_spill, output, out_stride, ramps,
-                                  n_ramps, mask_lut, atlas_texels, atlas_w, atlas_h);
-}
-
 template <int AA>
 static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_lut) {
-    const uint32_t n_tiles = f.cfg.width_in_tiles * f.cfg.height_in_tiles;
-    // n_long (known on the device only) four-wave workgroups + a wave for every other tile
-    dim3 grid((n_tiles + 3u) / 4u + (n_tiles < FINE_LONG_MAX_WGS ? n_tiles : FINE_LONG_MAX_WGS));
+    dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles);
     uint32_t stride = (uint32_t)f.out_stride;
     if (f.brushes)
-        hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(256), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+        hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
                            stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
     else
-        hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(256), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+        hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
                            stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
 }
 
