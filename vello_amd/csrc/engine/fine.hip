@@ -199,17 +199,12 @@ __device__ __forceinline__ MsSetup ms_setup(const Segment &sg, bool even_odd) {
 }
 
 // One pixel crossing: which pixel, the 8/16-bit sample mask from the LUT, and the flags the accumulation needs.
-// Split in two around the LUT load so that a batch can have the loads of ALL its crossings in flight at once:
-// ms_item_pre -> (record without its mask, LUT index and the two clip shifts), ms_item_fin(LUT word) -> record.
-struct ItemPre {
-    uint32_t rec;   // pixel + flags
-    uint32_t lut;   // mask_ix | shift0 << 16 | shift1 << 22 (shift 0 / 32 = "keep everything" for the start / end clip)
-};
 template <int AA>
-__device__ __forceinline__ ItemPre ms_item_pre(const MsSetup &su, uint32_t sub_ix, bool last_pixel) {
+__device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_ix, bool last_pixel, const uint32_t *__restrict__ mask_lut) {
     constexpr bool MSAA16 = AA == 2;
     constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
     constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
+    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
     const bool is_down = (su.flags & SU_IS_DOWN) != 0u, is_positive_slope = (su.flags & SU_POS_SLOPE) != 0u;
     const float a = su.a, b = su.b;
     const float zf = a * (float)sub_ix + b;
@@ -230,34 +225,20 @@ __device__ __forceinline__ ItemPre ms_item_pre(const MsSetup &su, uint32_t sub_i
     const uint32_t mask_block = (is_positive_slope ? 1u : 0u) * (MASK_WIDTH * MASK_HEIGHT / 2u);
     const float mask_col = floorf((zf - z) * (float)MASK_WIDTH);
     const uint32_t mask_ix = mask_block + f2u(su.mask_row + mask_col);
-    uint32_t shift0 = 0u, shift1 = 32u;
-    if (sub_ix == 0u && !is_bump) shift0 = minu(f2u(roundf_te((float)NSAMP * (su.xy0y - (float)y))), 32u);
-    if (last_pixel && (su.flags & SU_END_OK) != 0u) shift1 = minu(f2u(roundf_te((float)NSAMP * (su.xy1y - (float)y))), 32u);
-    ItemPre p;
-    // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
-    p.rec = (pix_ix & 0xffu) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) | (is_bump ? REC_IS_BUMP : 0u) |
-            (delta_ok ? REC_DELTA_OK : 0u);
-    p.lut = (mask_ix & 0xffffu) | (shift0 << 16) | (shift1 << 22);
-    return p;
-}
-template <int AA>
-__device__ __forceinline__ uint32_t lut_word_index(uint32_t lut) { return (lut & 0xffffu) / (AA == 2 ? 2u : 4u); }
-template <int AA>
-__device__ __forceinline__ uint32_t ms_item_fin(ItemPre p, uint32_t lut_word) {
-    constexpr bool MSAA16 = AA == 2;
-    constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
-    const uint32_t mask_ix = p.lut & 0xffffu, shift0 = (p.lut >> 16) & 63u, shift1 = (p.lut >> 22) & 63u;
     uint32_t mask;
-    if (MSAA16) mask = (lut_word >> ((mask_ix % 2u) * 16u)) & 0xffffu;
-    else mask = (lut_word >> ((mask_ix % 4u) * 8u)) & 0xffu;
-    mask &= shift0 < 32u ? (FULL << shift0) : 0u;
-    mask &= ~(shift1 < 32u ? (FULL << shift1) : 0u);
-    return p.rec | ((mask & FULL) << 8);
-}
-template <int AA>
-__device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_ix, bool last_pixel, const uint32_t *__restrict__ mask_lut) {
-    const ItemPre p = ms_item_pre<AA>(su, sub_ix, last_pixel);
-    return ms_item_fin<AA>(p, mask_lut[lut_word_index<AA>(p.lut)]);
+    if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
+    else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
+    if (sub_ix == 0u && !is_bump) {
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy0y - (float)y)));
+        mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
+    }
+    if (last_pixel && (su.flags & SU_END_OK) != 0u) {
+        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy1y - (float)y)));
+        mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
+    }
+    // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
+    return (pix_ix & 0xffu) | ((mask & FULL) << 8) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) |
+           (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
 }
 
 template <int AA>
@@ -559,32 +540,14 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     if (n_fit == 0u) return 0u;
     const uint32_t total = bt.item_end[n_fit];
     const uint32_t n_staged = tot_segs;
-    // all LUT loads of the batch's crossings in flight together (MS_ITEM_CAP / 64 steps at most): a load per step in the
-    // middle of the loop cost one memory round trip per 64 crossings
-    constexpr uint32_t MAX_STEPS = MS_ITEM_CAP / 64u;
-    ItemPre pre[MAX_STEPS];
-    uint32_t lutw[MAX_STEPS];
-#pragma unroll
-    for (uint32_t k = 0; k < MAX_STEPS; k++) {
-        const uint32_t i = k * 64u + lane;
-        pre[k].rec = 0u;
-        pre[k].lut = 0u;
-        lutw[k] = 0u;
-        if (i < total) {
-            const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
-            const bool last_pixel = i + 1u == sh.count[el_ix];
-            const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
-            MsSetup su;
-            su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
-            su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
-            pre[k] = ms_item_pre<AA>(su, sub_ix, last_pixel);
-            lutw[k] = mask_lut[lut_word_index<AA>(pre[k].lut)];
-        }
-    }
-#pragma unroll
-    for (uint32_t k = 0; k < MAX_STEPS; k++) {
-        const uint32_t i = k * 64u + lane;
-        if (i < total) bt.item[i] = ms_item_fin<AA>(pre[k], lutw[k]);
+    for (uint32_t i = lane; i < total; i += 64u) {
+        const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
+        const bool last_pixel = i + 1u == sh.count[el_ix];
+        const uint32_t sub_ix = i - (el_ix > 0u ? sh.count[el_ix - 1u] : 0u);
+        MsSetup su;
+        su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
+        su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
+        bt.item[i] = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
     }
     wave_lds_sync();
     return n_fit;
