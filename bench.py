@@ -185,9 +185,16 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     rc = engine.sync()
     if rc != 0:
         raise SystemExit(f"frame failed: {rc} {engine.bump()}")
-    warm_ms = engine.stage_ms()
+    engine.stage_ms()
     bump = engine.bump()
-    dominant = max(warm_ms, key=lambda k: warm_ms[k][0] / max(warm_ms[k][1], 1))
+    # the dominant kernel = the stage with the longest launch when frames run one at a time (with frames in flight a
+    # stage's events also span the other frames' kernels that share the CUs with it)
+    for _ in range(10):
+        engine.render_resident(WIDTH, HEIGHT, BASE_COLOR, aa, out=frame)
+        engine.sync_frame(0)
+    engine.sync()
+    iso_ms = engine.stage_ms()
+    dominant = max(iso_ms, key=lambda k: iso_ms[k][0] / max(iso_ms[k][1], 1))
 
     # timed region: exactly K steps, events only around the dominant kernel (+ one completion event per frame)
     engine.set_profiling([dominant])
