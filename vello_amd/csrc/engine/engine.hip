@@ -80,6 +80,7 @@ struct vello_hip_ctx {
     hipStream_t copy_stream = nullptr;  // vello_hip_gather_frames: this context's peer copy
     hipEvent_t frame_done = nullptr;
     uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
+    bool force_brushes = false;  // pre-warm: run fine's brush specialisation on a scene without brushes
     uint32_t last_render_attempts = 0;  // rounds the last vello_hip_render needed (robust mode)
     // last frame
     Config cfg{};
@@ -290,7 +291,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     }
     f.ramps = sc.n_ramps ? (const uint32_t *)sc.ramps.ptr : nullptr;
     f.n_ramps = sc.n_ramps;
-    f.brushes = sc.brushes;
+    f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
     f.atlas_w = c->atlas_w;
@@ -456,6 +457,31 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
         if (hipMemcpy(c->mask8.ptr, l8.data(), 1024, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(c->mask16.ptr, l16.data(), 8192, hipMemcpyHostToDevice) != hipSuccess)
             return fail("mask lut upload");
+    }
+    // Pre-warm: the first launch of a kernel loads its code object and, for the kernels with a scratch segment (fine, the
+    // heavy flattener), makes the runtime allocate scratch for the queue -- ~20 ms that would otherwise land in the
+    // caller's first frame.  One frame of an empty scene per enabled AA mode and fine specialisation.
+    {
+        std::vector<uint8_t> empty(1024u * 4u, 0);  // 1024 zero tag words = 4096 padded path tags, nothing else
+        vello_hip_layout lay{};
+        lay.path_tag_base = 0u;
+        lay.path_data_base = lay.draw_tag_base = lay.draw_data_base = lay.transform_base = lay.style_base = 1024u;
+        if (vello_hip_upload_scene(c, empty.data(), empty.size(), &lay, nullptr, 0) == VELLO_HIP_OK) {
+            for (uint32_t aa = 0; aa < 3u; aa++) {
+                if (((c->aa_mask >> aa) & 1u) == 0u) continue;
+                for (int brushes = 0; brushes < 2; brushes++) {
+                    c->force_brushes = brushes != 0;
+                    vello_hip_render_params rp{16u, 16u, 0u, aa};
+                    (void)vello_hip_render_resident(c, &rp, nullptr, 0);
+                }
+            }
+            c->force_brushes = false;
+            (void)sync_all(c);
+            c->lanes[0].used = false;
+            c->have_cfg = false;
+        }
+        c->shared.resident = false;  // the caller uploads its own scene
+        c->last_error.clear();
     }
     *out = c;
     return VELLO_HIP_OK;

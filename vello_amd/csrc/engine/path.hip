@@ -253,56 +253,38 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
     }
 }
 
-// backdrop_dyn.wgsl:28-86: row-wise inclusive prefix of tile backdrops, rows load-balanced over
-// the workgroup with a scan + binary search.
+// backdrop_dyn.wgsl:28-86: row-wise inclusive prefix of tile backdrops.
+// The reference gives a row to a thread that walks it tile by tile (load -> add -> store, one memory latency per tile,
+// lanes striding rows: nothing coalesces).  Here a WAVE owns a path and its lanes take 64 CONSECUTIVE tiles of the
+// path's tile rectangle at a time -- rows are contiguous in it, so the loads and stores are whole cache lines -- with
+// a segmented shuffle scan whose segments are the rows (a lane may add the lane d to its left iff its column is >= d)
+// and a carry for the row that continues from the previous 64 tiles.  The road-map scene allocates 10 M path tiles.
 __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__restrict__ bump, const Path *__restrict__ paths, Tile *tiles) {
-    __shared__ uint32_t sh_row_width[256];
-    __shared__ uint32_t sh_row_count[256];
-    __shared__ uint32_t sh_offset[256];
-    __shared__ uint32_t sh_scan[4];
-    const uint32_t tid = threadIdx.x;
     if (bump->failed != 0u) return;
-    const uint32_t drawobj_ix = blockIdx.x * 256u + tid;
-    uint32_t row_count = 0u;
-    if (drawobj_ix < cfg.layout.n_draw_objects) {
-        Path path = paths[drawobj_ix];
-        sh_row_width[tid] = path.bbox[2] - path.bbox[0];
-        row_count = path.bbox[3] - path.bbox[1];
-        sh_offset[tid] = path.tiles;
-    } else {
-        sh_row_width[tid] = 0u;
-    }
-    uint32_t total_rows;
-    uint32_t incl = block256_incl_scan_u32(row_count, sh_scan, &total_rows);
-    sh_row_count[tid] = incl;
-    __syncthreads();
-    // gridDim.y workgroups share the rows of one group of 256 paths (a scene of a few hundred big paths is ONE group)
-    for (uint32_t row = blockIdx.y * 256u + tid; row < total_rows; row += gridDim.y * 256u) {
-        uint32_t el_ix = 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    for (uint32_t drawobj_ix = wave; drawobj_ix < cfg.layout.n_draw_objects; drawobj_ix += n_waves) {
+        const Path path = paths[drawobj_ix];
+        const uint32_t width = path.bbox[2] - path.bbox[0];
+        const uint32_t n = width * (path.bbox[3] - path.bbox[1]);
+        if (width <= 1u) continue;  // (a row of one tile is its own prefix)
+        int32_t carry = 0;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + lane;
+            const bool valid = i < n;
+            const uint32_t col = i % width;
+            const uint32_t tile_ix = path.tiles + i;
+            int32_t v = 0;
+            if (valid && tile_ix < cfg.tiles_size) v = tiles[tile_ix].backdrop;
+            const int32_t own = v;
 #pragma unroll
-        for (uint32_t i = 0; i < 8u; i++) {
-            uint32_t probe = el_ix + (128u >> i);
-            if (row >= sh_row_count[probe - 1u]) el_ix = probe;
-        }
-        uint32_t width = sh_row_width[el_ix];
-        if (width > 0u) {
-            uint32_t seq_ix = row - (el_ix > 0u ? sh_row_count[el_ix - 1u] : 0u);
-            uint32_t tile_ix = sh_offset[el_ix] + seq_ix * width;
-            // Eight tiles per step: the loads of a step are independent (the reference's load -> add -> store chain
-            // costs one memory latency per tile: 66 us for the tiger's 64-tile-wide paths on a single workgroup).
-            int32_t sum = 0;
-            for (uint32_t x0 = 0u; x0 < width; x0 += 8u) {
-                int32_t v[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) v[k] = x0 + k < width ? tiles[tile_ix + x0 + k].backdrop : 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 8u; k++) {
-                    if (x0 + k < width) {
-                        sum += v[k];
-                        if (x0 + k > 0u) tiles[tile_ix + x0 + k].backdrop = sum;
-                    }
-                }
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                const int32_t up = __shfl_up(v, (int)d);
+                if (lane >= d && col >= d) v += up;
             }
+            if (col > lane) v += carry;  // the row began before this step's first lane
+            carry = __shfl(v, 63);
+            if (valid && tile_ix < cfg.tiles_size && v != own) tiles[tile_ix].backdrop = v;
         }
     }
 }
@@ -444,9 +426,11 @@ void launch_path_count(const Frame &f, hipStream_t s) {
 }
 
 void launch_backdrop(const Frame &f, hipStream_t s) {
-    uint32_t n_wg = (f.cfg.layout.n_paths + 255u) / 256u;
-    if (n_wg == 0) return;
-    hipLaunchKernelGGL(k_backdrop, dim3(n_wg, 4), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
+    if (f.cfg.layout.n_paths == 0) return;
+    // a wave per path, waves striding over the paths; enough workgroups to cover the chip several times over
+    uint32_t n_wg = (f.cfg.layout.n_paths + 3u) / 4u;
+    if (n_wg > 4096u) n_wg = 4096u;
+    hipLaunchKernelGGL(k_backdrop, dim3(n_wg), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
 }
 
 void launch_path_tiling(const Frame &f, hipStream_t s) {
