@@ -269,13 +269,17 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
         const uint32_t n = width * (path.bbox[3] - path.bbox[1]);
         if (width <= 1u) continue;  // (a row of one tile is its own prefix)
         int32_t carry = 0;
+        // the tiles of the NEXT step are requested before this step is scanned: a long path is a chain of steps
+        int32_t next = 0;
+        if (lane < n && path.tiles + lane < cfg.tiles_size) next = tiles[path.tiles + lane].backdrop;
         for (uint32_t base = 0; base < n; base += 64u) {
             const uint32_t i = base + lane;
-            const bool valid = i < n;
+            const bool valid = i < n && path.tiles + i < cfg.tiles_size;
             const uint32_t col = i % width;
             const uint32_t tile_ix = path.tiles + i;
-            int32_t v = 0;
-            if (valid && tile_ix < cfg.tiles_size) v = tiles[tile_ix].backdrop;
+            int32_t v = next;
+            next = 0;
+            if (i + 64u < n && tile_ix + 64u < cfg.tiles_size) next = tiles[tile_ix + 64u].backdrop;
             const int32_t own = v;
 #pragma unroll
             for (uint32_t d = 1; d < 64u; d <<= 1) {
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
             }
             if (col > lane) v += carry;  // the row began before this step's first lane
             carry = __shfl(v, 63);
-            if (valid && tile_ix < cfg.tiles_size && v != own) tiles[tile_ix].backdrop = v;
+            if (valid && v != own) tiles[tile_ix].backdrop = v;
         }
     }
 }
