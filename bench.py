@@ -47,7 +47,7 @@ SEED0 = 0x5EED0001
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 # pools for the d2 scene (elements; vello_hip_capacities).  Its demand: 3.06 M lines, 4.28 M crossings / segments,
 # 9.98 M path tiles, 7.35 M dynamic PTCL words -- beyond config.rs:401-408's 2^21 / 2^21 / 2^21 / 2^23.
-THREADED_STAGES = "fine (tile-parallel); the other stages run on one thread"
+THREADED_STAGES = "flatten (per tag), path_count (per line), coarse (per bin), path_tiling (per crossing), fine (per tile); the scans, binning, tile_alloc and backdrop (2 % of the single-thread time) stay serial"
 D2_CAPS = {"lines": 1 << 22, "tiles": 1 << 24, "seg_counts": 1 << 23, "segments": 1 << 23, "ptcl": 3 << 22}
 
 

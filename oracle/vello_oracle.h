@@ -125,7 +125,10 @@ void *vo_buffer(vo_ctx *, int buf_id, size_t *size_bytes);
 void vo_make_mask_lut(uint8_t out[1024]);
 void vo_make_mask_lut_16(uint8_t out[8192]);
 
-/* Multi-threaded fine (tile-parallel) for the CPU baseline leg; 0/1 = serial. */
+/* CPU baseline leg: n_threads > 1 runs flatten (per tag), path_count (per line), coarse (per bin), path_tiling (per
+ * crossing) and fine (per tile) on that many threads -- the units the shaders themselves run in parallel, with the
+ * shaders' own atomics; outputs then differ from the serial run by what the order of atomics decides.  0/1 = serial,
+ * the mode every parity test uses. */
 void vo_set_threads(vo_ctx *, int n_threads);
 
 #ifdef __cplusplus

@@ -104,9 +104,16 @@ static void write_line_xf(flat_state *s, uint32_t line_ix, uint32_t path_ix, vec
     write_line(s, line_ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
 }
 static uint32_t alloc_lines(flat_state *s, uint32_t n) {
-    uint32_t ix = s->bump->lines;
-    s->bump->lines += n;
-    return ix;
+    /* atomic for the threaded CPU-baseline mode (vo_set_threads); with one thread it is the plain bump of the shader */
+    return __atomic_fetch_add(&s->bump->lines, n, __ATOMIC_RELAXED);
+}
+static void atomic_min_i32(int32_t *p, int32_t v) {
+    int32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+static void atomic_max_i32(int32_t *p, int32_t v) {
+    int32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
 }
 static void output_line_xf(flat_state *s, uint32_t path_ix, vec2 p0, vec2 p1, const vo_xform *t) {
     write_line_xf(s, alloc_lines(s, 1), path_ix, p0, p1, t);
@@ -644,14 +651,17 @@ static cubic_points read_path_segment(const vo_ctx *c, const path_tag_data *tag,
 
 /* flatten.wgsl:831-923 */
 void vo_stage_flatten(vo_ctx *c) {
-    flat_state st;
-    st.c = c;
-    st.lines = (vo_line_soup *)c->buf[VO_BUF_LINES];
-    st.bump = (vo_bump *)c->buf[VO_BUF_BUMP];
     vo_path_bbox *path_bboxes = (vo_path_bbox *)c->buf[VO_BUF_PATH_BBOXES];
     const vo_layout *L = &c->cfg.layout;
     uint32_t n_tags = c->n_tag_words * 4u;
+    /* one invocation per tag, as the shader: independent but for the line bump and the per-path bbox atomics
+     * (flatten.wgsl:916-921), so the CPU-baseline mode simply runs the tags on n_threads threads */
+#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
     for (uint32_t ix = 0; ix < n_tags; ix++) {
+        flat_state st;
+        st.c = c;
+        st.lines = (vo_line_soup *)c->buf[VO_BUF_LINES];
+        st.bump = (vo_bump *)c->buf[VO_BUF_BUMP];
         st.bbox[0] = 1e31f; st.bbox[1] = 1e31f; st.bbox[2] = -1e31f; st.bbox[3] = -1e31f;
         path_tag_data tag = compute_tag_monoid(c, ix);
         uint32_t path_ix = tag.monoid.path_ix;
@@ -718,10 +728,10 @@ void vo_stage_flatten(vo_ctx *c) {
             }
             if (st.bbox[2] > st.bbox[0] || st.bbox[3] > st.bbox[1]) {
                 vo_path_bbox *out = &path_bboxes[path_ix];
-                out->x0 = imin(out->x0, f2i(floorf(st.bbox[0])));
-                out->y0 = imin(out->y0, f2i(floorf(st.bbox[1])));
-                out->x1 = imax(out->x1, f2i(ceilf(st.bbox[2])));
-                out->y1 = imax(out->y1, f2i(ceilf(st.bbox[3])));
+                atomic_min_i32(&out->x0, f2i(floorf(st.bbox[0])));
+                atomic_min_i32(&out->y0, f2i(floorf(st.bbox[1])));
+                atomic_max_i32(&out->x1, f2i(ceilf(st.bbox[2])));
+                atomic_max_i32(&out->y1, f2i(ceilf(st.bbox[3])));
             }
         }
     }

@@ -171,6 +171,8 @@ void vo_stage_path_count(vo_ctx *c) {
     vo_seg_count *seg_counts = (vo_seg_count *)c->buf[VO_BUF_SEG_COUNTS];
     const float TILE_SCALE = 0.0625f;
     uint32_t n_lines = bump->lines;
+    /* one invocation per line; tile counters and the SegmentCount bump are atomics in the shader (path_count.wgsl:172-199) */
+#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
     for (uint32_t line_ix = 0; line_ix < n_lines; line_ix++) {
         vo_line_soup line = lines[line_ix];
         int is_down = line.p1[1] >= line.p0[1];
@@ -255,11 +257,10 @@ void vo_stage_path_count(vo_ctx *c) {
         ymax = imin(ymax, bbox[3]);
         for (int32_t y = ymin; y < ymax; y++) {
             int32_t base = (int32_t)path.tiles + (y - bbox[1]) * stride;
-            if ((uint32_t)base < cfg->tiles_size) tile[base].backdrop += delta; /* robust access: an out-of-range store is dropped */
+            if ((uint32_t)base < cfg->tiles_size) __atomic_fetch_add(&tile[base].backdrop, delta, __ATOMIC_RELAXED); /* robust access: an out-of-range store is dropped */
         }
         float last_z = floorf(a * ((float)imin_ - 1.0f) + b);
-        uint32_t seg_base = bump->seg_counts;
-        bump->seg_counts += imax_ - imin_;
+        uint32_t seg_base = __atomic_fetch_add(&bump->seg_counts, imax_ - imin_, __ATOMIC_RELAXED);
         for (uint32_t i = imin_; i < imax_; i++) {
             float zf = a * (float)i + b;
             float z = floorf(zf);
@@ -269,12 +270,11 @@ void vo_stage_path_count(vo_ctx *c) {
             int top_edge = (i == 0u) ? (y0 == s0.y) : (last_z == z);
             if (top_edge && x + 1 < bbox[2]) {
                 int32_t x_bump = imax(x + 1, bbox[0]);
-                if ((uint32_t)(base + x_bump) < cfg->tiles_size) tile[base + x_bump].backdrop += delta;
+                if ((uint32_t)(base + x_bump) < cfg->tiles_size) __atomic_fetch_add(&tile[base + x_bump].backdrop, delta, __ATOMIC_RELAXED);
             }
             uint32_t seg_within_slice = 0u; /* robust access: an out-of-range atomic returns 0 and stores nothing */
             if ((uint32_t)(base + x) < cfg->tiles_size) {
-                seg_within_slice = tile[base + x].segment_count_or_ix;
-                tile[base + x].segment_count_or_ix += 1u;
+                seg_within_slice = __atomic_fetch_add(&tile[base + x].segment_count_or_ix, 1u, __ATOMIC_RELAXED);
             }
             uint32_t seg_ix = seg_base + i - imin_;
             if (seg_ix < cfg->seg_counts_size) {
@@ -329,11 +329,10 @@ static void alloc_cmd(tile_state *ts, uint32_t size) {
     if (ts->cmd_offset + size >= ts->cmd_limit) {
         const vo_config *cfg = &ts->c->cfg;
         uint32_t ptcl_dyn_start = cfg->width_in_tiles * cfg->height_in_tiles * PTCL_INITIAL_ALLOC;
-        uint32_t new_cmd = ptcl_dyn_start + ts->bump->ptcl;
-        ts->bump->ptcl += PTCL_INCREMENT;
+        uint32_t new_cmd = ptcl_dyn_start + __atomic_fetch_add(&ts->bump->ptcl, PTCL_INCREMENT, __ATOMIC_RELAXED);
         if (new_cmd + PTCL_INCREMENT > cfg->ptcl_size) {
             new_cmd = 0u;
-            ts->bump->failed |= STAGE_COARSE;
+            __atomic_fetch_or(&ts->bump->failed, STAGE_COARSE, __ATOMIC_RELAXED);
         }
         ptcl_write(ts, ts->cmd_offset, CMD_JUMP);
         ptcl_write(ts, ts->cmd_offset + 1u, new_cmd);
@@ -345,8 +344,7 @@ static void alloc_cmd(tile_state *ts, uint32_t size) {
 static void write_path(tile_state *ts, vo_tile *tile, uint32_t draw_flags) {
     uint32_t n_segs = tile->segment_count_or_ix;
     if (n_segs != 0u) {
-        uint32_t seg_ix = ts->bump->segments;
-        ts->bump->segments += n_segs;
+        uint32_t seg_ix = __atomic_fetch_add(&ts->bump->segments, n_segs, __ATOMIC_RELAXED);
         tile->segment_count_or_ix = ~seg_ix;
         alloc_cmd(ts, 4u);
         ptcl_write(ts, ts->cmd_offset, CMD_FILL);
@@ -401,11 +399,16 @@ void vo_stage_coarse(vo_ctx *c) {
     uint32_t drawtag_base = cfg->layout.draw_tag_base;
     uint32_t n_partitions = (cfg->layout.n_draw_objects + N_TILE - 1u) / N_TILE;
 
+    /* one workgroup per bin, as the shader; the CPU-baseline mode runs the bins on n_threads threads (segment slices,
+     * PTCL chunks and blend spill are bump atomics in the shader too) */
+#pragma omp parallel if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
+    {
     /* per-tile compacted draw object lists for the current bin */
     uint32_t *list[N_TILE];
     uint32_t list_len[N_TILE], list_cap[N_TILE];
     for (uint32_t i = 0; i < N_TILE; i++) { list[i] = NULL; list_len[i] = 0; list_cap[i] = 0; }
 
+#pragma omp for schedule(dynamic, 1)
     for (uint32_t bin = 0; bin < n_bins; bin++) {
         for (uint32_t i = 0; i < N_TILE; i++) list_len[i] = 0;
         uint32_t bin_x = bin % width_in_bins, bin_y = bin / width_in_bins;
@@ -541,15 +544,15 @@ void vo_stage_coarse(vo_ctx *c) {
                 uint32_t blend_ix = 0u;
                 if (max_blend_depth > BLEND_STACK_SPLIT) {
                     uint32_t scratch_size = (max_blend_depth - BLEND_STACK_SPLIT) * TILE_WIDTH * TILE_HEIGHT;
-                    blend_ix = bump->blend;
-                    bump->blend += scratch_size;
-                    if (blend_ix + scratch_size > cfg->blend_size) bump->failed |= STAGE_COARSE;
+                    blend_ix = __atomic_fetch_add(&bump->blend, scratch_size, __ATOMIC_RELAXED);
+                    if (blend_ix + scratch_size > cfg->blend_size) __atomic_fetch_or(&bump->failed, STAGE_COARSE, __ATOMIC_RELAXED);
                 }
                 ptcl_write(&ts, blend_offset, blend_ix);
             }
         }
     }
     for (uint32_t i = 0; i < N_TILE; i++) free(list[i]);
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -571,6 +574,7 @@ void vo_stage_path_tiling(vo_ctx *c) {
     vo_segment *segments = (vo_segment *)c->buf[VO_BUF_SEGMENTS];
     const float TILE_SCALE = 0.0625f;
     uint32_t n_segments = bump->seg_counts;
+#pragma omp parallel for schedule(static) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
     for (uint32_t gi = 0; gi < n_segments; gi++) {
         vo_seg_count sc = seg_counts[gi];
         vo_line_soup line = lines[sc.line_ix];
