@@ -656,7 +656,7 @@ void vo_stage_flatten(vo_ctx *c) {
     uint32_t n_tags = c->n_tag_words * 4u;
     /* one invocation per tag, as the shader: independent but for the line bump and the per-path bbox atomics
      * (flatten.wgsl:916-921), so the CPU-baseline mode simply runs the tags on n_threads threads */
-#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
+#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(VO_OMP_THREADS(c))
     for (uint32_t ix = 0; ix < n_tags; ix++) {
         flat_state st;
         st.c = c;

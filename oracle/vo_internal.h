@@ -114,6 +114,9 @@ struct vo_ctx {
     vo_config cfg;
     int aa;
     int n_threads;
+/* threads of the OpenMP stages: their shared bump counters and tile words are plain atomics, which stop scaling long
+ * before a 256-thread host is used up (measured: slower at 256 than at 8); fine, with no shared writes, takes them all */
+#define VO_OMP_THREADS(c) ((c)->n_threads > 32 ? 32 : ((c)->n_threads > 1 ? (c)->n_threads : 1))
     uint32_t n_tag_words; /* padded tag bytes / 4 */
     uint32_t n_ramps;
     uint32_t *ramps;

@@ -172,7 +172,7 @@ void vo_stage_path_count(vo_ctx *c) {
     const float TILE_SCALE = 0.0625f;
     uint32_t n_lines = bump->lines;
     /* one invocation per line; tile counters and the SegmentCount bump are atomics in the shader (path_count.wgsl:172-199) */
-#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
+#pragma omp parallel for schedule(dynamic, 4096) if (c->n_threads > 1) num_threads(VO_OMP_THREADS(c))
     for (uint32_t line_ix = 0; line_ix < n_lines; line_ix++) {
         vo_line_soup line = lines[line_ix];
         int is_down = line.p1[1] >= line.p0[1];
@@ -401,7 +401,7 @@ void vo_stage_coarse(vo_ctx *c) {
 
     /* one workgroup per bin, as the shader; the CPU-baseline mode runs the bins on n_threads threads (segment slices,
      * PTCL chunks and blend spill are bump atomics in the shader too) */
-#pragma omp parallel if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
+#pragma omp parallel if (c->n_threads > 1) num_threads(VO_OMP_THREADS(c))
     {
     /* per-tile compacted draw object lists for the current bin */
     uint32_t *list[N_TILE];
@@ -574,7 +574,7 @@ void vo_stage_path_tiling(vo_ctx *c) {
     vo_segment *segments = (vo_segment *)c->buf[VO_BUF_SEGMENTS];
     const float TILE_SCALE = 0.0625f;
     uint32_t n_segments = bump->seg_counts;
-#pragma omp parallel for schedule(static) if (c->n_threads > 1) num_threads(c->n_threads > 1 ? c->n_threads : 1)
+#pragma omp parallel for schedule(static) if (c->n_threads > 1) num_threads(VO_OMP_THREADS(c))
     for (uint32_t gi = 0; gi < n_segments; gi++) {
         vo_seg_count sc = seg_counts[gi];
         vo_line_soup line = lines[sc.line_ix];

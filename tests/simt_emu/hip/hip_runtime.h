@@ -52,6 +52,13 @@ void barrier();
 int wave_exchange(unsigned long long v, unsigned long long *vals, unsigned long long *active);
 }  // namespace simt_emu
 
+// what the kernels' wave_lds_sync() is here: every live lane of the wave arrives before any proceeds
+#define VELLO_EMU_WAVE_RENDEZVOUS()                       \
+    do {                                                  \
+        unsigned long long v_[64], a_;                    \
+        simt_emu::wave_exchange(0ull, v_, &a_);           \
+    } while (0)
+
 #define threadIdx simt_emu::g_threadIdx
 #define blockIdx simt_emu::g_blockIdx
 #define blockDim simt_emu::g_blockDim

@@ -182,12 +182,9 @@ constexpr int WAVE = 64;
 // __syncthreads() puts in front of it (it would also wait for the global loads in flight).  Only the compiler has
 // to keep the order.  The CPU emulator runs lanes as fibers and needs the real rendezvous.
 #ifdef VELLO_SIMT_EMU
-// (a rendezvous of the WAVE, not of the workgroup: waves of one workgroup may be on different tiles)
-#define wave_lds_sync()                                   \
-    do {                                                  \
-        unsigned long long v_[64], a_;                    \
-        simt_emu::wave_exchange(0ull, v_, &a_);           \
-    } while (0)
+// a rendezvous of the WAVE, not of the workgroup (waves of one workgroup may be on different tiles): the emulator's
+// header provides it
+#define wave_lds_sync() VELLO_EMU_WAVE_RENDEZVOUS()
 #else
 #define wave_lds_sync()                                          \
     do {                                                         \
