@@ -903,16 +903,23 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     const uint32_t tid = threadIdx.x;
     // final counts: written by the previous kernel on this stream
     const uint32_t n_curves = control->heavy_count[0], n_heavy = n_curves + control->heavy_count[1];
-    if (blockIdx.x * 256u >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
+    // Lanes of a wave walk DIFFERENT subdivision trees, so a wave executes the union of its lanes' loops: as long as the
+    // launch has more waves than the list has entries to fill them, every wave takes only as many entries as it must
+    // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
+    // waves on four CUs); a long list fills the waves completely and strides.
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t lpw = minu(maxu((n_heavy + n_waves - 1u) / n_waves, 1u), 64u);  // list entries per wave
+    if (blockIdx.x * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
     }
     __syncthreads();
     Bump *bump = &control->bump;
+    const uint32_t lane = tid & 63u, wave = blockIdx.x * 4u + (tid >> 6);
     // no indirect dispatch in HIP: a fixed grid strides over the list
 #pragma unroll 1
-    for (uint32_t base = blockIdx.x * 256u; base < n_heavy; base += gridDim.x * 256u) {
+    for (uint32_t base = 0u; base + blockIdx.x * 4u * lpw < n_heavy; base += n_waves * lpw) {
         Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
@@ -920,8 +927,8 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         em.bind(sh);
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
-        if (base + tid < n_heavy) {
-            const uint32_t e = base + tid;
+        const uint32_t e = base + wave * lpw + lane;
+        if (lane < lpw && e < n_heavy) {
             const uint32_t tag_ix = e < n_curves ? heavy_list[e] : heavy_list[n_tags + (e - n_curves)];
             key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
@@ -929,7 +936,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
             }
         }
         // list entries of one source workgroup keep tag order, so equal path keys still come in runs
-        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)(tid & 63u));
+        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
         flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     }
 }
@@ -940,8 +947,8 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     if (grid == 0) return;
     hipLaunchKernelGGL(k_flatten_light, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
-    uint32_t grid_heavy = (n_tags + 255u) / 256u;
-    if (grid_heavy > 2048u) grid_heavy = 2048u;
+    // 2048 waves = the chip's wave slots at this kernel's register budget; workgroups beyond the list exit at once
+    const uint32_t grid_heavy = 512u;
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
 }
