@@ -908,7 +908,9 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
     // waves on four CUs); a long list fills the waves completely and strides.
     const uint32_t n_waves = gridDim.x * 4u;
-    const uint32_t lpw = minu(maxu((n_heavy + n_waves - 1u) / n_waves, 1u), 64u);  // list entries per wave
+    // list entries per wave: full waves as soon as the list would otherwise need more waves than the chip holds (2048 at
+    // this kernel's 256 VGPRs); the workgroups are then scheduled one round each, dynamically
+    const uint32_t lpw = minu(maxu((n_heavy + 2047u) / 2048u, 1u), 64u);
     if (blockIdx.x * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
@@ -947,8 +949,11 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     if (grid == 0) return;
     hipLaunchKernelGGL(k_flatten_light, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
-    // 2048 waves = the chip's wave slots at this kernel's register budget; workgroups beyond the list exit at once
-    const uint32_t grid_heavy = 512u;
+    // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
+    // (workgroups beyond the list exit at once)
+    uint32_t grid_heavy = (n_tags + 3u) / 4u;
+    if (grid_heavy > 2048u) grid_heavy = 2048u;
+    if (grid_heavy < 64u) grid_heavy = 64u;
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
 }
