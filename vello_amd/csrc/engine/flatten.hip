@@ -951,9 +951,13 @@ void launch_flatten(const Frame &f, hipStream_t s) {
                        f.lines, f.heavy_list);
     // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
     // (workgroups beyond the list exit at once)
-    uint32_t grid_heavy = (n_tags + 3u) / 4u;
+    // (a segment owns at least one word of path data, so the path-data stream bounds the list even though the tag stream
+    // is padded to 4096 tags)
+    const uint32_t n_data = f.cfg.layout.draw_tag_base - f.cfg.layout.path_data_base;
+    const uint32_t n_seg_max = n_tags < n_data ? n_tags : n_data;
+    uint32_t grid_heavy = (n_seg_max + 3u) / 4u;
     if (grid_heavy > 2048u) grid_heavy = 2048u;
-    if (grid_heavy < 64u) grid_heavy = 64u;
+    if (grid_heavy < 4u) grid_heavy = 4u;
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
 }
