@@ -457,40 +457,65 @@ template <int AA>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
                                    uint32_t lane) {
-    auto rd = [&](uint32_t ix) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
-    };
-    // scalar scan over the window; lane k keeps the parameters of fill slot k
-    uint32_t n = 0u, tot_segs = 0u;
-    uint32_t my_seg_data = 0u, my_seg_start = 0u, my_rule_n = 0u, my_backdrop = 0u;
-    uint32_t ix = cmd_ix;
-    const uint32_t win_end = win_base + 64u;
-    while (n < MS_BATCH_FILLS && ix + 4u <= win_end) {
-        const uint32_t tag = rd(ix);
-        if (tag == CMD_FILL) {
-            const uint32_t size_and_rule = rd(ix + 1u);
-            const uint32_t n_segs = size_and_rule >> 1;
-            if (tot_segs + n_segs > 64u) break;
-            const uint32_t seg_data_w = rd(ix + 2u), backdrop_w = rd(ix + 3u);
-            if (lane == n) {
-                my_seg_data = seg_data_w;
-                my_backdrop = backdrop_w;
-                my_rule_n = size_and_rule;
-                my_seg_start = tot_segs;
-            }
-            tot_segs += n_segs;
-            n += 1u;
-            ix += 4u;
-        } else if (tag == CMD_COLOR || tag == CMD_IMAGE) {
-            ix += 2u;
-        } else if (tag == CMD_SOLID || tag == CMD_BEGIN_CLIP) {
-            ix += 1u;
-        } else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) {
-            ix += 3u;
-        } else {
-            break;  // END, JUMP: the list continues elsewhere
+    // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
+    // its hazard slots, cost 600+ issue slots per batch).  Lane i looks at word i as if a command started there:
+    // next[i] = i + its size, stopping at END / JUMP / unknown tags and where a FILL's four words would leave the window.
+    // Pointer doubling then gives lane k the position of the k-th command from cmd_ix (apply next^(2^b) for every set
+    // bit b of k); the chain's fixed point is its stopping position, which is never a FILL that is taken.
+    const uint32_t s0 = cmd_ix - win_base;
+    uint32_t sz = 0u;
+    if (win == CMD_FILL) sz = 4u;
+    else if (win == CMD_COLOR || win == CMD_IMAGE) sz = 2u;
+    else if (win == CMD_SOLID || win == CMD_BEGIN_CLIP) sz = 1u;
+    else if (win == CMD_END_CLIP || win == CMD_LIN_GRAD || win == CMD_RAD_GRAD || win == CMD_SWEEP_GRAD || win == CMD_BLUR_RECT) sz = 3u;
+    const bool stop_here = sz == 0u || lane > 60u;  // (the walk went on only while ix + 4 <= window end)
+    uint32_t jump = stop_here ? lane : minu(lane + sz, 63u);
+    uint32_t pos = s0;
+#pragma unroll
+    for (uint32_t bit = 0; bit < 6u; bit++) {
+        const uint32_t hop = (uint32_t)__shfl((int)jump, (int)pos);
+        if ((lane >> bit) & 1u) pos = hop;
+        jump = (uint32_t)__shfl((int)jump, (int)jump);
+    }
+    // lane k: the k-th command of the list sits at `pos`
+    const uint32_t tag_k = (uint32_t)__shfl((int)win, (int)pos);
+    const uint32_t rule_k = (uint32_t)__shfl((int)win, (int)minu(pos + 1u, 63u));
+    bool is_fill = tag_k == CMD_FILL && pos <= 60u;
+    const uint32_t segs_k = is_fill ? rule_k >> 1 : 0u;
+    const uint32_t seg_incl = wave_incl_scan_u32(segs_k, (int)lane);
+    // the batch ends in front of the first FILL whose segments no longer fit, and after MS_BATCH_FILLS fills
+    unsigned long long fills = __ballot(is_fill);
+    const unsigned long long over = __ballot(is_fill && seg_incl > 64u);
+    if (over != 0ull) fills &= (1ull << (__ffsll((long long)over) - 1)) - 1ull;
+    uint32_t n = (uint32_t)__popcll(fills);
+    if (n > MS_BATCH_FILLS) {
+        // keep the first MS_BATCH_FILLS set bits
+        unsigned long long m = fills;
+        for (uint32_t k = 0; k < MS_BATCH_FILLS; k++) m &= m - 1ull;
+        fills &= ~m;
+        n = MS_BATCH_FILLS;
+    }
+    // slot j (lane j < n) pulls the parameters of the j-th kept fill
+    uint32_t src = 0u;
+    {
+        unsigned long long m = fills;
+        for (uint32_t k = 0; k < MS_BATCH_FILLS; k++) {  // lane j: position of the j-th set bit
+            const uint32_t b = m ? (uint32_t)__ffsll((long long)m) - 1u : 0u;
+            if (lane == k) src = b;
+            m &= m - 1ull;
         }
     }
+    const uint32_t src_pos = (uint32_t)__shfl((int)pos, (int)src);
+    uint32_t my_rule_n = (uint32_t)__shfl((int)win, (int)minu(src_pos + 1u, 63u));
+    uint32_t my_seg_data = (uint32_t)__shfl((int)win, (int)minu(src_pos + 2u, 63u));
+    uint32_t my_backdrop = (uint32_t)__shfl((int)win, (int)minu(src_pos + 3u, 63u));
+    uint32_t my_seg_start = (uint32_t)__shfl((int)(seg_incl - segs_k), (int)src);
+    if (lane >= n) {
+        my_rule_n = 0u; my_seg_data = 0u; my_backdrop = 0u; my_seg_start = 0u;
+    }
+    // segments of the kept fills: the inclusive count at the last kept fill
+    uint32_t tot_segs = 0u;
+    if (n != 0u) tot_segs = (uint32_t)__shfl((int)seg_incl, 63 - __clzll((long long)fills));
     if (n == 0u) return 0u;
     wave_lds_sync();
     if (lane < n) {
@@ -534,9 +559,8 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     }
     wave_lds_sync();
     // keep only the fills whose records fit
-    uint32_t n_fit = 0u;
-    for (uint32_t k = 0; k < n; k++)
-        if (bt.item_end[k + 1u] <= MS_ITEM_CAP) n_fit = k + 1u;
+    const unsigned long long fits = __ballot(lane < n && bt.item_end[lane + 1u] <= MS_ITEM_CAP);  // (ends are non-decreasing)
+    const uint32_t n_fit = fits ? 64u - (uint32_t)__clzll((long long)fits) : 0u;
     if (n_fit == 0u) return 0u;
     const uint32_t total = bt.item_end[n_fit];
     const uint32_t n_staged = tot_segs;
