@@ -139,6 +139,7 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
 // one count/scan, one dense item pass writing records to LDS; each FILL command then only replays its records
 // (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
 constexpr uint32_t MS_BATCH_FILLS = 12u;    // fills per batch (their segments must fit one 64-lane load)
+static_assert(MS_BATCH_FILLS <= 16u, "the slot search of ms_build_batch covers 16 slots");
 constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
 constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
 
@@ -525,19 +526,19 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
     }
-    // which slot does staged segment `lane` belong to
-    uint32_t slot = 0u, seg_data = 0u, seg_start = 0u, rule = 0u;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_start, (int)k);
-        const uint32_t sd_k = (uint32_t)__builtin_amdgcn_readlane((int)my_seg_data, (int)k);
-        const uint32_t rl_k = (uint32_t)__builtin_amdgcn_readlane((int)my_rule_n, (int)k);
-        if (lane >= st_k) {
-            slot = k;
-            seg_data = sd_k;
-            seg_start = st_k;
-            rule = rl_k;
-        }
+    // which slot does staged segment `lane` belong to: the last slot whose first segment is <= lane (starts are
+    // non-decreasing; an empty fill shares its start with its successor, which wins) -- a binary search over the slots'
+    // starts held in lanes 0 .. n-1, by shuffles
+    uint32_t slot = 0u;
+#pragma unroll
+    for (uint32_t step = 8u; step >= 1u; step >>= 1) {
+        const uint32_t probe = slot + step;
+        const uint32_t st = (uint32_t)__shfl((int)my_seg_start, (int)minu(probe, 63u));
+        if (probe < n && st <= lane) slot = probe;
     }
+    const uint32_t seg_data = (uint32_t)__shfl((int)my_seg_data, (int)slot);
+    const uint32_t seg_start = (uint32_t)__shfl((int)my_seg_start, (int)slot);
+    const uint32_t rule = (uint32_t)__shfl((int)my_rule_n, (int)slot);
     wave_lds_sync();
     uint32_t count = 0u;
     if (lane < tot_segs) {
