@@ -1173,10 +1173,23 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                 }
             }
             cmd_ix += 4u;
+            // FILL is followed by its draw command, CMD_COLOR as a rule: blend right away instead of going round the loop
+            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {
+                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
+#pragma unroll
+                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                cmd_ix += 2u;
+            }
         } else if (tag == CMD_SOLID) {
 #pragma unroll
             for (int i = 0; i < 4; i++) area[i] = 1.0f;
             cmd_ix += 1u;
+            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {  // (as after FILL)
+                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
+#pragma unroll
+                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                cmd_ix += 2u;
+            }
         } else if (tag == CMD_COLOR) {
             const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
 #pragma unroll
