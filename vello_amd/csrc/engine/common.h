@@ -194,6 +194,26 @@ constexpr int WAVE = 64;
     } while (0)
 #endif
 
+// v of the lane K to the left within a row of 16 lanes (lanes whose position in the row is < K get an unspecified value):
+// a DPP row shift on the GPU -- a modifier of an ordinary VALU move instead of a trip through the LDS crossbar.
+template <int K>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v) {
+#ifdef VELLO_SIMT_EMU
+    return (uint32_t)__shfl_up((int)v, K);
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, false);
+#endif
+}
+// v of a lane known at compile time (v_readlane on the GPU)
+template <int L>
+__device__ __forceinline__ uint32_t lane_value(uint32_t v) {
+#ifdef VELLO_SIMT_EMU
+    return (uint32_t)__shfl((int)v, L);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, L);
+#endif
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {

@@ -354,12 +354,12 @@ __device__ __forceinline__ void ms_resolve(FineShared &sh, uint32_t *sh_samples,
     // fine.wgsl publishes both prefixes through workgroup memory (sh_winding, sh_winding_y_prefix) and re-reads
     // them after a barrier; one wave does it with shuffles.  Integer adds: the order of the terms is irrelevant.
     const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
-    const uint32_t px1 = __shfl_up(prefix_x, 1), px2 = __shfl_up(prefix_x, 2), px3 = __shfl_up(prefix_x, 3);
+    const uint32_t px1 = row_shr<1>(prefix_x), px2 = row_shr<2>(prefix_x), px3 = row_shr<3>(prefix_x);
     if (lx >= 1u) packed_w += px1;
     if (lx >= 2u) packed_w += px2;
     if (lx >= 3u) packed_w += px3;
     // wind_y of rows 3, 7, 11 (any lane of the row holds it)
-    const uint32_t wy3 = __shfl(wind_y, 12), wy7 = __shfl(wind_y, 28), wy11 = __shfl(wind_y, 44);
+    const uint32_t wy3 = lane_value<12>(wind_y), wy7 = lane_value<28>(wind_y), wy11 = lane_value<44>(wind_y);
     if (ly >= 4u) wind_y += wy3;
     if (ly >= 8u) wind_y += wy7;
     if (ly >= 12u) wind_y += wy11;
@@ -582,9 +582,11 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
 template <int AA>
 __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4]) {
     constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
-    const bool even_odd = (bt.rule_backdrop[slot][0] & 1u) != 0u;
-    const int32_t backdrop = (int32_t)bt.rule_backdrop[slot][1];
-    const uint32_t begin = bt.item_end[slot], end = bt.item_end[slot + 1u];
+    // (uniform values: in scalar registers the rule's branches are real branches, not lane masks)
+    const bool even_odd = ((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][0]) & 1u) != 0u;
+    const int32_t backdrop = __builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][1]);
+    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot]);
+    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot + 1u]);
     wave_lds_sync();
     ms_clear(sh, sh_samples, even_odd, lane, SWPP);
     wave_lds_sync();
