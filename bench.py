@@ -112,6 +112,10 @@ def git_head():
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
+        pass
+    try:  # the GPU box gets a snapshot without .git: scripts/grun.sh leaves the stamp beside it
+        return open(os.path.join(ROOT, ".commit_stamp")).read().strip() or None
+    except OSError:
         return None
 
 

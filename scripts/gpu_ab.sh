@@ -2,7 +2,7 @@
 # same-box A/B: in-tree build (A) vs ab_tmp/libvello_hip_<X>.so for X in $VARIANTS (default B), alternating
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in ${REPS:-1 2}; do
 for w in A ${VARIANTS:-B}; do
   python scripts/ab_bench.py $w --steps ${STEPS:-80} --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import json,sys

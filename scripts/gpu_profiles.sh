@@ -37,7 +37,7 @@ for wl in d2 r1mix; do
   pmc sq1_$wl SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU -- $CMD
   pmc sq2_$wl SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -- $CMD
 done
-git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || true
+git rev-parse --short HEAD > $OUT/commit.txt 2>/dev/null || cp .commit_stamp $OUT/commit.txt 2>/dev/null || true
 python scripts/make_pmc_traffic.py $OUT $TAG > $OUT/pmc_traffic.json
 rm -f $OUT/*.log
 ls $OUT

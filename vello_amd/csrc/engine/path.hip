@@ -259,37 +259,50 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
 // path's tile rectangle at a time -- rows are contiguous in it, so the loads and stores are whole cache lines -- with
 // a segmented shuffle scan whose segments are the rows (a lane may add the lane d to its left iff its column is >= d)
 // and a carry for the row that continues from the previous 64 tiles.  The road-map scene allocates 10 M path tiles.
+// Rows are independent, so a path is cut into blocks of whole rows (about BACKDROP_BLOCK_TILES tiles) and the four
+// waves of a workgroup share the blocks of FOUR consecutive paths (block b of the group's path p goes to wave
+// (b + p) & 3): a typical path (99 tiles, one block) still gets a wave of its own, while the launch no longer ends with
+// one wave's chain of 97 dependent steps through the largest road (6 k tiles).
+constexpr uint32_t BACKDROP_BLOCK_TILES = 1024u;
 __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__restrict__ bump, const Path *__restrict__ paths, Tile *tiles) {
     if (bump->failed != 0u) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
-    for (uint32_t drawobj_ix = wave; drawobj_ix < cfg.layout.n_draw_objects; drawobj_ix += n_waves) {
+    const uint32_t lane = threadIdx.x & 63u, slice = threadIdx.x >> 6;
+    const uint32_t n_obj = cfg.layout.n_draw_objects;
+    for (uint32_t group = blockIdx.x; group * 4u < n_obj; group += gridDim.x) {
+      for (uint32_t p = 0; p < 4u; p++) {
+        const uint32_t drawobj_ix = group * 4u + p;
+        if (drawobj_ix >= n_obj) break;
         const Path path = paths[drawobj_ix];
-        const uint32_t width = path.bbox[2] - path.bbox[0];
-        const uint32_t n = width * (path.bbox[3] - path.bbox[1]);
+        const uint32_t width = path.bbox[2] - path.bbox[0], height = path.bbox[3] - path.bbox[1];
         if (width <= 1u) continue;  // (a row of one tile is its own prefix)
-        int32_t carry = 0;
-        // the tiles of the NEXT step are requested before this step is scanned: a long path is a chain of steps
-        int32_t next = 0;
-        if (lane < n && path.tiles + lane < cfg.tiles_size) next = tiles[path.tiles + lane].backdrop;
-        for (uint32_t base = 0; base < n; base += 64u) {
-            const uint32_t i = base + lane;
-            const bool valid = i < n && path.tiles + i < cfg.tiles_size;
-            const uint32_t col = i % width;
-            const uint32_t tile_ix = path.tiles + i;
-            int32_t v = next;
-            next = 0;
-            if (i + 64u < n && tile_ix + 64u < cfg.tiles_size) next = tiles[tile_ix + 64u].backdrop;
-            const int32_t own = v;
+        const uint32_t block_rows = maxu(1u, BACKDROP_BLOCK_TILES / width);
+        for (uint32_t row0 = ((slice - p) & 3u) * block_rows; row0 < height; row0 += 4u * block_rows) {
+            const uint32_t first = path.tiles + row0 * width;
+            const uint32_t n = minu(block_rows, height - row0) * width;
+            int32_t carry = 0;
+            // the tiles of the NEXT step are requested before this step is scanned: a block is a chain of steps
+            int32_t next = 0;
+            if (lane < n && first + lane < cfg.tiles_size) next = tiles[first + lane].backdrop;
+            for (uint32_t base = 0; base < n; base += 64u) {
+                const uint32_t i = base + lane;
+                const uint32_t tile_ix = first + i;
+                const bool valid = i < n && tile_ix < cfg.tiles_size;
+                const uint32_t col = i % width;
+                int32_t v = next;
+                next = 0;
+                if (i + 64u < n && tile_ix + 64u < cfg.tiles_size) next = tiles[tile_ix + 64u].backdrop;
+                const int32_t own = v;
 #pragma unroll
-            for (uint32_t d = 1; d < 64u; d <<= 1) {
-                const int32_t up = __shfl_up(v, (int)d);
-                if (lane >= d && col >= d) v += up;
+                for (uint32_t d = 1; d < 64u; d <<= 1) {
+                    const int32_t up = __shfl_up(v, (int)d);
+                    if (lane >= d && col >= d) v += up;
+                }
+                if (col > lane) v += carry;  // the row began before this step's first lane
+                carry = __shfl(v, 63);
+                if (valid && v != own) tiles[tile_ix].backdrop = v;
             }
-            if (col > lane) v += carry;  // the row began before this step's first lane
-            carry = __shfl(v, 63);
-            if (valid && v != own) tiles[tile_ix].backdrop = v;
         }
+      }
     }
 }
 
@@ -431,9 +444,9 @@ void launch_path_count(const Frame &f, hipStream_t s) {
 
 void launch_backdrop(const Frame &f, hipStream_t s) {
     if (f.cfg.layout.n_paths == 0) return;
-    // a wave per path, waves striding over the paths; enough workgroups to cover the chip several times over
+    // a workgroup per four paths (its waves share their row blocks), workgroups striding over the groups
     uint32_t n_wg = (f.cfg.layout.n_paths + 3u) / 4u;
-    if (n_wg > 4096u) n_wg = 4096u;
+    if (n_wg > 8192u) n_wg = 8192u;
     hipLaunchKernelGGL(k_backdrop, dim3(n_wg), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
 }
 
