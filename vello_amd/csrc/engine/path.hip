@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                 for (uint32_t k = 0; k < 4u; k++) {
                     const uint32_t s = s0 + k;
                     const bool act = s < count;
-                    uint32_t key = 0xffffffffu;
+                    uint32_t key = 0xffffffffu, bkey = 0xffffffffu;
                     uint32_t i = w.imin + s;
                     if (act) {
                         float zf = w.a * (float)i + w.b;
@@ -213,10 +213,27 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                         bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
                         if (top_edge && x + 1 < w.bbox2) {
                             int32_t x_bump = maxi(x + 1, w.bbox0);
-                            if ((uint32_t)(base + x_bump) < cfg.tiles_size) atomicAdd(&tile[base + x_bump].backdrop, delta);
+                            if ((uint32_t)(base + x_bump) < cfg.tiles_size) bkey = (uint32_t)(base + x_bump);
                         }
                         key = (uint32_t)(base + x);
                         last_z = z;
+                    }
+                    // Backdrop bumps of ADJACENT lanes on the same tile are added up before they touch memory, in pairs
+                    // (even offsets of a run of equal targets absorb their right neighbour).  The two outlines of a stroked
+                    // segment are neighbours in the soup (flatten allocates them together), run a few pixels apart in
+                    // opposite directions and cross a tile row in the same tile: their +1 and -1 cancel and no atomic is
+                    // issued at all.  What a scattered atomic costs is one request per distinct cache line and
+                    // instruction, 2.7e10 per second chip-wide (scripts/calib/atomic_rate.hip) -- that rate, not
+                    // arithmetic or bandwidth, is what bounds this kernel.  Integer adds: any grouping gives the same sum.
+                    if (__ballot(bkey != 0xffffffffu) != 0ull) {
+                        const uint32_t bprev = __shfl_up(bkey, 1), bnext = __shfl_down(bkey, 1);
+                        const int32_t dnext = __shfl_down(delta, 1);
+                        const unsigned long long bheads = __ballot(lane == 0 || bprev != bkey);
+                        const int bhead_lane = 63 - __clzll((long long)(bheads & (~0ull >> (63 - lane))));
+                        if (bkey != 0xffffffffu && (((lane - bhead_lane) & 1) == 0)) {
+                            const int32_t d = delta + ((lane < 63 && bnext == bkey) ? dnext : 0);
+                            if (d != 0) atomicAdd(&tile[bkey].backdrop, d);
+                        }
                     }
                     uint32_t prev_key = __shfl_up(key, 1);
                     bool head = !act || lane == 0 || prev_key != key;
