@@ -38,6 +38,10 @@ struct dim3 {
 struct uint4 {
     unsigned x, y, z, w;
 };
+struct float4 {
+    float x, y, z, w;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 namespace simt_emu {

@@ -59,10 +59,17 @@ struct SegSetupLds {
     int32_t x0i[64], y0i[64];
     uint32_t flags[64];
 };
+// Per-pixel exchange of ms_fill_from_batch (live only while a staged fill is resolved): the byte a sample counter
+// holds where the winding number is zero, and the coverage, indexed by pixel.
+struct alignas(16) PixelLds {
+    uint32_t expected_zero[256];
+    float area[256];
+};
 struct FineShared {
     union {
         Segment seg[64];
         SegSetupLds su;
+        PixelLds px;
     };
     uint32_t count[64];
     uint32_t winding_y[4];
@@ -578,21 +585,132 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     return n_fit;
 }
 
-// A FILL command whose crossings were staged by ms_build_batch: replay its records and resolve.
+// The per-pixel part of the resolve (fine.wgsl:399-466) for one pixel of a non-zero fill: `ez` is the byte a sample
+// counter holds where the winding number is zero, s0.. the pixel's packed sample counters.
 template <int AA>
-__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4]) {
+__device__ __forceinline__ float ms_pixel_area(uint32_t ez, uint32_t samples0, uint32_t samples1, uint32_t samples2, uint32_t samples3) {
+    if (AA != 2) {
+        uint32_t xored0 = (ez * 0x1010101u) ^ samples0;
+        uint32_t xored0_2 = xored0 | (xored0 * 2u);
+        uint32_t xored1 = (ez * 0x1010101u) ^ samples1;
+        uint32_t xored1_2 = xored1 | (xored1 >> 1);
+        uint32_t xored2 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+        uint32_t xored4 = xored2 | (xored2 * 4u);
+        uint32_t xored8 = xored4 | (xored4 * 16u);
+        return (float)__popc(xored8 & 0xC0C0C0C0u) * 0.125f;
+    }
+    uint32_t xored0 = (ez * 0x1010101u) ^ samples0;
+    uint32_t xored0_2 = xored0 | (xored0 * 2u);
+    uint32_t xored1 = (ez * 0x1010101u) ^ samples1;
+    uint32_t xored1_2 = xored1 | (xored1 >> 1);
+    uint32_t xored01 = (xored0_2 & 0xAAAAAAAAu) | (xored1_2 & 0x55555555u);
+    uint32_t xored01_4 = xored01 | (xored01 * 4u);
+    uint32_t xored2 = (ez * 0x1010101u) ^ samples2;
+    uint32_t xored2_2 = xored2 | (xored2 * 2u);
+    uint32_t xored3 = (ez * 0x1010101u) ^ samples3;
+    uint32_t xored3_2 = xored3 | (xored3 >> 1);
+    uint32_t xored23 = (xored2_2 & 0xAAAAAAAAu) | (xored3_2 & 0x55555555u);
+    uint32_t xored23_4 = xored23 | (xored23 >> 2);
+    uint32_t xored4 = (xored01_4 & 0xCCCCCCCCu) | (xored23_4 & 0x33333333u);
+    uint32_t xored8 = xored4 | (xored4 * 16u);
+    return (float)__popc(xored8 & 0xF0F0F0F0u) * 0.0625f;
+}
+
+// A FILL command whose crossings were staged by ms_build_batch: replay its records and resolve.
+//
+// Non-zero fills are resolved SPARSELY.  fine.wgsl clears all sample counters, lets the crossings bump some, and has
+// every thread read and evaluate the counters of its 4 pixels (MSAA16: 16 LDS words and ~160 VALU per lane and fill).
+// A fill of a map-like scene puts ~35 crossings into a tile: >= 85 % of the pixels are never touched, and an untouched
+// pixel's counters all hold the cleared value 0x80, so its coverage is 1 if the winding number that reaches it is
+// non-zero and 0 otherwise -- no counter has to be read.  So: every lane derives `expected_zero` for its 4 pixels from
+// the winding prefix sums as before and takes that 0/1 coverage; ONE LANE PER CROSSING RECORD then evaluates the real
+// formula for the record's pixel (its expected_zero comes from the owning lane through LDS), stores the coverage for the
+// owner to pick up, and puts the pixel's counters back to the cleared value -- which is what leaves the counters
+// clean for the next fill without a clearing pass (`clean` tracks that across fills; the even-odd and the
+// one-fill-at-a-time paths clear for themselves and leave the counters dirty).  Two records on one pixel compute and
+// store the same value.  Same integer operations on the same counter values as the dense resolve: bit-identical.
+template <int AA>
+__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4],
+                                   bool &clean) {
     constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
     // (uniform values: in scalar registers the rule's branches are real branches, not lane masks)
     const bool even_odd = ((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][0]) & 1u) != 0u;
     const int32_t backdrop = __builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][1]);
     const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot]);
     const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot + 1u]);
+    if (even_odd) {
+        wave_lds_sync();
+        ms_clear(sh, sh_samples, true, lane, SWPP);
+        clean = false;
+        wave_lds_sync();
+        for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], true, sh.winding, sh_samples);
+        wave_lds_sync();
+        ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], true, backdrop, lane, area);
+        return;
+    }
     wave_lds_sync();
-    ms_clear(sh, sh_samples, even_odd, lane, SWPP);
+    if (!clean) {
+        ms_clear(sh, sh_samples, false, lane, SWPP);
+        clean = true;
+        wave_lds_sync();
+    }
+    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], false, sh.winding, sh_samples);
     wave_lds_sync();
-    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], even_odd, sh.winding, sh_samples);
+    // winding prefix sums exactly as ms_resolve; the row counters go back to their cleared value as they are read
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    uint32_t packed_w = sh.winding[lane];
+    sh.winding[lane] = 0x80808080u;
+    packed_w += (packed_w - 0x808080u) << 8;
+    packed_w += (packed_w - 0x8080u) << 16;
+    uint32_t packed_y = bt.winding_y[slot][ly >> 2];
+    packed_y += (packed_y - 0x808080u) << 8;
+    packed_y += (packed_y - 0x8080u) << 16;
+    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
+    const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
+    const uint32_t px1 = row_shr<1>(prefix_x), px2 = row_shr<2>(prefix_x), px3 = row_shr<3>(prefix_x);
+    if (lx >= 1u) packed_w += px1;
+    if (lx >= 2u) packed_w += px2;
+    if (lx >= 3u) packed_w += px3;
+    const uint32_t wy3 = lane_value<12>(wind_y), wy7 = lane_value<28>(wind_y), wy11 = lane_value<44>(wind_y);
+    if (ly >= 4u) wind_y += wy3;
+    if (ly >= 8u) wind_y += wy7;
+    if (ly >= 12u) wind_y += wy11;
+    uint32_t ez[4];
+#pragma unroll
+    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
+        ez[i] = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
+        // untouched counters are 0x80: every sample differs from expected_zero, or none does
+        area[i] = ez[i] == 0x80u ? 0.0f : 1.0f;
+    }
+    if (begin == end) return;
+    *reinterpret_cast<uint4 *>(&sh.px.expected_zero[lane * 4u]) = make_uint4(ez[0], ez[1], ez[2], ez[3]);
+    *reinterpret_cast<float4 *>(&sh.px.area[lane * 4u]) = make_float4(area[0], area[1], area[2], area[3]);
     wave_lds_sync();
-    ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], even_odd, backdrop, lane, area);
+    for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t rec = i < end ? bt.item[i] : 0u;
+        if (rec & REC_PIX_VALID) {
+            const uint32_t pix_ix = rec & 0xffu;
+            const uint32_t e = sh.px.expected_zero[pix_ix];
+            const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
+            const uint32_t s0 = sh_samples[so], s1 = sh_samples[so + 64u];
+            const uint32_t s2 = AA == 2 ? sh_samples[so + 128u] : 0u, s3 = AA == 2 ? sh_samples[so + 192u] : 0u;
+            if (e < 256u) sh.px.area[pix_ix] = ms_pixel_area<AA>(e, s0, s1, s2, s3);  // (>= 256: coverage 1, as the owner has it)
+        }
+    }
+    wave_lds_sync();
+    for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        const uint32_t rec = i < end ? bt.item[i] : 0u;
+        if (rec & REC_PIX_VALID) {
+            const uint32_t pix_ix = rec & 0xffu;
+            const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
+#pragma unroll
+            for (uint32_t w = 0; w < SWPP; w++) sh_samples[so + w * 64u] = 0x80808080u;
+        }
+    }
+    const float4 a = *reinterpret_cast<const float4 *>(&sh.px.area[lane * 4u]);
+    area[0] = a.x; area[1] = a.y; area[2] = a.z; area[3] = a.w;
 }
 
 // ---------------- blend (shared/blend.wgsl) ----------------
@@ -1127,6 +1245,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     pre.p0x = 0.0f; pre.p0y = 0.0f; pre.p1x = 0.0f; pre.p1y = 0.0f; pre.y_edge = 0.0f; pre.pad = 0u;
     uint32_t pre_seg_data = ~0u;
     uint32_t batch_n = 0u, batch_pos = 0u;  // MSAA: fills staged by ms_build_batch / already consumed
+    bool samples_clean = false;             // MSAA: the sample counters hold their cleared (non-zero rule) value
     for (;;) {
         ensure(cmd_ix, 4u);
         const uint32_t tag = rd(cmd_ix);
@@ -1164,7 +1283,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     batch_pos = 0u;
                 }
                 if (batch_n != 0u) {
-                    ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area);
+                    ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area, samples_clean);
                     batch_pos += 1u;
                 } else {
                     CmdFill fill;
@@ -1172,6 +1291,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     fill.seg_data = rd(cmd_ix + 2u);
                     fill.backdrop = (int32_t)rd(cmd_ix + 3u);
                     fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area);
+                    samples_clean = false;
                 }
             }
             cmd_ix += 4u;
