@@ -39,10 +39,10 @@ namespace vk {
 namespace {
 
 constexpr uint32_t SUB_W = 8;         // a workgroup owns an 8x8-tile quadrant of a bin
-constexpr uint32_t NW = 4;            // waves per workgroup; wave w emits objects [64w, 64w + 64) of a batch
+constexpr uint32_t NW = 8;            // waves per workgroup; wave w emits objects [64w, 64w + 64) of a batch
 constexpr uint32_t WG = 64 * NW;
 constexpr uint32_t NB = 64 * NW;      // draw objects per batch
-constexpr uint32_t QCAP = 512;        // queue slots: NB - 1 left over + WG new ones; power of two
+constexpr uint32_t QCAP = 1024;       // queue slots: NB - 1 left over + WG new ones; power of two
 constexpr uint32_t PART_CHUNK = 256;  // bin headers (partitions of 256 draw objects) merged at a time
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
@@ -186,11 +186,17 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
 
 // coarse.wgsl:156-471.  256 threads: as draw objects while the bin's list is filtered, as 4 x 64 (tile, object) pairs
 // while a batch is emitted; wave 0's lanes are also the 64 tiles of the quadrant (write pointers, clip state).
-__global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
+__global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
                                                 const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
                                                 const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
                                                 uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order) {
+#ifdef VELLO_SIMT_EMU
     __shared__ CoarseLds sh;
+#else
+    // more than the 64 KB a kernel may declare statically: dynamic LDS, sized and enabled by launch_coarse
+    extern __shared__ __attribute__((aligned(16))) unsigned char coarse_lds_raw[];
+    CoarseLds &sh = *reinterpret_cast<CoarseLds *>(coarse_lds_raw);
+#endif
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     {  // coarse.wgsl:161-176
@@ -219,6 +225,18 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
     const bool has_clips = cfg.layout.n_clips != 0u;
     const bool cull = allow_cull && !has_clips;
     const uint32_t ptcl_dyn_start = cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
+#ifdef VELLO_COARSE_PROF
+    // Measurement build only (scripts/coarse_prof.py): shader-clock cycles per phase and workgroup, left in the last
+    // 8192 words of the PTCL pool.  0 stream rounds, 1 batch front (transposes, occluders, clips), 2 allocation,
+    // 3 emission, 4 batch end, 5 list end; 6 = stream rounds, 7 = batches.
+    long long prof_prev = clock64();
+    uint32_t prof_acc[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#define CPROF(k) do { const long long t_ = clock64(); prof_acc[k] += (uint32_t)(t_ - prof_prev); prof_prev = t_; } while (0)
+#define CPROF_COUNT(k) prof_acc[k] += 1u
+#else
+#define CPROF(k)
+#define CPROF_COUNT(k)
+#endif
 
     // ---- per-tile state, live in wave 0 (lane = tile) ----
     const uint32_t this_tile_ix = (sub_y0 + lane / SUB_W) * cfg.width_in_tiles + sub_x0 + lane % SUB_W;
@@ -308,6 +326,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             cur_valid = next_valid;
             next_valid = nn_valid;
             more = cur_valid;
+            CPROF(8);
             // An object matters to this quadrant if its tile rectangle meets it (coarse.wgsl:264-289) AND at least one of
             // those tiles is included (coarse.wgsl:318-341): its 64-bit coverage masks come from <= 8 row windows of the
             // bit planes (the reference reads a Tile per (object, tile) pair and sets LDS bits with atomics), and an
@@ -321,46 +340,48 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             const uint32_t stride = (uint32_t)(bx1 - bx0);
             const uint32_t base = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
             u64 inc = 0ull, kil = 0ull, seg = 0ull, clr = 0ull;
-            if (meets) {
-                const uint32_t rx0 = (uint32_t)x0, ry0 = (uint32_t)y0, w = (uint32_t)(x1 - x0), h = (uint32_t)(y1 - y0);
+            {
+                // BRANCH-FREE on purpose: with each row's two loads under `if (r < h)` the compiler ends every one of the
+                // 16 conditional blocks with s_waitcnt vmcnt(0) -- sixteen memory round trips in a row, 8 300 of a
+                // round's 13 000 cycles.  Rows an object does not have (and objects that miss the quadrant) load the
+                // first words of the plane instead and get an empty row mask.
+                const uint32_t rx0 = (uint32_t)x0, ry0 = (uint32_t)y0;
+                const uint32_t w = meets ? (uint32_t)(x1 - x0) : 0u, h = meets ? (uint32_t)(y1 - y0) : 0u;
                 const bool is_clip = (el.tag & 1u) != 0u;
                 const uint32_t BLEND_CLIP = (128u << 8) | 3u;
                 const bool is_blend = is_clip && el.w0 != BLEND_CLIP;
                 const bool even_odd = (el.flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
                 const uint32_t *plane_c = even_odd ? plane_o : plane_z;
                 const uint32_t wmask = (1u << w) - 1u;
+                const uint32_t b0 = base + stride * ry0 + rx0;
                 u64 ws[SUB_W], wc[SUB_W];
 #pragma unroll
                 for (uint32_t r = 0; r < SUB_W; r++) {
-                    ws[r] = 0ull;
-                    wc[r] = 0ull;
-                    if (r < h) {
-                        const uint32_t b = base + stride * (ry0 + r) + rx0;
-                        ws[r] = plane_window(plane_s, b);
-                        wc[r] = plane_window(plane_c, b);
-                    }
+                    const uint32_t b = r < h ? b0 + stride * r : 0u;
+                    ws[r] = plane_window(plane_s, b);
+                    wc[r] = plane_window(plane_c, b);
                 }
 #pragma unroll
                 for (uint32_t r = 0; r < SUB_W; r++) {
-                    if (r < h) {
-                        const uint32_t sg = (uint32_t)ws[r] & wmask;
-                        const uint32_t clear = (uint32_t)wc[r] & wmask;  // backdrop_clear per tile of the row
-                        // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
-                        const uint32_t in = is_blend ? wmask : (sg | ((is_clip ? clear : ~clear) & wmask));
-                        const uint32_t shift = (ry0 + r) * SUB_W + rx0;
-                        inc |= (u64)in << shift;
-                        kil |= (u64)(in & ~sg) << shift;
-                        seg |= (u64)(in & sg) << shift;
-                        clr |= (u64)(in & clear) << shift;
-                    }
+                    const uint32_t rmask = r < h ? wmask : 0u;
+                    const uint32_t sg = (uint32_t)ws[r] & rmask;
+                    const uint32_t clear = (uint32_t)wc[r] & rmask;  // backdrop_clear per tile of the row
+                    // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
+                    const uint32_t in = is_blend ? rmask : (sg | ((is_clip ? clear : ~clear) & rmask));
+                    const uint32_t shift = ((ry0 + r) * SUB_W + rx0) & 63u;
+                    inc |= (u64)in << shift;
+                    seg |= (u64)(in & sg) << shift;
+                    clr |= (u64)(in & clear) << shift;
                 }
                 // fully covering opaque solid colour: occludes every earlier draw of the tile
-                if (!(cull && el.tag == DRAWTAG_FILL_COLOR && (el.w0 >> 24) == 0xffu)) kil = 0ull;
+                if (cull && el.tag == DRAWTAG_FILL_COLOR && (el.w0 >> 24) == 0xffu) kil = inc & ~seg;
             }
             const bool keep = inc != 0ull;
             const u64 m = __ballot(keep);
+            CPROF(9);
             if (lane == 0u) sh.wave_cnt[wave] = popc64(m);
             __syncthreads();
+            CPROF(10);
             uint32_t before = 0u, total_new = 0u;
 #pragma unroll
             for (uint32_t w = 0; w < NW; w++) {
@@ -393,6 +414,8 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             }
             qlen += total_new;
             __syncthreads();
+            CPROF(0);
+            CPROF_COUNT(6);
         }
 
         // ---- full batches, and whatever is left when the stream has ended ----
@@ -544,6 +567,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             Tile tl[EMIT_GROUP];
             load_group(0u, info, tix, tl);  // in flight across the barrier and wave 0's allocation
             __syncthreads();  // (2) S of all slices
+            CPROF(1);
             // ALLOCATE (wave 0, lane = tile): one PTCL region per tile that needs one behind ONE atomic; the command sizes
             // follow from the bitmaps alone, so no Tile has been read yet
             if (wave == 0u) {
@@ -592,6 +616,7 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             // records are scanned once and the wave reserves the
             // group's segment slices with ONE atomic (a slice may sit anywhere: CMD_FILL carries its index)
             bool bases_ready = false;
+            CPROF(2);
             for (uint32_t g0 = 0; g0 < n_iter; g0 += EMIT_GROUP) {
                 if (g0 != 0u) load_group(g0, info, tix, tl);
                 uint32_t my_segs = 0u;
@@ -650,9 +675,12 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
                 }
             }
             if (!bases_ready) __syncthreads();  // (3) for the waves whose slice emits nothing
+            CPROF(3);
             qh = (qh + n) & (QCAP - 1u);
             qlen -= n;
             __syncthreads();  // (4) the per-batch tables and the freed queue slots are rewritten next
+            CPROF(4);
+            CPROF_COUNT(7);
         }
     }
     if (wave == 0u) {
@@ -687,6 +715,11 @@ __global__ void __launch_bounds__(256) k_coarse(Config cfg, const uint32_t *__re
             }
         }
     }
+#ifdef VELLO_COARSE_PROF
+    CPROF(5);
+    if (tid == 0u && cfg.ptcl_size >= 8192u && blockIdx.x < 512u)
+        for (uint32_t k = 0; k < 16u; k++) ptcl[cfg.ptcl_size - 8192u + blockIdx.x * 16u + k] = prof_acc[k];
+#endif
 }
 
 void launch_coarse(const Frame &f, hipStream_t s) {
@@ -700,7 +733,12 @@ void launch_coarse(const Frame &f, hipStream_t s) {
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
-    hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), 0, s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
+#ifndef VELLO_SIMT_EMU
+    static const hipError_t lds_enabled =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CoarseLds));
+    (void)lds_enabled;  // (a refusal shows up as the launch error the engine reports)
+#endif
+    hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order);
 }
 
