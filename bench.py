@@ -366,7 +366,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--in-flight", type=int, default=6,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="frames the engine keeps in flight (wgpu queues recordings the same way); 1 = serial frames")
     ap.add_argument("--workload", choices=["both", "d2", "r1mix"], default="both",
                     help="d2 = SURVEY 8d d2's C3 scene (the workload of `value`); r1mix = round 1's mix; both = d2 + r1mix beside it")

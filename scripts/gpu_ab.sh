@@ -8,6 +8,6 @@ for w in A ${VARIANTS:-B}; do
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['config']['secondary']
 f=lambda r: ' '.join('%s %.0f' % (k[:6], v*1e3) for k,v in r['stage_ms'].items() if v*1e3 >= 20)
-print('$w d2 %.0f/%.0f [%s] | r1mix %.0f/%.0f [%s]' % (d['value'], d['config']['value_one_frame_at_a_time'], f(d['roofline']), s['value'], s['value_one_frame_at_a_time'], f(s['roofline'])))"
+print('$w d2 %.0f/%.0f r1mix %.0f/%.0f | d2 [%s] r1mix [%s]' % (d['value'], d['config']['value_one_frame_at_a_time'], s['value'], s['value_one_frame_at_a_time'], f(d['roofline']), f(s['roofline'])))"
 done
 done
