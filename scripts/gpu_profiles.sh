@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ holds for one state of the code, in one GPU session: rocprofv3 kernel stats (one frame at a time,
-# both workloads; 6 frames in flight for the agreement check), PMC traffic (calibrated FETCH_SIZE / WRITE_SIZE, separate
+# both workloads; the default frames in flight for the agreement check), PMC traffic (calibrated FETCH_SIZE / WRITE_SIZE, separate
 # passes, kernel trace only) and SQ counters.  Results land in gpurun_out/profiles_<tag>/; copy them to profiles/.
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -25,7 +25,7 @@ pmc() { # name counters -- cmd...
 for wl in d2 r1mix; do
   stats serial_$wl python bench.py --workload $wl --steps 50 --warmup 5 --in-flight 1 --timed-only
 done
-stats inflight6_d2 python bench.py --workload d2 --steps 100 --warmup 10 --timed-only
+stats pipelined_d2 python bench.py --workload d2 --steps 100 --warmup 10 --timed-only
 python bench.py --workload d2 --steps 100 --warmup 10 --timed-only 2>/dev/null | tail -1 > $OUT/${TAG}_bench_timed_only_d2.json
 if [ ! -x scripts/calib/pmc_calib ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/calib/pmc_calib.hip -o scripts/calib/pmc_calib; fi
 pmc calib_fetch FETCH_SIZE -- scripts/calib/pmc_calib
