@@ -749,3 +749,40 @@ def test_emu_gather_frames_between_contexts(built):
             assert np.array_equal(dst[i], refs[i])
     finally:
         L._use_library(None)
+
+
+def _fill_rule_interleave_scene(seed):
+    """One or two tiles covered by many small fills whose rule alternates at random between NonZero and EvenOdd, with
+    a > 64-segment fill (taken one at a time by fine) and empty-coverage fills thrown in: every order in which fine's
+    three MSAA resolve paths (sparse non-zero, dense even-odd, unbatched) can hand the sample counters to each other."""
+    import math
+
+    from vello_amd import Affine, BezPath, Color, Fill, Scene
+
+    rng = np.random.default_rng(seed)
+    s = Scene()
+    for k in range(40):
+        p = BezPath()
+        big = rng.random() < 0.12
+        n = int(rng.integers(200, 320)) if big else int(rng.integers(3, 9))
+        cx, cy = rng.uniform(2, 30, 2)
+        r0 = float(rng.uniform(2.0, 6.0)) if big else float(rng.uniform(1.0, 9.0))
+        for i in range(n):
+            a = 2 * math.pi * (i * (3 if rng.random() < 0.5 else 1)) / n  # star polygons self-intersect: the rules differ
+            r = r0 * (1.0 if i % 2 == 0 else float(rng.uniform(0.3, 1.0)))
+            pt = (cx + r * math.cos(a), cy + r * math.sin(a))
+            p.move_to(pt) if i == 0 else p.line_to(pt)
+        p.close_path()
+        if rng.random() < 0.1:  # a fill that misses every sample (degenerate sliver on a pixel boundary)
+            p = BezPath()
+            p.move_to((4.0, 8.0)); p.line_to((20.0, 8.0)); p.line_to((4.0, 8.0)); p.close_path()
+        col = Color(float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.choice([1.0, 0.6])))
+        s.fill(Fill(int(rng.integers(0, 2))), Affine.IDENTITY, col, None, p)
+    return s.resolve()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_emu_fill_rules_interleaved_in_one_tile(emu_engine, seed):
+    packed, layout = _fill_rule_interleave_scene(seed)
+    for aa in (AaConfig.Msaa8, AaConfig.Msaa16):
+        compare_frame(emu_engine, packed, layout, 32, 32, 0xFF203040, aa, f"emu_rules_{seed}_{int(aa)}", order_sensitive=True)

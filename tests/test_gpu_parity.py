@@ -639,3 +639,14 @@ def test_gather_frames_peer_copy(built):
     out = dst.cpu().numpy()
     for i in range(3):
         assert np.array_equal(out[i], refs[i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_gpu_fill_rules_interleaved_in_one_tile(gpu_engine, seed):
+    # fine's three MSAA resolve paths (sparse non-zero, dense even-odd, unbatched) handing the sample counters to each other
+    from tests.test_emu_parity import _fill_rule_interleave_scene
+
+    packed, layout = _fill_rule_interleave_scene(seed)
+    for aa in (AaConfig.Msaa8, AaConfig.Msaa16):
+        compare_frame(gpu_engine, packed, layout, 32, 32, 0xFF203040, aa, f"gpu_rules_{seed}_{int(aa)}", order_sensitive=True)
