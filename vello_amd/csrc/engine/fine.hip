@@ -464,7 +464,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
 template <int AA>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t lane) {
+                                   uint32_t lane, uint32_t &after_batch) {
     // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
     // its hazard slots, cost 600+ issue slots per batch).  Lane i looks at word i as if a command started there:
     // next[i] = i + its size, stopping at END / JUMP / unknown tags and where a FILL's four words would leave the window.
@@ -525,6 +525,9 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     uint32_t tot_segs = 0u;
     if (n != 0u) tot_segs = (uint32_t)__shfl((int)seg_incl, 63 - __clzll((long long)fills));
     if (n == 0u) return 0u;
+    // the word behind the last FILL seen: where the caller points its window prefetch (if fewer fills fit, the prefetch
+    // is simply not used)
+    after_batch = win_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pos, 63 - __clzll((long long)fills))) + 4u;
     wave_lds_sync();
     if (lane < n) {
         const bool eo = (my_rule_n & 1u) != 0u;
@@ -1246,6 +1249,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     uint32_t pre_seg_data = ~0u;
     uint32_t batch_n = 0u, batch_pos = 0u;  // MSAA: fills staged by ms_build_batch / already consumed
     bool samples_clean = false;             // MSAA: the sample counters hold their cleared (non-zero rule) value
+    uint32_t pf_win = 0u, pf_base = 0xffffffffu;  // MSAA: the command window requested ahead for the next batch
     for (;;) {
         ensure(cmd_ix, 4u);
         const uint32_t tag = rd(cmd_ix);
@@ -1272,15 +1276,27 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                 fill_path_area(sh, segments, fill, lane, area, first);
             } else {
                 if (batch_pos == batch_n) {
-                    // the scan wants to see as far ahead as possible: restart the window at this command
+                    // the scan wants to see as far ahead as possible: a window that starts at (or a draw command in front
+                    // of) this command -- the one requested when the previous batch was staged, if the list went on there
                     if (cmd_ix != win_base) {
-                        win_base = cmd_ix;
-                        uint32_t a = win_base + lane;
-                        win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+                        if (pf_base != 0xffffffffu && cmd_ix >= pf_base && cmd_ix - pf_base <= 8u) {
+                            win = pf_win;
+                            win_base = pf_base;
+                        } else {
+                            win_base = cmd_ix;
+                            uint32_t a = win_base + lane;
+                            win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+                        }
                     }
+                    uint32_t after_batch = 0xffffffffu;
                     batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane));
+                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch));
                     batch_pos = 0u;
+                    pf_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_batch);
+                    if (pf_base != 0xffffffffu) {
+                        const uint32_t a = pf_base + lane;
+                        pf_win = a < cfg.ptcl_size ? ptcl[a] : 0u;  // arrives while the batch's fills are replayed
+                    }
                 }
                 if (batch_n != 0u) {
                     ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area, samples_clean);
