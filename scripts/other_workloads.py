@@ -7,7 +7,7 @@ import numpy as np, torch
 import vello_amd, workloads
 from vello_amd import AaConfig
 
-def run(name, packed, layout, w, h, aa, resolved=None, nif=6, n=200):
+def run(name, packed, layout, w, h, aa, resolved=None, nif=4, n=200):
     eng = vello_amd.Engine()
     eng.set_frames_in_flight(nif)
     if resolved is not None:

@@ -286,10 +286,15 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
     const uint32_t lane = threadIdx.x & 63u, slice = threadIdx.x >> 6;
     const uint32_t n_obj = cfg.layout.n_draw_objects;
     for (uint32_t group = blockIdx.x; group * 4u < n_obj; group += gridDim.x) {
+      // the group's four Path records are requested together (one round trip, not four in a row)
+      Path group_paths[4];
+#pragma unroll
+      for (uint32_t p = 0; p < 4u; p++) group_paths[p] = load_path(paths, minu(group * 4u + p, n_obj - 1u));
+#pragma unroll
       for (uint32_t p = 0; p < 4u; p++) {
         const uint32_t drawobj_ix = group * 4u + p;
         if (drawobj_ix >= n_obj) break;
-        const Path path = paths[drawobj_ix];
+        const Path path = group_paths[p];
         const uint32_t width = path.bbox[2] - path.bbox[0], height = path.bbox[3] - path.bbox[1];
         if (width <= 1u) continue;  // (a row of one tile is its own prefix)
         const uint32_t block_rows = maxu(1u, BACKDROP_BLOCK_TILES / width);
