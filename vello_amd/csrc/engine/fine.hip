@@ -657,7 +657,15 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         clean = true;
         wave_lds_sync();
     }
-    for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], false, sh.winding, sh_samples);
+    // (a fill of <= 64 crossings -- nearly all of them -- keeps its record in a register through the three passes)
+    const bool one_round = end - begin <= 64u;
+    uint32_t rec0 = 0u;
+    if (one_round) {
+        if (begin + lane < end) rec0 = bt.item[begin + lane];
+        ms_apply<AA>(rec0, false, sh.winding, sh_samples);  // (a zero record does nothing)
+    } else {
+        for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], false, sh.winding, sh_samples);
+    }
     wave_lds_sync();
     // winding prefix sums exactly as ms_resolve; the row counters go back to their cleared value as they are read
     const uint32_t lx = lane & 3u, ly = lane >> 2;
@@ -691,7 +699,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     wave_lds_sync();
     for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
         const uint32_t i = i0 + lane;
-        const uint32_t rec = i < end ? bt.item[i] : 0u;
+        const uint32_t rec = one_round ? rec0 : (i < end ? bt.item[i] : 0u);
         if (rec & REC_PIX_VALID) {
             const uint32_t pix_ix = rec & 0xffu;
             const uint32_t e = sh.px.expected_zero[pix_ix];
@@ -704,7 +712,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     wave_lds_sync();
     for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
         const uint32_t i = i0 + lane;
-        const uint32_t rec = i < end ? bt.item[i] : 0u;
+        const uint32_t rec = one_round ? rec0 : (i < end ? bt.item[i] : 0u);
         if (rec & REC_PIX_VALID) {
             const uint32_t pix_ix = rec & 0xffu;
             const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
