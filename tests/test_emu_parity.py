@@ -786,3 +786,61 @@ def test_emu_fill_rules_interleaved_in_one_tile(emu_engine, seed):
     packed, layout = _fill_rule_interleave_scene(seed)
     for aa in (AaConfig.Msaa8, AaConfig.Msaa16):
         compare_frame(emu_engine, packed, layout, 32, 32, 0xFF203040, aa, f"emu_rules_{seed}_{int(aa)}", order_sensitive=True)
+
+
+def _stroke_kernel_cases():
+    """(name, packed, layout, w, h) of the stroke-heavy scenes: flatten's stroked-line kernel normally takes over from
+    393 216 stroked lines, VELLO_HIP_DEBUG_STROKE_KERNEL runs it for these."""
+    import math
+
+    from vello_amd import Affine, BezPath, Cap, Color, Join, Scene, Stroke
+
+    out = []
+    s = workloads.stroke_styles_scene()
+    out.append(("stroke_styles", *s.resolve(), 256, 256))
+    for which in ("tricky_strokes", "robust_paths"):
+        scene, w, h = getattr(workloads, which + "_scene")()
+        out.append((which, *scene.resolve(), w, h))
+    for name, t in (("ref_identity", None), ("ref_skew", Affine.skew(1.0, 0.0)), ("ref_non_uniform", Affine.scale_non_uniform(1.2, 0.7))):
+        scene, w, h = workloads.ref_stroke_styles_scene(t)
+        out.append((name, *scene.resolve(), w, h))
+    # polylines with every join / cap, closed and open, zero-length and sub-ULP segments (those are handed on to the heavy kernel),
+    # hairlines and a width far larger than the segments
+    rng = np.random.default_rng(5)
+    s = Scene()
+    for k in range(60):
+        p = BezPath()
+        x, y = rng.uniform(8, 120, 2)
+        p.move_to((x, y))
+        for i in range(int(rng.integers(1, 14))):
+            r = rng.random()
+            if r < 0.08:
+                pass  # zero-length segment
+            elif r < 0.14:
+                x, y = x + float(rng.choice([1e-7, -3e-6, 2e-5])), y
+            else:
+                a = rng.uniform(0, 2 * math.pi)
+                d = float(rng.choice([0.3, 2.0, 9.0, 30.0]))
+                x, y = x + d * math.cos(a), y + d * math.sin(a)
+            p.line_to((x, y))
+        if rng.random() < 0.4:
+            p.close_path()
+        st = Stroke(float(rng.choice([0.0, 0.05, 1.0, 3.5, 24.0])))
+        st = st.with_join([Join.Bevel, Join.Miter, Join.Round][int(rng.integers(0, 3))]).with_caps([Cap.Butt, Cap.Square, Cap.Round][int(rng.integers(0, 3))])
+        tr = Affine.IDENTITY if rng.random() < 0.6 else Affine.rotate(float(rng.uniform(0, 6))) * Affine.scale(float(rng.uniform(0.3, 2.5)))
+        s.stroke(st, Affine.translate(64.0, 64.0) * tr * Affine.translate(-64.0, -64.0), Color(float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), 0.5, 0.8), None, p)
+    out.append(("random_polylines", *s.resolve(), 128, 128))
+    return out
+
+
+@pytest.mark.parametrize("case", range(7))
+def test_emu_stroked_line_kernel(emu_engine, case):
+    name, packed, layout, w, h = _stroke_kernel_cases()[case]
+    emu_engine.set_debug_flags(stroke_kernel=True)
+    emu_engine.set_auto_grow(True)
+    try:
+        for aa in (AaConfig.Area, AaConfig.Msaa16):
+            compare_frame(emu_engine, packed, layout, w, h, WHITE, aa, f"emu_strokekernel_{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+    finally:
+        emu_engine.set_debug_flags()
+        emu_engine.set_auto_grow(False)

@@ -650,3 +650,20 @@ def test_gpu_fill_rules_interleaved_in_one_tile(gpu_engine, seed):
     packed, layout = _fill_rule_interleave_scene(seed)
     for aa in (AaConfig.Msaa8, AaConfig.Msaa16):
         compare_frame(gpu_engine, packed, layout, 32, 32, 0xFF203040, aa, f"gpu_rules_{seed}_{int(aa)}", order_sensitive=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(7))
+def test_gpu_stroked_line_kernel(gpu_engine, case):
+    # flatten's stroked-line kernel (normally from 393 216 stroked lines on: the d2 scene) forced on the stroke catalogue
+    from tests.test_emu_parity import _stroke_kernel_cases
+
+    name, packed, layout, w, h = _stroke_kernel_cases()[case]
+    gpu_engine.set_debug_flags(stroke_kernel=True)
+    gpu_engine.set_auto_grow(True)
+    try:
+        for aa in (AaConfig.Area, AaConfig.Msaa16):
+            compare_frame(gpu_engine, packed, layout, w, h, 0xFFFFFFFF, aa, f"gpu_strokekernel_{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+    finally:
+        gpu_engine.set_debug_flags()
+        gpu_engine.set_auto_grow(False)

@@ -25,6 +25,9 @@ constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a 
 // every later stage that would index with those counts bails out, the frame reports VELLO_HIP_E_INVALID
 constexpr uint32_t FAILED_SCENE = 0x40000000u;
 constexpr uint32_t FINE_WORK_BUCKETS = 8;
+// Stroked lines get a kernel of their own (k_flatten_strokes) once they alone fill the chip twice over at its 12 waves per CU
+// (256 CUs x 12 x 64 lanes); below that they ride along in k_flatten_heavy, whose duration the curves set anyway.
+constexpr uint32_t FLATTEN_STROKE_KERNEL_MIN_LINES = 2u * 256u * 12u * 64u;
 // command words from which a tile counts as long: its wave raises its issue priority (s_setprio) in k_fine
 constexpr uint32_t FINE_HEAVY_WORDS = 384;
 
@@ -34,8 +37,8 @@ struct Control {
     Bump bump;              // must be first: VELLO_HIP_BUF_BUMP aliases it
     uint32_t ticket_pathtag;
     uint32_t ticket_draw;
-    uint32_t heavy_count[2];  // flatten: tags queued for k_flatten_heavy: [0] fill curves, [1] strokes
-    uint32_t pad[4];
+    uint32_t heavy_count[3];  // flatten: tags queued by k_flatten_light: [0] fill curves, [1] strokes, [2] stroked lines
+    uint32_t pad[3];
     uint32_t work_count[FINE_WORK_BUCKETS];  // coarse -> fine: tiles per bucket of command-list length (k_fine runs the long ones first)
     uint32_t pad2[16 - FINE_WORK_BUCKETS];
 };
@@ -78,6 +81,8 @@ struct Frame {
     uint32_t n_ramps;
     const uint32_t *atlas;  // RGBA8 image atlas (render.rs:160-203), atlas_w x atlas_h texels
     uint32_t atlas_w, atlas_h;
+    uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which k_flatten_strokes takes them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
+    bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that k_flatten_strokes would exit at once
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;

@@ -43,6 +43,10 @@ struct SceneSlot {
     size_t zero_bytes = 0;
     bool brushes = false;   // gradient / image / blurred-rect draw objects present (selects fine's specialisation)
     bool resident = false;
+    // stroked-line tags of the scene as k_flatten_light counted them in an earlier frame (-1: not known yet).  A property of
+    // the scene alone; lets the host leave out a k_flatten_strokes launch that would exit at once.
+    int64_t stroke_lines = -1;
+    uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
 };
 
 struct Lane {
@@ -62,6 +66,7 @@ struct Lane {
     };
     std::vector<EvPair> events;
     bool used = false;
+    uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
 };
 
 struct vello_hip_ctx {
@@ -293,6 +298,9 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.n_ramps = sc.n_ramps;
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
+    f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
+    f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
+    l.frame_generation = sc.generation;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
     f.atlas_w = c->atlas_w;
     f.atlas_h = c->atlas_h;
@@ -567,6 +575,8 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     // Which fine specialisation the scene needs: any draw tag other than COLOR / BEGIN_CLIP / END_CLIP / NOP
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
     sc.brushes = false;
+    sc.stroke_lines = -1;
+    sc.generation += 1u;
     {
         // The same pass checks what draw_leaf / clip_leaf will index with (shared/drawtag.wgsl:47-54: bit 0 = clip,
         // bits 2-4 = draw data words, bits 6-9 = info words).  WebGPU's robust buffer access absorbs an inconsistent
@@ -731,9 +741,15 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
 // overflowed the old pools (l.used) -- so a retry on another lane is not failed by the lane that overflowed.
 static int check_lane(vello_hip_ctx *c, Lane &l) {
     if (!l.used || !l.zero_region.ptr) return VELLO_HIP_OK;
+    Control ctl;
+    HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
     vello_hip_bump b;
-    HIP_TRY(c, hipMemcpy(&b, l.zero_region.ptr, sizeof b, hipMemcpyDeviceToHost));
-    if (b.failed == 0u) return VELLO_HIP_OK;
+    std::memcpy(&b, &ctl.bump, sizeof b);
+    if (b.failed == 0u) {
+        SceneSlot &sc = slot_of(c, l);
+        if (l.frame_generation == sc.generation) sc.stroke_lines = (int64_t)ctl.heavy_count[2];  // (flatten ran to its end)
+        return VELLO_HIP_OK;
+    }
     if ((b.failed & FAILED_SCENE) != 0u) {
         c->last_error = "the path tag stream needs more path data, transforms or styles than the scene buffer holds";
         return VELLO_HIP_E_INVALID;

@@ -799,7 +799,7 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 // other segment tag is queued for k_flatten_heavy, curves and strokes on separate lists so that its waves are
 // homogeneous (a wave mixing 8 cubics with 56 stroked lines runs the subdivision loop at 1/8 lane use).
 // Returns 0 = done, HEAVY_CURVE or HEAVY_STROKE.
-constexpr uint32_t HEAVY_CURVE = 1u, HEAVY_STROKE = 2u;
+constexpr uint32_t HEAVY_CURVE = 1u, HEAVY_STROKE = 2u, HEAVY_STROKE_LINE = 3u;
 __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                                   PathBbox *path_bboxes, uint32_t ix, uint32_t &path_ix_out) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
@@ -817,7 +817,8 @@ __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config 
         path_bboxes[path_ix].trans_ix = trans_ix;
     }
     if (seg_type == 0u) return 0u;
-    if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return HEAVY_STROKE;  // joins, caps, offset curves
+    // joins, caps, offset curves; stroked LINES (most of a map) are listed apart: they need no Euler spirals
+    if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return seg_type == PATH_TAG_LINETO ? HEAVY_STROKE_LINE : HEAVY_STROKE;
     const uint32_t *pd = scene + cfg.layout.path_data_base;
     Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
     CubicPoints pts = read_path_segment(pd, tag, false);
@@ -837,7 +838,8 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
                                                           Control *control, LineSoup *lines, uint32_t *heavy_list) {
     __shared__ FlattenShared<FLATTEN_BLOCK_TAGS> sh;  // at most one line per tag: never overflows
     __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];  // curves from the front, strokes from the back
-    __shared__ uint32_t sh_n_heavy[2], sh_heavy_base[2];
+    __shared__ uint32_t sh_lines[FLATTEN_BLOCK_TAGS];  // stroked lines
+    __shared__ uint32_t sh_n_heavy[3], sh_heavy_base[3];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
@@ -847,7 +849,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
-        sh_n_heavy[0] = sh_n_heavy[1] = 0u;
+        sh_n_heavy[0] = sh_n_heavy[1] = sh_n_heavy[2] = 0u;
     }
     __syncthreads();
     Bump *bump = &control->bump;
@@ -871,7 +873,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
         }
         // wave-aggregated appends to the workgroup's two heavy lists (tag order is kept inside a wave)
 #pragma unroll
-        for (uint32_t kind = 0; kind < 2u; kind++) {
+        for (uint32_t kind = 0; kind < 3u; kind++) {
             const unsigned long long hm = __ballot(heavy == kind + 1u);
             if (hm != 0ull) {
                 const int leader = __ffsll((long long)hm) - 1;
@@ -880,29 +882,133 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
                 wbase = (uint32_t)__shfl((int)wbase, leader);
                 if (heavy == kind + 1u) {
                     uint32_t pos = wbase + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
-                    sh_heavy[kind == 0u ? pos : FLATTEN_BLOCK_TAGS - 1u - pos] = ix;
+                    if (kind == 2u) sh_lines[pos] = ix;
+                    else sh_heavy[kind == 0u ? pos : FLATTEN_BLOCK_TAGS - 1u - pos] = ix;
                 }
             }
         }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
     }
     flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
-    if (tid < 2u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
+    if (tid < 3u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
     __syncthreads();
-    // curves fill heavy_list[0, n_tags), strokes heavy_list[n_tags, 2 n_tags)
+    // curves fill heavy_list[0, n_tags); strokes heavy_list[n_tags, 2 n_tags): curved ones (and the lines k_flatten_strokes
+    // hands on) from its front, stroked lines from its back
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
     for (uint32_t i = tid; i < sh_n_heavy[1]; i += 256u) heavy_list[n_tags + sh_heavy_base[1] + i] = sh_heavy[FLATTEN_BLOCK_TAGS - 1u - i];
+    for (uint32_t i = tid; i < sh_n_heavy[2]; i += 256u) heavy_list[2u * n_tags - 1u - (sh_heavy_base[2] + i)] = sh_lines[i];
+}
+
+// ---- stroked lines: flatten_tag's stroke branch without the Euler-spiral flattener ------------------------------
+// Same operations in the same order as flatten_tag -> flatten_euler's straight-segment shortcut -> draw_join / draw_cap.
+// Returns false (having emitted nothing) for a line flatten_euler would not take that shortcut for (degenerate, or offset
+// lines that fail the straight-segment test): the caller queues it for k_flatten_heavy.
+__device__ bool flatten_stroked_line(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix,
+                                     uint32_t &path_ix_out) {
+    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
+    const uint32_t path_ix = tag.monoid.path_ix;
+    path_ix_out = path_ix;
+    em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+    if ((tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u) return true;  // cap marker of a closed subpath: draws nothing (flatten.wgsl:797-807)
+    const uint32_t style_ix = tag.monoid.style_ix;
+    const uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
+    const uint32_t *pd = scene + cfg.layout.path_data_base;
+    const Xform transform = read_transform(scene, cfg.layout.transform_base, tag.monoid.trans_ix);
+    const CubicPoints pts = read_path_segment(pd, tag, true);
+    const float offset = 0.5f * __uint_as_float(scene[cfg.layout.style_base + style_ix + 1u]);
+    const float scale = 0.5f * (length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
+                                length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
+    // (false for a degenerate segment too: its chord is shorter than the test's lower bound)
+    if (!cubic_is_straight(pts.p0, pts.p1, pts.p2, pts.p3, scale, offset)) return false;
+    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
+    PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
+    CubicPoints npts = read_path_segment(pd, ntag, true);
+    bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
+    bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+    bool do_join = !n_is_marker || n_is_closed;
+    vec2 n_tangent = npts.p3 - npts.p0;
+    if (!n_is_marker) n_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
+    vec2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+    if (dot(tan_start, tan_start) < TANGENT_THRESH * TANGENT_THRESH) tan_start = v2(TANGENT_THRESH, 0.0f);
+    vec2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+    if (dot(tan_prev, tan_prev) < TANGENT_THRESH * TANGENT_THRESH) tan_prev = v2(TANGENT_THRESH, 0.0f);
+    vec2 tan_next = n_tangent;
+    if (dot(tan_next, tan_next) < TANGENT_THRESH * TANGENT_THRESH) tan_next = v2(TANGENT_THRESH, 0.0f);
+    vec2 n_start = normalize(v2(-tan_start.y, tan_start.x)) * offset;
+    vec2 offset_tangent = normalize(tan_prev) * offset;
+    vec2 n_prev = v2(-offset_tangent.y, offset_tangent.x);
+    vec2 tnn = normalize(tan_next) * offset;
+    vec2 n_next = v2(-tnn.y, tnn.x);
+    {
+        // the two offset lines (flatten_euler's shortcut with two_sided = true)
+        const uint32_t line_ix = em.alloc(2u);
+        em.write_xf(line_ix, path_ix, pts.p0 + n_start, pts.p3 + n_prev, transform);
+        em.write_xf(line_ix + 1u, path_ix, pts.p3 - n_prev, pts.p0 - n_start, transform);
+    }
+    if (do_join) draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+    else draw_cap(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev, offset_tangent, transform);
+    return true;
+}
+
+// Runs between k_flatten_light and k_flatten_heavy when the scene has enough stroked lines to occupy the chip on their own
+// (FLATTEN_STROKE_KERNEL_MIN_LINES): a thread per line at 3 waves per SIMD and 30 KB of staging, instead of the heavy
+// kernel's 2 waves per SIMD (256 VGPRs, 60 KB).  One frame at a time this is a little slower (the curves of the heavy
+// kernel no longer have the lines to overlap with: d2 flatten 145 -> 164 us); with frames in flight, which is what the
+// chip time is for, d2 gains 4 %.
+constexpr uint32_t FLATTEN_STROKE_LDS_LINES = 1536u;  // 30 KB per workgroup
+__global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                            const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                            Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines) {
+    __shared__ FlattenShared<FLATTEN_STROKE_LDS_LINES> sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_lines_q = control->heavy_count[2];  // final: written by k_flatten_light
+    if (n_lines_q < min_lines) return;  // k_flatten_heavy takes them
+    if (blockIdx.x * 256u >= n_lines_q || (control->bump.failed & FAILED_SCENE) != 0u) return;
+    if (tid == 0u) {
+        sh.count = 0u;
+        sh.lds_end = 0xffffffffu;
+    }
+    __syncthreads();
+    Bump *bump = &control->bump;
+    const uint32_t lane = tid & 63u;
+#pragma unroll 1
+    for (uint32_t base = blockIdx.x * 256u; base < n_lines_q; base += gridDim.x * 256u) {
+        Emitter em;
+        em.lines = lines;
+        em.lines_size = cfg.lines_size;
+        em.bump = bump;
+        em.bind(sh);
+        uint32_t key = 0xffffffffu;
+        float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
+        const uint32_t e = base + tid;
+        bool hand_on = false;
+        uint32_t tag_ix = 0u;
+        if (e < n_lines_q) {
+            tag_ix = heavy_list[2u * n_tags - 1u - e];
+            hand_on = !flatten_stroked_line(em, cfg, scene, tag_monoids, tag_ix, key);
+            if (hand_on) key = 0xffffffffu;
+            else if (em.bx1 > em.bx0 || em.by1 > em.by0) {
+                x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
+            }
+        }
+        if (hand_on) heavy_list[n_tags + atomicAdd(&control->heavy_count[1], 1u)] = tag_ix;  // (rare: one atomic each is fine)
+        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
+        flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
+    }
 }
 
 // ---- heavy kernel: curves that need subdivision and everything stroked ----------------------------------------
 constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
 __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list) {
+                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
+                                                          uint32_t stroke_kernel_min_lines) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
     const uint32_t tid = threadIdx.x;
     // final counts: written by the previous kernel on this stream
-    const uint32_t n_curves = control->heavy_count[0], n_heavy = n_curves + control->heavy_count[1];
+    const uint32_t n_curves = control->heavy_count[0], n_strokes = control->heavy_count[1];
+    const uint32_t n_lines_q = control->heavy_count[2] < stroke_kernel_min_lines ? control->heavy_count[2] : 0u;  // else k_flatten_strokes' work
+    const uint32_t n_heavy = n_curves + n_strokes + n_lines_q;
     // Lanes of a wave walk DIFFERENT subdivision trees, so a wave executes the union of its lanes' loops: as long as the
     // launch has more waves than the list has entries to fill them, every wave takes only as many entries as it must
     // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
@@ -931,7 +1037,9 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
         const uint32_t e = base + wave * lpw + lane;
         if (lane < lpw && e < n_heavy) {
-            const uint32_t tag_ix = e < n_curves ? heavy_list[e] : heavy_list[n_tags + (e - n_curves)];
+            const uint32_t tag_ix = e < n_curves               ? heavy_list[e]
+                                    : e < n_curves + n_strokes ? heavy_list[n_tags + (e - n_curves)]
+                                                               : heavy_list[2u * n_tags - 1u - (e - n_curves - n_strokes)];
             key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
@@ -958,8 +1066,15 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     uint32_t grid_heavy = (n_seg_max + 3u) / 4u;
     if (grid_heavy > 2048u) grid_heavy = 2048u;
     if (grid_heavy < 4u) grid_heavy = 4u;
+    // (exits at once when the scene has too few stroked lines for a kernel of their own)
+    uint32_t grid_strokes = (n_seg_max + 255u) / 256u;
+    if (grid_strokes > 4096u) grid_strokes = 4096u;
+    if (grid_strokes < 1u) grid_strokes = 1u;
+    if (f.launch_stroke_kernel)
+        hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
+                       f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines);
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                       f.lines, f.heavy_list);
+                       f.lines, f.heavy_list, f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu);  // (not launched: every line is the heavy kernel's)
 }
 
 }  // namespace vk

@@ -209,9 +209,10 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False):
-        """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments)."""
-        self._check(self._lib.vello_hip_set_debug_flags(self._h, 1 if no_cull else 0), "set_debug_flags")
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False):
+        """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
+        runs flatten's stroked-line kernel whatever the number of stroked lines."""
+        self._check(self._lib.vello_hip_set_debug_flags(self._h, (1 if no_cull else 0) | (2 if stroke_kernel else 0)), "set_debug_flags")
 
     def last_render_attempts(self):
         return int(self._lib.vello_hip_last_render_attempts(self._h))
