@@ -830,10 +830,21 @@ def _stroke_kernel_cases():
         tr = Affine.IDENTITY if rng.random() < 0.6 else Affine.rotate(float(rng.uniform(0, 6))) * Affine.scale(float(rng.uniform(0.3, 2.5)))
         s.stroke(st, Affine.translate(64.0, 64.0) * tr * Affine.translate(-64.0, -64.0), Color(float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), 0.5, 0.8), None, p)
     out.append(("random_polylines", *s.resolve(), 128, 128))
+    # nothing but sub-micro-pixel and zero-length stroked segments: every one of them is handed on to the heavy kernel's list
+    s = Scene()
+    for k in range(40):
+        p = BezPath()
+        x, y = rng.uniform(8, 56, 2)
+        p.move_to((x, y))
+        for i in range(12):
+            x += float(rng.choice([0.0, 1e-7, -1e-7]))
+            p.line_to((x, y))
+        s.stroke(Stroke(float(rng.choice([1.0, 6.0]))).with_caps(Cap.Round), Affine.IDENTITY, Color(0.2, 0.5, float(rng.uniform(0, 1)), 1.0), None, p)
+    out.append(("all_handed_on", *s.resolve(), 64, 64))
     return out
 
 
-@pytest.mark.parametrize("case", range(7))
+@pytest.mark.parametrize("case", range(8))
 def test_emu_stroked_line_kernel(emu_engine, case):
     name, packed, layout, w, h = _stroke_kernel_cases()[case]
     emu_engine.set_debug_flags(stroke_kernel=True)

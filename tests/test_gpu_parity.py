@@ -653,7 +653,7 @@ def test_gpu_fill_rules_interleaved_in_one_tile(gpu_engine, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", range(7))
+@pytest.mark.parametrize("case", range(8))
 def test_gpu_stroked_line_kernel(gpu_engine, case):
     # flatten's stroked-line kernel (normally from 393 216 stroked lines on: the d2 scene) forced on the stroke catalogue
     from tests.test_emu_parity import _stroke_kernel_cases

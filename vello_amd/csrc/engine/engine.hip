@@ -174,7 +174,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
     if ((r = ensure(c, l.coarse_el, (size_t)(L.n_draw_objects + 1u) * sizeof(CoarseEl)))) return r;
-    if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 32u))) return r;  // 2 lists x 4 tags per word x u32
+    if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 48u))) return r;  // 3 lists x 4 tags per word x u32
     return 0;
 }
 

@@ -892,11 +892,11 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     if (tid < 3u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
     __syncthreads();
-    // curves fill heavy_list[0, n_tags); strokes heavy_list[n_tags, 2 n_tags): curved ones (and the lines k_flatten_strokes
-    // hands on) from its front, stroked lines from its back
+    // curves fill heavy_list[0, n_tags), strokes [n_tags, 2 n_tags) (k_flatten_strokes appends the lines it hands on there),
+    // stroked lines [2 n_tags, 3 n_tags)
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
     for (uint32_t i = tid; i < sh_n_heavy[1]; i += 256u) heavy_list[n_tags + sh_heavy_base[1] + i] = sh_heavy[FLATTEN_BLOCK_TAGS - 1u - i];
-    for (uint32_t i = tid; i < sh_n_heavy[2]; i += 256u) heavy_list[2u * n_tags - 1u - (sh_heavy_base[2] + i)] = sh_lines[i];
+    for (uint32_t i = tid; i < sh_n_heavy[2]; i += 256u) heavy_list[2u * n_tags + sh_heavy_base[2] + i] = sh_lines[i];
 }
 
 // ---- stroked lines: flatten_tag's stroke branch without the Euler-spiral flattener ------------------------------
@@ -984,7 +984,7 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
         bool hand_on = false;
         uint32_t tag_ix = 0u;
         if (e < n_lines_q) {
-            tag_ix = heavy_list[2u * n_tags - 1u - e];
+            tag_ix = heavy_list[2u * n_tags + e];
             hand_on = !flatten_stroked_line(em, cfg, scene, tag_monoids, tag_ix, key);
             if (hand_on) key = 0xffffffffu;
             else if (em.bx1 > em.bx0 || em.by1 > em.by0) {
@@ -1039,7 +1039,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         if (lane < lpw && e < n_heavy) {
             const uint32_t tag_ix = e < n_curves               ? heavy_list[e]
                                     : e < n_curves + n_strokes ? heavy_list[n_tags + (e - n_curves)]
-                                                               : heavy_list[2u * n_tags - 1u - (e - n_curves - n_strokes)];
+                                                               : heavy_list[2u * n_tags + (e - n_curves - n_strokes)];
             key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
