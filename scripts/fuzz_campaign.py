@@ -5,6 +5,8 @@ test suites carry.  Prints the failing seeds only.
     python scripts/fuzz_campaign.py sizes    LO HI     awkward target sizes, up to 700 operations per scene
     python scripts/fuzz_campaign.py pools    LO HI     every pool started at 64 elements, auto-grow
     python scripts/fuzz_campaign.py extreme  LO HI     12 % of the points from {+-1e6 ... +-3e38, +-inf, NaN}
+    FUZZ_GPU=1 ...             the product library on the GPU instead of the emulator build
+    FUZZ_STROKE_KERNEL=1 ...   with flatten's stroked-line kernel forced on (VELLO_HIP_DEBUG_STROKE_KERNEL)
 
 Round 1 ran api 0-43500, sizes 0-6000, pools 0-4000, extreme 0-358 (some extreme seeds emit tens of millions of lines and take
 minutes each on the emulator) (see DESIGN.md section 4 for what they found).
@@ -18,7 +20,10 @@ sys.path.insert(0, ROOT)
 import vello_amd  # noqa: E402
 import vello_amd._lib as L  # noqa: E402
 
-L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
+ON_GPU = os.environ.get("FUZZ_GPU") == "1"              # the product library on a real MI355X instead of the emulator build
+STROKE_KERNEL = os.environ.get("FUZZ_STROKE_KERNEL") == "1"  # VELLO_HIP_DEBUG_STROKE_KERNEL: flatten's stroked-line kernel for every scene
+if not ON_GPU:
+    L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
 from oracle.oracle import Oracle  # noqa: E402
 from tests.parity import compare_frame  # noqa: E402
 from vello_amd import AaConfig  # noqa: E402
@@ -40,13 +45,15 @@ def one(mode, seed, eng):
     elif mode == "pools":
         eng = vello_amd.Engine(capacities=TINY)
         eng.set_auto_grow(True)
+        eng.set_debug_flags(stroke_kernel=STROKE_KERNEL)
         w, h = [(128, 128), (300, 200), (64, 64)][seed % 3]
         scene = fuzz_scene(seed, size=max(w, h), n_ops=[40, 300][seed % 2])
         aa, base, kw = AAS[(seed // 2) % 3], 0xFF203040, {}
     elif mode == "extreme":
         w = h = 128
         scene, aa, base = fuzz_scene(seed, n_ops=14, extreme=True), AAS[seed % 3], 0xFF000000
-        kw = {"min_agree": None, "oracle": Oracle(capacity_scale=4)}  # (scenes that emit > 8 M lines overflow this oracle)
+        # (scenes that emit > 8 M lines overflow this oracle; crossing indices beyond 16 bits collide in the slot diff of the back half)
+        kw = {"min_agree": None, "oracle": Oracle(capacity_scale=4), "back_half": False}
     else:
         raise SystemExit(__doc__)
     r = vello_amd.Resolver().resolve(scene)
@@ -60,6 +67,7 @@ def main():
     mode, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     eng = vello_amd.Engine()
     eng.set_auto_grow(True)
+    eng.set_debug_flags(stroke_kernel=STROKE_KERNEL)
     bad, t0 = [], time.time()
     for seed in range(lo, hi):
         try:
