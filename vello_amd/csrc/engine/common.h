@@ -119,7 +119,12 @@ __device__ __forceinline__ float atan2_cr(float y, float x) {
 }
 __device__ __forceinline__ float asin_cr(float x) { return (float)asin((double)x); }
 __device__ __forceinline__ float acos_cr(float x) { return (float)acos((double)x); }
-__device__ __forceinline__ float pow_cr(float x, float y) { return (float)pow((double)x, (double)y); }
+// (own fp64 kernel for the arguments the flattener produces -- a positive finite base, |y| <= 8: 115 instructions against
+// ocml's 253, same rounded-once contract, fp64_math.h; everything else goes to ocml)
+__device__ __forceinline__ float pow_cr(float x, float y) {
+    if (x > 0.0f && x < __builtin_inff() && fabsf(y) <= 8.0f) return (float)f64::pow_pos((double)x, (double)y);
+    return (float)pow((double)x, (double)y);
+}
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
 __device__ __forceinline__ uint32_t f2u(float f) {

@@ -733,6 +733,12 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
     uint32_t n = c->n_active;
     Lane &l = c->lanes[(c->last_lane + n - age) % n];
     HIP_TRY(c, hipStreamSynchronize(l.stream));
+    // (once per scene: what flatten counted, so that later frames can leave out a launch that would exit at once)
+    if (l.used && l.zero_region.ptr && slot_of(c, l).stroke_lines < 0 && l.frame_generation == slot_of(c, l).generation) {
+        Control ctl;
+        HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
+        if (ctl.bump.failed == 0u) slot_of(c, l).stroke_lines = (int64_t)ctl.heavy_count[2];
+    }
     return VELLO_HIP_OK;
 }
 

@@ -58,5 +58,69 @@ __device__ __forceinline__ void sincos_medium(double x, double &s, double &c) {
     c = ((q + 1) & 2) ? -ca : ca;
 }
 
+// x^y for a finite x > 0 that came from an f32 (24 significant bits, any f32 exponent incl. denormals) and an f32-valued
+// exponent with |y| <= 8: what the flattener's inverse-integral needs (|u|^(2/3) with the f32 constant 2/3) under the same
+// contract as above -- the fp64 value, rounded ONCE to f32 by the caller, differs from libm's only when the exact value
+// lies within ~2^-55 (relative) of an f32 rounding boundary.  ocml's pow is 253 instructions (double-double log and exp
+// for any argument); this is ~115:
+//   x = 2^e m, m in [sqrt(1/2), sqrt(2));  z = (m - 1) / (m + 1) as z_hi + z_lo (the residual by ONE exact fma: m - 1 and
+//   m + 1 are exact for a 24-bit m);  ln m = 2 z_hi + [2 z_lo + z^3 P(z^2)], P the atanh series to z^22 (|z| <= 0.1716:
+//   the bracket is < 0.006, so plain fp64 leaves it 2^-60 absolute);  log2 m as a double-double product with log2(e);
+//   E = y (e + log2 m) with the rounding of the sum recovered (two-sum);  2^E = 2^k exp(f ln 2), |f| <= 1/2, degree-13.
+__device__ inline __attribute__((noinline)) double pow_pos(double x, double y) {
+    // exponent and mantissa (x is a normal double: an f32 denormal is one too)
+    long long bits = __double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff) - 1023;
+    double m = __longlong_as_double((bits & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+    if (m >= 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double num = m - 1.0, den = m + 1.0;
+    const double rcp = 1.0 / den;
+    const double z_hi = num * rcp;
+    const double z_lo = fma(-z_hi, den, num) * rcp;
+    const double w = z_hi * z_hi;
+    double P = fma(w, 2.0 / 23.0, 2.0 / 21.0);
+    P = fma(w, P, 2.0 / 19.0);
+    P = fma(w, P, 2.0 / 17.0);
+    P = fma(w, P, 2.0 / 15.0);
+    P = fma(w, P, 2.0 / 13.0);
+    P = fma(w, P, 2.0 / 11.0);
+    P = fma(w, P, 2.0 / 9.0);
+    P = fma(w, P, 2.0 / 7.0);
+    P = fma(w, P, 2.0 / 5.0);
+    P = fma(w, P, 2.0 / 3.0);
+    const double H = 2.0 * z_hi;                          // ln m = H + T
+    const double T = fma(z_hi * w, P, 2.0 * z_lo);
+    constexpr double L2E_HI = 1.4426950408889634074, L2E_LO = 2.0355273740931033e-17;  // log2(e) = hi + lo
+    const double p_hi = H * L2E_HI;
+    const double p_lo = fma(H, L2E_HI, -p_hi) + fma(H, L2E_LO, T * L2E_HI);
+    // E = y * (e + p_hi + p_lo): y * e is exact (24 x 11 bits)
+    const double A = y * (double)e;
+    const double B_hi = y * p_hi;
+    const double B_lo = fma(y, p_hi, -B_hi) + y * p_lo;
+    const double S = A + B_hi;
+    const double bb = S - A;
+    const double S_err = (A - (S - bb)) + (B_hi - bb);    // two-sum
+    const double E_lo = S_err + B_lo;
+    const double k = rint(S);
+    const double f = (S - k) + E_lo;                      // |f| <= 1/2 (+ a hair)
+    const double g = f * 6.93147180559945286227e-01;
+    double q = fma(g, 1.6059043836821613e-10, 2.08767569878681e-09);   // 1/13!, 1/12!
+    q = fma(g, q, 2.505210838544172e-08);
+    q = fma(g, q, 2.755731922398589e-07);
+    q = fma(g, q, 2.7557319223985893e-06);
+    q = fma(g, q, 2.48015873015873e-05);
+    q = fma(g, q, 1.984126984126984e-04);
+    q = fma(g, q, 1.388888888888889e-03);
+    q = fma(g, q, 8.333333333333333e-03);
+    q = fma(g, q, 4.1666666666666664e-02);
+    q = fma(g, q, 1.6666666666666666e-01);
+    q = fma(g, q, 0.5);
+    const double r = fma(g * g, q, g) + 1.0;              // exp(g) = 1 + g + g^2 q
+    return ldexp(r, (int)k);
+}
+
 }  // namespace f64
 }  // namespace vk
