@@ -160,6 +160,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     ring = [torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.uint8, device=dev) for _ in range(nif)]
     frame = ring[0]
     gathered = [torch.zeros_like(frame) for _ in range(world)] if (distributed and rank == 0) else None
+    torch.cuda.synchronize()  # torch's zero fills run on torch's stream, the frames on the engine's own
     steps = args.steps if timed_headline else max(20, args.steps // 2)
 
     def exchange(slot):

@@ -155,7 +155,9 @@ int vello_hip_upload_scene(vello_hip_ctx *ctx, const uint8_t *scene, size_t scen
 /* ... then each call enqueues one full frame (all stages) on the context's stream and returns
  * without waiting.  `out_device` may be NULL (render into the internal target only).  Resident frames ALWAYS show
  * the scene of the last vello_hip_upload_scene: scenes passed to vello_hip_render_frame are private to their frame
- * (VELLO_HIP_E_INVALID if no scene was ever uploaded). */
+ * (VELLO_HIP_E_INVALID if no scene was ever uploaded).  The frame runs on the context's own (non-blocking) stream
+ * (vello_hip_get_stream): work of the caller's streams on `out_device` -- clearing it, reading the previous frame -- has
+ * to be finished or ordered against that stream by the caller, as with any wgpu texture shared between queues. */
 int vello_hip_render_resident(vello_hip_ctx *ctx, const vello_hip_render_params *params, void *out_device, size_t out_stride);
 /* Animation form (every frame has its own scene): vello_hip_upload_scene + vello_hip_render_resident in one call
  * that does NOT wait for the frame.  The scene is copied into the private slot of the next in-flight buffer set

@@ -15,6 +15,7 @@ def run(name, packed, layout, w, h, aa, resolved=None, nif=4, n=200):
     else:
         eng.upload_scene(packed, layout)
     ring = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for _ in range(nif)]
+    torch.cuda.synchronize()
     for i in range(20):
         eng.render_resident(w, h, 0xFFFFFFFF, aa, out=ring[i % nif])
     assert eng.sync() == 0

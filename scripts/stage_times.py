@@ -10,7 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] != "A":
 from vello_amd import AaConfig
 def run(name, packed, layout, w, h, aa):
     eng = vello_amd.Engine(); eng.upload_scene(packed, layout)
-    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0")
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0"); torch.cuda.synchronize()
     for _ in range(5): eng.render_resident(w, h, 0xFFFFFFFF, aa, out=out); eng.sync_frame(0)
     eng.set_profiling(vello_amd.renderer.STAGES)
     for _ in range(30): eng.render_resident(w, h, 0xFFFFFFFF, aa, out=out); eng.sync_frame(0)

@@ -154,6 +154,7 @@ def test_renderer_api_render_to_texture(built):
     host = np.zeros((256, 256, 4), dtype=np.uint8)
     r.render_to_texture(scene, host, params)
     dev = torch.zeros((256, 256, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()  # (torch's zero fill runs on torch's stream, the engine on its own)
     r.render_to_texture(scene, dev, params)
     torch.cuda.synchronize()
     packed, layout = scene.resolve()
@@ -242,6 +243,7 @@ def test_frames_in_flight_match_oracle(built):
     eng.upload_scene(packed, layout)
     variants = [(384, 384, BLACK, AaConfig.Msaa16), (320, 256, WHITE, AaConfig.Msaa8), (384, 200, 0xFF204060, AaConfig.Msaa16)]
     targets = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for (w, h, _, _) in variants]
+    torch.cuda.synchronize()
     for rep in range(4):
         for (w, h, base, aa), t in zip(variants, targets):
             eng.render_resident(w, h, base, aa, out=t)
@@ -335,6 +337,7 @@ def test_render_frame_pipelines_scenes(built):
     eng.set_frames_in_flight(3)
     scenes = [workloads.random_test_scene(10 + k, n_paths=300, size=320.0, strokes=True, clips=(k % 2 == 1)).resolve() for k in range(3)]
     targets = [torch.zeros((320, 320, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+    torch.cuda.synchronize()
     for rep in range(3):
         for k in range(3):
             eng.render_frame(scenes[k][0], scenes[k][1], 320, 320, BLACK, AaConfig.Msaa16, out=targets[k])
@@ -623,18 +626,19 @@ def test_gather_frames_peer_copy(built):
 
     scenes = [workloads.stroke_styles_scene(), workloads.clip_blend_scene(), workloads.random_test_scene(5, n_paths=200, size=256.0)]
     engines, srcs, refs = [], [], []
+    dst = torch.zeros((3, 256, 256, 4), dtype=torch.uint8, device="cuda:0")
     for sc in scenes:
         packed, layout = sc.resolve()
         e = vello_amd.Engine(device=0)
         e.upload_scene(packed, layout)
         src = torch.zeros((256, 256, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()  # torch's zero fills (torch's stream) before the engine's streams touch the buffers
         e.render_resident(256, 256, BLACK, AaConfig.Msaa16, out=src)   # NOT waited for: the gather orders itself behind it
         o = Oracle()
         o.set_scene(packed, layout, 256, 256, BLACK, int(AaConfig.Msaa16))
         refs.append(o.render())
         engines.append(e)
         srcs.append(src)
-    dst = torch.zeros((3, 256, 256, 4), dtype=torch.uint8, device="cuda:0")
     gather_frames(engines, srcs, [dst[i] for i in range(3)], 256 * 256 * 4)
     out = dst.cpu().numpy()
     for i in range(3):
