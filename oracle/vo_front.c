@@ -671,7 +671,9 @@ void vo_stage_flatten(vo_ctx *c) {
         if ((tag.tag_byte & PATH_TAG_PATH) == 0u && seg_type == 0u) continue; /* nothing observable */
         uint32_t style_flags = c->scene[(uint32_t)(L->style_base + style_ix)];
         uint32_t draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
-        if ((tag.tag_byte & PATH_TAG_PATH) != 0u) {
+        /* resolve appends one PATH marker per unclosed layer behind the last counted path (resolve.rs:127-129): their
+         * stores land outside path_bboxes[n_paths], where WebGPU's robust buffer access drops them */
+        if ((tag.tag_byte & PATH_TAG_PATH) != 0u && path_ix < L->n_paths) {
             path_bboxes[path_ix].draw_flags = draw_flags;
             path_bboxes[path_ix].trans_ix = trans_ix;
         }
@@ -726,7 +728,7 @@ void vo_stage_flatten(vo_ctx *c) {
             } else {
                 flatten_euler(&st, &pts, path_ix, &transform, 0.0f, pts.p0, pts.p3);
             }
-            if (st.bbox[2] > st.bbox[0] || st.bbox[3] > st.bbox[1]) {
+            if ((st.bbox[2] > st.bbox[0] || st.bbox[3] > st.bbox[1]) && path_ix < L->n_paths) {
                 vo_path_bbox *out = &path_bboxes[path_ix];
                 atomic_min_i32(&out->x0, f2i(floorf(st.bbox[0])));
                 atomic_min_i32(&out->y0, f2i(floorf(st.bbox[1])));

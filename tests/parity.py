@@ -316,3 +316,76 @@ def compare_frame(engine, packed, layout, width, height, base_color, aa, name, t
             oracle.render()  # the same-order check overwrote the oracle's tiles / PTCL / segments with the engine's
         compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=ramps, ref=ref)
     return img, ref, bump
+
+
+def clip_ops_scene(ops, rng):
+    """A scene of nothing but clip layers: ops[i] > 0 pushes a layer clipped to a random rectangle, otherwise the innermost
+    open layer is popped (if there is one).  Layers still open at the end are closed by resolve (resolve.rs:127-141)."""
+    from vello_amd import Affine, Fill, Rect, Scene
+
+    s = Scene()
+    depth = 0
+    for o in ops:
+        if o > 0:
+            x0, y0 = rng.uniform(0, 200, 2)
+            w, h = rng.uniform(5, 300, 2)
+            s.push_clip_layer(Fill.NonZero, Affine.IDENTITY, Rect(x0, y0, x0 + w, y0 + h))
+            depth += 1
+        elif depth > 0:
+            s.pop_layer()
+            depth -= 1
+    return s
+
+
+def compare_clip_stage(engine, ops, rng, name, oracle=None):
+    """clip_reduce + clip_leaf alone (clip_reduce.wgsl:24-67, clip_leaf.wgsl:80-217): the front stages up to the clip stage run
+    on the engine -- once with its partitioned kernels, once with the one-wave stack machine (VELLO_HIP_DEBUG_SEQ_CLIP) -- and
+    on the oracle; clip_bboxes and the patched draw monoids must be equal word for word."""
+    from vello_amd import AaConfig
+
+    packed, layout = clip_ops_scene(ops, rng).resolve()
+    o = oracle or Oracle()
+    o.set_scene(packed, layout, 256, 256, 0xFF000000, int(AaConfig.Area))
+    o.run(0, 3)
+    ref_cb = o.buffer("clip_bboxes", np.float32)[: layout.n_clips * 4].copy()
+    ref_dm = o.buffer("draw_monoids", np.uint32)[: layout.n_draw_objects * 4].copy()
+    try:
+        for flags in (0, 4):
+            engine.set_debug_flags(flags)
+            engine.upload_scene(packed, layout)
+            engine.run_stages(256, 256, 0xFF000000, AaConfig.Area, 0, 3)
+            cb = engine.read_buffer("clip_bboxes", np.float32)[: layout.n_clips * 4]
+            dm = engine.read_buffer("draw_monoids", np.uint32)[: layout.n_draw_objects * 4]
+            bad = np.nonzero(cb != ref_cb)[0]
+            assert bad.size == 0, f"{name} (debug flags {flags}): clip_bboxes differ first at clip {bad[0] // 4}: {cb[bad[:4]]} vs {ref_cb[bad[:4]]}"
+            bad = np.nonzero(dm != ref_dm)[0]
+            assert bad.size == 0, f"{name} (debug flags {flags}): draw_monoids differ first at draw object {bad[0] // 4}"
+    finally:
+        engine.set_debug_flags(0)
+    return layout
+
+
+def clip_structures(big):
+    """(name, ops) pairs for compare_clip_stage: +1 pushes a clip layer, -1 pops.  The partitioned kernels cut the clip stream every
+    256 clips: runs, teeth and depths are chosen around that, the stack grows far beyond the 256 entries clip_leaf.wgsl:87-112 holds."""
+    yield "one", [1, -1]
+    yield "flat", [1, -1] * 300
+    yield "deep", [1] * 700 + [-1] * 700
+    yield "outer+flat", [1] * 300 + [1, -1] * 400 + [-1] * 300
+    yield "left open", [1] * 5 + [1, -1] * 200 + [1] * 600
+    for seed in range(12):
+        rng = np.random.default_rng(100 + seed)
+        n = int(rng.integers(1, 4000))
+        if seed % 4 == 0:
+            ops = np.where(rng.random(n) < rng.uniform(0.3, 0.7), 1, -1)
+        elif seed % 4 == 1:  # long runs
+            ops = np.repeat(np.where(rng.random(n // 50 + 1) < 0.5, 1, -1), rng.integers(1, 400, n // 50 + 1))[:n]
+        elif seed % 4 == 2:  # teeth around the partition size
+            ops = np.concatenate([[1] * int(rng.integers(200, 300)) + [-1] * int(rng.integers(100, 300)) for _ in range(n // 400 + 1)])
+        else:
+            ops = np.where(rng.random(n) < 0.5 + 0.3 * np.sin(np.arange(n) / 97.0), 1, -1)
+        yield f"random {seed}", list(ops)
+    if big:
+        yield "20 000 deep", [1] * 20000 + [-1] * 20000
+        n = 300000  # > 1024 partitions: two per thread in k_clip_stack
+        yield "300 000 clips", list(np.where(np.random.default_rng(5).random(n) < 0.5 + 0.2 * np.sin(np.arange(n) / 3001.0), 1, -1))

@@ -855,3 +855,12 @@ def test_emu_stroked_line_kernel(emu_engine, case):
     finally:
         emu_engine.set_debug_flags()
         emu_engine.set_auto_grow(False)
+
+
+def test_emu_clip_stage_partitioned(emu_engine):
+    # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip) and as the one-wave stack machine, against the oracle's stack
+    from tests.parity import clip_structures, compare_clip_stage
+
+    for name, ops in clip_structures(big=False):
+        compare_clip_stage(emu_engine, ops, np.random.default_rng(len(ops)), "emu clips " + name)
+    compare_clip_stage(emu_engine, [1] * 3000 + [1, -1] * 32000 + [-1] * 3000, np.random.default_rng(3), "emu clips 70 000")

@@ -671,3 +671,15 @@ def test_gpu_stroked_line_kernel(gpu_engine, case):
     finally:
         gpu_engine.set_debug_flags()
         gpu_engine.set_auto_grow(False)
+
+
+def test_clip_stage_partitioned(gpu_engine):
+    # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip: 256 clips per workgroup, one workgroup over the partitions, a
+    # second pass per partition) and as the one-wave stack machine, against the oracle's sequential stack; up to 300 000 clips and
+    # 20 000 open layers (the reference's kernels stop at 65 536 clips / 256 open layers, clip_leaf.wgsl:87-112)
+    from oracle.oracle import Oracle
+    from tests.parity import clip_structures, compare_clip_stage
+
+    oracle = Oracle()
+    for name, ops in clip_structures(big=True):
+        compare_clip_stage(gpu_engine, ops, np.random.default_rng(len(ops)), "gpu clips " + name, oracle=oracle)

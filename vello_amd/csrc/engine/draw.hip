@@ -328,8 +328,8 @@ void launch_draw_scan(const Frame &f, hipStream_t s) {
                        f.draw_monoids, f.info_bin_data, f.clip_inp);
 }
 
-void launch_clip(const Frame &f, hipStream_t s) {
-    if (f.cfg.layout.n_clips == 0) return;  // render.rs:368,379: clip dispatches are skipped when there are no clips
+void launch_clip_sequential(const Frame &f, hipStream_t s) {
+    if (f.cfg.layout.n_clips == 0) return;
     hipLaunchKernelGGL(k_clip, dim3(1), dim3(64), 0, s, f.cfg, f.clip_inp, f.path_bboxes, f.draw_monoids, f.clip_bboxes,
                        f.clip_stack);
 }

@@ -30,6 +30,24 @@ constexpr uint32_t FINE_WORK_BUCKETS = 8;
 constexpr uint32_t FLATTEN_STROKE_KERNEL_MIN_LINES = 2u * 256u * 12u * 64u;
 // command words from which a tile counts as long: its wave raises its issue priority (s_setprio) in k_fine
 constexpr uint32_t FINE_HEAVY_WORDS = 384;
+// clip matching (clip.hip): clips per partition (a thread each) and the most partitions the one-workgroup stack pass holds
+// in LDS; beyond CLIP_PART * CLIP_MAX_PARTS clips the one-wave stack machine (draw.hip) runs instead
+constexpr uint32_t CLIP_PART = 256;
+constexpr uint32_t CLIP_MAX_PARTS = 2048;
+struct ClipEl { uint32_t clip_ix; float x0, y0, x1, y1; };  // an open BeginClip: its index in clip_inp, its box ∩ its local ancestors'
+__host__ __device__ inline uint32_t clip_parts_pad(uint32_t parts) {  // leaves of the min-tree over the partitions
+    uint32_t n = 2u;
+    while (n < parts) n <<= 1;
+    return n;
+}
+// words of Frame::clip_stack: the sequential machine's spill area (6 words per clip) or the partitions' scratch
+// (open pushes, Bic, height, box below: 1287 words per partition; then the min-tree)
+inline size_t clip_scratch_words(uint32_t n_clips) {
+    size_t parts = (n_clips + CLIP_PART - 1u) / CLIP_PART;
+    size_t par = parts * (CLIP_PART * 5u + 4u + 2u + 1u) + 2u * (size_t)clip_parts_pad((uint32_t)parts);
+    size_t seq = ((size_t)n_clips + 1u) * 6u;
+    return par > seq ? par : seq;
+}
 
 // Words of the per-frame control block (zeroed by ONE hipMemsetAsync per frame, together with
 // the bump allocators and both look-back state arrays which follow it in the same allocation).
@@ -74,7 +92,7 @@ struct Frame {
     uint32_t *tile_bits;     // coarse: three bit planes over the tile pool (segments present / backdrop zero / backdrop even)
     uint32_t tile_bits_plane_words;
     uint32_t *tile_order;    // coarse -> fine: [bucket][n_tiles] tile indices, filled up to control->work_count[bucket]
-    uint32_t *clip_stack;  // spill area for clip stacks deeper than the LDS window
+    uint32_t *clip_stack;  // clip_scratch_words(n_clips): scratch of the partitioned clip kernels / spill area of the sequential one
     uint8_t *output;
     size_t out_stride;
     const uint32_t *ramps;
@@ -83,6 +101,7 @@ struct Frame {
     uint32_t atlas_w, atlas_h;
     uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which k_flatten_strokes takes them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that k_flatten_strokes would exit at once
+    bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;
@@ -93,7 +112,8 @@ struct Frame {
 void launch_pathtag_scan(const Frame &f, hipStream_t s);
 void launch_flatten(const Frame &f, hipStream_t s);
 void launch_draw_scan(const Frame &f, hipStream_t s);
-void launch_clip(const Frame &f, hipStream_t s);
+void launch_clip(const Frame &f, hipStream_t s);             // clip.hip
+void launch_clip_sequential(const Frame &f, hipStream_t s);  // draw.hip
 void launch_binning(const Frame &f, hipStream_t s);
 void launch_tile_alloc(const Frame &f, hipStream_t s);
 void launch_path_count(const Frame &f, hipStream_t s);

@@ -172,7 +172,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_CLIP_BBOXES], (size_t)(L.n_clips + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(Bbox4)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
-    if ((r = ensure(c, l.clip_stack, (size_t)(L.n_clips + 1u) * 24u))) return r;
+    if ((r = ensure(c, l.clip_stack, clip_scratch_words(L.n_clips) * 4u))) return r;
     if ((r = ensure(c, l.coarse_el, (size_t)(L.n_draw_objects + 1u) * sizeof(CoarseEl)))) return r;
     if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 48u))) return r;  // 3 lists x 4 tags per word x u32
     return 0;
@@ -298,6 +298,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.n_ramps = sc.n_ramps;
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
+    f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;
