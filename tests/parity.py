@@ -350,18 +350,18 @@ def compare_clip_stage(engine, ops, rng, name, oracle=None):
     ref_cb = o.buffer("clip_bboxes", np.float32)[: layout.n_clips * 4].copy()
     ref_dm = o.buffer("draw_monoids", np.uint32)[: layout.n_draw_objects * 4].copy()
     try:
-        for flags in (0, 4):
-            engine.set_debug_flags(flags)
+        for flags in ("partitioned kernels", "one-wave stack machine"):
+            engine.set_debug_flags(seq_clip=flags == "one-wave stack machine")
             engine.upload_scene(packed, layout)
             engine.run_stages(256, 256, 0xFF000000, AaConfig.Area, 0, 3)
             cb = engine.read_buffer("clip_bboxes", np.float32)[: layout.n_clips * 4]
             dm = engine.read_buffer("draw_monoids", np.uint32)[: layout.n_draw_objects * 4]
             bad = np.nonzero(cb != ref_cb)[0]
-            assert bad.size == 0, f"{name} (debug flags {flags}): clip_bboxes differ first at clip {bad[0] // 4}: {cb[bad[:4]]} vs {ref_cb[bad[:4]]}"
+            assert bad.size == 0, f"{name} ({flags}): clip_bboxes differ first at clip {bad[0] // 4}: {cb[bad[:4]]} vs {ref_cb[bad[:4]]}"
             bad = np.nonzero(dm != ref_dm)[0]
-            assert bad.size == 0, f"{name} (debug flags {flags}): draw_monoids differ first at draw object {bad[0] // 4}"
+            assert bad.size == 0, f"{name} ({flags}): draw_monoids differ first at draw object {bad[0] // 4}"
     finally:
-        engine.set_debug_flags(0)
+        engine.set_debug_flags()
     return layout
 
 

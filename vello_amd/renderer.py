@@ -209,10 +209,12 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False, stroke_kernel=False):
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False):
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
-        runs flatten's stroked-line kernel whatever the number of stroked lines."""
-        self._check(self._lib.vello_hip_set_debug_flags(self._h, (1 if no_cull else 0) | (2 if stroke_kernel else 0)), "set_debug_flags")
+        runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
+        stack machine instead of the partitioned kernels."""
+        flags = (1 if no_cull else 0) | (2 if stroke_kernel else 0) | (4 if seq_clip else 0)
+        self._check(self._lib.vello_hip_set_debug_flags(self._h, flags), "set_debug_flags")
 
     def last_render_attempts(self):
         return int(self._lib.vello_hip_last_render_attempts(self._h))
