@@ -173,7 +173,9 @@ int vello_hip_render_frame(vello_hip_ctx *ctx, const uint8_t *scene, size_t scen
  * the packing: it patches every DrawImage's atlas xy (resolve.rs:300-316) and lists the images to (re)write.
  * resize discards the contents (zero-filled), as creating a new ImageProxy does.  Texel bytes are stored
  * verbatim; BGRA / straight-alpha images are normalised while sampling (fine.wgsl:829-858).
- * Both calls wait for the frames in flight. */
+ * resize waits for the frames in flight.  write_image does not (wgpu's queue.write_texture is queued as well): it copies
+ * the caller's pixels to pinned memory during the call and enqueues the transfer in submission order -- behind every
+ * frame enqueued before it (they still sample the old texels), in front of every frame enqueued after it. */
 int vello_hip_resize_image_atlas(vello_hip_ctx *ctx, uint32_t width, uint32_t height);
 int vello_hip_write_image(vello_hip_ctx *ctx, uint32_t x, uint32_t y, uint32_t width, uint32_t height, const uint8_t *rgba8,
                           size_t stride /* bytes per source row; 0 = width*4 */);

@@ -864,3 +864,30 @@ def test_emu_clip_stage_partitioned(emu_engine):
     for name, ops in clip_structures(big=False):
         compare_clip_stage(emu_engine, ops, np.random.default_rng(len(ops)), "emu clips " + name)
     compare_clip_stage(emu_engine, [1] * 3000 + [1, -1] * 32000 + [-1] * 3000, np.random.default_rng(3), "emu clips 70 000")
+
+
+def test_emu_write_image_between_frames(emu_engine):
+    # host logic of the stream-ordered vello_hip_write_image (staging blocks, epochs): every frame shows the upload before it
+    import vello_amd
+    from vello_amd import Affine, ImageBrush, ImageData, ImageQuality, Scene
+
+    frames = [np.full((16, 16, 4), 255, dtype=np.uint8) for _ in range(6)]
+    for k, px in enumerate(frames):
+        px[:, :, 0] = 40 * k
+        px[k, :, 1] = 3
+    s = Scene()
+    s.draw_image(ImageBrush(ImageData(frames[0]), quality=ImageQuality.Low), Affine.translate(4.0, 4.0) * Affine.scale(2.0))
+    r = vello_amd.Resolver().resolve(s)
+    (x, y, _), = r.uploads
+    emu_engine.set_frames_in_flight(3)
+    try:
+        emu_engine.upload_resolved(r)
+        for k in range(6):
+            emu_engine.write_image(x, y, frames[k])
+            emu_engine.render_resident(48, 48, BLACK, AaConfig.Area)
+            emu_engine.sync_frame(0)
+            img = emu_engine.read_buffer("output", np.uint8, 48 * 48 * 4).reshape(48, 48, 4)
+            for ty in (0, k, 15):
+                assert tuple(img[4 + 2 * ty + 1, 4 + 2 * 7 + 1]) == tuple(frames[k][ty, 7]), (k, ty)
+    finally:
+        emu_engine.set_frames_in_flight(1)

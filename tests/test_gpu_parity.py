@@ -683,3 +683,38 @@ def test_clip_stage_partitioned(gpu_engine):
     oracle = Oracle()
     for name, ops in clip_structures(big=True):
         compare_clip_stage(gpu_engine, ops, np.random.default_rng(len(ops)), "gpu clips " + name, oracle=oracle)
+
+
+def test_write_image_is_ordered_with_frames_in_flight(built):
+    # vello_hip_write_image does not wait for the frames in flight: a "video texture" whose pixels change before every frame,
+    # four frames in flight, nothing waited for until the end -- frame k must show the k-th upload (not the one before it:
+    # the frame waits for the transfer; not the one after it: the transfer waits for the frames that still sample the atlas)
+    import torch
+    import vello_amd
+    from vello_amd import Affine, ImageBrush, ImageData, ImageQuality, Scene
+
+    n = 12
+    frames = [np.full((64, 64, 4), 255, dtype=np.uint8) for _ in range(n)]
+    for k, px in enumerate(frames):
+        px[:, :, 0] = 20 * k
+        px[:, :, 1] = 255 - 20 * k
+        px[k:k + 8, :, 2] = 7
+    s = Scene()
+    s.draw_image(ImageBrush(ImageData(frames[0]), quality=ImageQuality.Low), Affine.translate(8.0, 8.0) * Affine.scale(6.0))
+    r = vello_amd.Resolver().resolve(s)
+    (x, y, _), = r.uploads
+    eng = vello_amd.Engine()
+    eng.set_frames_in_flight(4)
+    eng.upload_resolved(r)
+    targets = [torch.zeros((400, 400, 4), dtype=torch.uint8, device="cuda:0") for _ in range(n)]
+    torch.cuda.synchronize()
+    for k in range(n):
+        eng.write_image(x, y, frames[k])
+        eng.render_resident(400, 400, BLACK, AaConfig.Msaa16, out=targets[k])
+    assert eng.sync() == 0
+    for k in range(n):
+        got = targets[k].cpu().numpy()
+        # texel (i, j) covers pixels 8 + 6 i .. 8 + 6 i + 5: sample the centres of a few texels
+        for ty in (0, k, k + 7, k + 8 if k + 8 < 64 else 0, 63):
+            for tx in (0, 31, 63):
+                assert tuple(got[8 + 6 * ty + 3, 8 + 6 * tx + 3]) == tuple(frames[k][ty, tx]), (k, ty, tx)

@@ -67,6 +67,16 @@ struct Lane {
     std::vector<EvPair> events;
     bool used = false;
     uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
+    uint64_t atlas_epoch_seen = 0;  // ctx::atlas_epoch the lane's stream has been ordered behind
+};
+
+// Pinned staging block of one vello_hip_write_image: the caller's pixels are copied here during the call, the DMA into the
+// atlas runs from it on the upload stream; free again once `done` has passed.
+struct Staging {
+    void *host = nullptr;
+    size_t size = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
 };
 
 struct vello_hip_ctx {
@@ -84,6 +94,13 @@ struct vello_hip_ctx {
     bool auto_grow = false;
     hipStream_t copy_stream = nullptr;  // vello_hip_gather_frames: this context's peer copy
     hipEvent_t frame_done = nullptr;
+    // vello_hip_write_image: atlas uploads are stream-ordered, not host-synchronous (wgpu's queue.write_texture is queued
+    // too, render.rs:160-203).  An upload waits for the frames enqueued before it (they may sample the texels it replaces)
+    // and every frame enqueued after it waits for `atlas_ready`.
+    hipStream_t upload_stream = nullptr;
+    hipEvent_t atlas_ready = nullptr, lane_mark = nullptr;
+    uint64_t atlas_epoch = 0;  // uploads enqueued so far
+    std::vector<Staging> staging;
     uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
     bool force_brushes = false;  // pre-warm: run fine's brush specialisation on a scene without brushes
     uint32_t last_render_attempts = 0;  // rounds the last vello_hip_render needed (robust mode)
@@ -134,6 +151,43 @@ hipEvent_t get_event(vello_hip_ctx *c) {
 int sync_all(vello_hip_ctx *c) {
     for (auto &l : c->lanes)
         if (l.stream) HIP_TRY(c, hipStreamSynchronize(l.stream));
+    return 0;
+}
+
+// waits for the atlas uploads still in flight (before the atlas is freed / resized / the context goes away)
+int sync_uploads(vello_hip_ctx *c) {
+    if (c->upload_stream) HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
+    for (auto &st : c->staging) st.busy = false;
+    return 0;
+}
+
+// a pinned block of >= bytes that no DMA is reading
+int acquire_staging(vello_hip_ctx *c, size_t bytes, Staging *&out) {
+    size_t held = 0;
+    for (auto &st : c->staging) {
+        if (st.busy && hipEventQuery(st.done) == hipSuccess) st.busy = false;
+        held += st.size;
+    }
+    for (auto &st : c->staging)
+        if (!st.busy && st.size >= bytes) {
+            out = &st;
+            return 0;
+        }
+    if (held > ((size_t)256 << 20)) {  // bound the pinned memory: drain and start over
+        int r = sync_uploads(c);
+        if (r) return r;
+        for (auto &st : c->staging) {
+            (void)hipHostFree(st.host);
+            (void)hipEventDestroy(st.done);
+        }
+        c->staging.clear();
+    }
+    Staging st;
+    st.size = bytes < ((size_t)1 << 16) ? ((size_t)1 << 16) : bytes;
+    HIP_TRY(c, hipHostMalloc(&st.host, st.size, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    c->staging.push_back(st);
+    out = &c->staging.back();
     return 0;
 }
 
@@ -307,6 +361,10 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.atlas_h = c->atlas_h;
     f.mask_lut8 = (const uint32_t *)c->mask8.ptr;
     f.mask_lut16 = (const uint32_t *)c->mask16.ptr;
+    if (l.atlas_epoch_seen != c->atlas_epoch) {  // atlas uploads enqueued since this lane's last frame come first
+        HIP_TRY(c, hipStreamWaitEvent(l.stream, c->atlas_ready, 0));
+        l.atlas_epoch_seen = c->atlas_epoch;
+    }
     l.used = true;
     return 0;
 }
@@ -516,6 +574,16 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->upload_stream) {
+        (void)hipStreamSynchronize(c->upload_stream);
+        for (auto &st : c->staging) {
+            (void)hipHostFree(st.host);
+            (void)hipEventDestroy(st.done);
+        }
+        (void)hipEventDestroy(c->atlas_ready);
+        (void)hipEventDestroy(c->lane_mark);
+        (void)hipStreamDestroy(c->upload_stream);
+    }
     if (c->frame_done) (void)hipEventDestroy(c->frame_done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (auto &l : c->lanes)
@@ -655,6 +723,7 @@ int vello_hip_resize_image_atlas(vello_hip_ctx *c, uint32_t width, uint32_t heig
     HIP_TRY(c, hipSetDevice(c->device));
     int r = sync_all(c);
     if (r) return r;
+    if ((r = sync_uploads(c))) return r;
     c->atlas_w = c->atlas_h = 0;
     if (width == 0 || height == 0) return VELLO_HIP_OK;
     size_t bytes = (size_t)width * height * 4u;
@@ -674,11 +743,31 @@ int vello_hip_write_image(vello_hip_ctx *c, uint32_t x, uint32_t y, uint32_t wid
     }
     if (width == 0 || height == 0) return VELLO_HIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
-    int r = sync_all(c);  // frames in flight sample the atlas
-    if (r) return r;
     if (stride == 0) stride = (size_t)width * 4u;
-    HIP_TRY(c, hipMemcpy2D((char *)c->atlas.ptr + ((size_t)y * c->atlas_w + x) * 4u, (size_t)c->atlas_w * 4u, rgba8, stride,
-                           (size_t)width * 4u, height, hipMemcpyHostToDevice));
+    if (!c->upload_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->atlas_ready, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->lane_mark, hipEventDisableTiming));
+    }
+    // the caller owns the pixels only for the duration of the call: into pinned memory now, DMA later
+    const size_t row_bytes = (size_t)width * 4u;
+    Staging *st = nullptr;
+    int r = acquire_staging(c, row_bytes * height, st);
+    if (r) return r;
+    for (uint32_t row = 0; row < height; row++) std::memcpy((char *)st->host + row * row_bytes, rgba8 + row * stride, row_bytes);
+    // frames already enqueued may sample the texels this upload replaces: it runs behind all of them
+    for (auto &l : c->lanes) {
+        if (!l.stream || !l.used) continue;
+        HIP_TRY(c, hipEventRecord(c->lane_mark, l.stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->upload_stream, c->lane_mark, 0));
+    }
+    HIP_TRY(c, hipMemcpy2DAsync((char *)c->atlas.ptr + ((size_t)y * c->atlas_w + x) * 4u, (size_t)c->atlas_w * 4u, st->host, row_bytes,
+                                row_bytes, height, hipMemcpyHostToDevice, c->upload_stream));
+    HIP_TRY(c, hipEventRecord(st->done, c->upload_stream));
+    st->busy = true;
+    // ... and every frame enqueued from here on runs behind it (prepare_frame)
+    HIP_TRY(c, hipEventRecord(c->atlas_ready, c->upload_stream));
+    c->atlas_epoch += 1u;
     return VELLO_HIP_OK;
 }
 
