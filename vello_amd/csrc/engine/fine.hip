@@ -23,6 +23,55 @@ constexpr uint32_t PIXELS_PER_THREAD = 4;
 constexpr int GRADIENT_WIDTH = 512;
 constexpr uint32_t LUMINANCE_MASK_LAYER = 0x10000u;
 
+// Measurement build only (make -C vello_amd/csrc EXTRA=-DVELLO_FINE_PROF, scripts/fine_prof.py): clock64 per phase of a
+// tile's wave, written to the tail of the blend-spill pool when the tile is done.  Without the macro FineProf is empty
+// and every mark() / count() is nothing: the product kernel's code is the same with or without these lines.
+enum {
+    FP_INTERP = 0,      // command decode, window loads, everything not listed below
+    FP_BATCH_SCAN,      // ms_build_batch: scan of the window, slots, segment addresses
+    FP_BATCH_SEGS,      // ... segment loads (the global round trip), setup, counts
+    FP_BATCH_ITEMS,     // ... one record per crossing (mask LUT loads)
+    FP_FILL_APPLY,      // ms_fill_from_batch: records -> counter atomics (incl. the slot's parameters from LDS)
+    FP_FILL_PREFIX,     // ... winding prefix sums, expected_zero, exchange through LDS
+    FP_FILL_SPARSE,     // ... one lane per record evaluates its pixel
+    FP_FILL_RESTORE,    // ... counters back to the cleared value, coverage picked up
+    FP_FILL_EVENODD,    // even-odd fills of a batch (dense path)
+    FP_FILL_UNBATCHED,  // fill_path_ms
+    FP_BLEND,           // CMD_COLOR src-over
+    FP_RARE,            // clip / brush commands
+    FP_N_FILLS, FP_N_BATCHES, FP_N_ITEMS, FP_N_WORDS,  // counts: fills, batches, crossing records, command words
+    FP_SLOTS
+};
+#ifdef VELLO_FINE_PROF
+struct FineProf {
+    uint32_t acc[FP_SLOTS];
+    long long prev;
+    __device__ __forceinline__ void start() {
+        for (int i = 0; i < FP_SLOTS; i++) acc[i] = 0u;
+        prev = clock64();
+    }
+    __device__ __forceinline__ void mark(int k) {
+        const long long t = clock64();
+        acc[k] += (uint32_t)(t - prev);
+        prev = t;
+    }
+    __device__ __forceinline__ void count(int k, uint32_t n) { acc[k] += n; }
+    __device__ __forceinline__ void store(uint32_t *blend_spill, uint32_t blend_size, uint32_t n_tiles, uint32_t tile_ix, uint32_t lane) {
+        if (blend_size < n_tiles * FP_SLOTS) return;
+        uint32_t *dst = blend_spill + (blend_size - n_tiles * FP_SLOTS) + tile_ix * FP_SLOTS;
+        if (lane == 0u)
+            for (int i = 0; i < FP_SLOTS; i++) dst[i] = acc[i];
+    }
+};
+#else
+struct FineProf {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void count(int, uint32_t) {}
+    __device__ __forceinline__ void store(uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t) {}
+};
+#endif
+
 struct vec4 {
     float x, y, z, w;
 };
@@ -464,7 +513,7 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
 template <int AA>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t lane, uint32_t &after_batch) {
+                                   uint32_t lane, uint32_t &after_batch, FineProf &pf) {
     // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
     // its hazard slots, cost 600+ issue slots per batch).  Lane i looks at word i as if a command started there:
     // next[i] = i + its size, stopping at END / JUMP / unknown tags and where a FILL's four words would leave the window.
@@ -550,6 +599,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     const uint32_t seg_start = (uint32_t)__shfl((int)my_seg_start, (int)slot);
     const uint32_t rule = (uint32_t)__shfl((int)my_rule_n, (int)slot);
     wave_lds_sync();
+    pf.mark(FP_BATCH_SCAN);
     uint32_t count = 0u;
     if (lane < tot_segs) {
         Segment sg = segments[seg_data + (lane - seg_start)];
@@ -575,6 +625,8 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     if (n_fit == 0u) return 0u;
     const uint32_t total = bt.item_end[n_fit];
     const uint32_t n_staged = tot_segs;
+    pf.mark(FP_BATCH_SEGS);
+    pf.count(FP_N_ITEMS, total);
     for (uint32_t i = lane; i < total; i += 64u) {
         const uint32_t el_ix = ms_find_segment(sh.count, n_staged, i);
         const bool last_pixel = i + 1u == sh.count[el_ix];
@@ -585,6 +637,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         bt.item[i] = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
     }
     wave_lds_sync();
+    pf.mark(FP_BATCH_ITEMS);
     return n_fit;
 }
 
@@ -634,7 +687,7 @@ __device__ __forceinline__ float ms_pixel_area(uint32_t ez, uint32_t samples0, u
 // store the same value.  Same integer operations on the same counter values as the dense resolve: bit-identical.
 template <int AA>
 __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4],
-                                   bool &clean) {
+                                   bool &clean, FineProf &pf) {
     constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
     // (uniform values: in scalar registers the rule's branches are real branches, not lane masks)
     const bool even_odd = ((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][0]) & 1u) != 0u;
@@ -649,6 +702,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], true, sh.winding, sh_samples);
         wave_lds_sync();
         ms_resolve<AA>(sh, sh_samples, bt.winding_y[slot], true, backdrop, lane, area);
+        pf.mark(FP_FILL_EVENODD);
         return;
     }
     wave_lds_sync();
@@ -667,6 +721,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], false, sh.winding, sh_samples);
     }
     wave_lds_sync();
+    pf.mark(FP_FILL_APPLY);
     // winding prefix sums exactly as ms_resolve; the row counters go back to their cleared value as they are read
     const uint32_t lx = lane & 3u, ly = lane >> 2;
     uint32_t packed_w = sh.winding[lane];
@@ -693,10 +748,14 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         // untouched counters are 0x80: every sample differs from expected_zero, or none does
         area[i] = ez[i] == 0x80u ? 0.0f : 1.0f;
     }
-    if (begin == end) return;
+    if (begin == end) {
+        pf.mark(FP_FILL_PREFIX);
+        return;
+    }
     *reinterpret_cast<uint4 *>(&sh.px.expected_zero[lane * 4u]) = make_uint4(ez[0], ez[1], ez[2], ez[3]);
     *reinterpret_cast<float4 *>(&sh.px.area[lane * 4u]) = make_float4(area[0], area[1], area[2], area[3]);
     wave_lds_sync();
+    pf.mark(FP_FILL_PREFIX);
     for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
         const uint32_t i = i0 + lane;
         const uint32_t rec = one_round ? rec0 : (i < end ? bt.item[i] : 0u);
@@ -710,6 +769,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         }
     }
     wave_lds_sync();
+    pf.mark(FP_FILL_SPARSE);
     for (uint32_t i0 = begin; i0 < end; i0 += 64u) {
         const uint32_t i = i0 + lane;
         const uint32_t rec = one_round ? rec0 : (i < end ? bt.item[i] : 0u);
@@ -722,6 +782,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     }
     const float4 a = *reinterpret_cast<const float4 *>(&sh.px.area[lane * 4u]);
     area[0] = a.x; area[1] = a.y; area[2] = a.z; area[3] = a.w;
+    pf.mark(FP_FILL_RESTORE);
 }
 
 // ---------------- blend (shared/blend.wgsl) ----------------
@@ -1247,6 +1308,9 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
         }
     };
     const uint32_t blend_offset = rd(cmd_ix);
+    FineProf prof;
+    prof.start();
+    prof.count(FP_N_WORDS, rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u));  // the tile's list length, as coarse left it
 #ifndef VELLO_SIMT_EMU
     // A long list is the launch's critical path: its wave issues ahead of the waves it shares the SIMD with.
     if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
@@ -1297,8 +1361,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                         }
                     }
                     uint32_t after_batch = 0xffffffffu;
+                    prof.mark(FP_INTERP);
+                    prof.count(FP_N_BATCHES, 1u);
                     batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch));
+                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof));
                     batch_pos = 0u;
                     pf_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_batch);
                     if (pf_base != 0xffffffffu) {
@@ -1306,8 +1372,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                         pf_win = a < cfg.ptcl_size ? ptcl[a] : 0u;  // arrives while the batch's fills are replayed
                     }
                 }
+                prof.mark(FP_INTERP);
+                prof.count(FP_N_FILLS, 1u);
                 if (batch_n != 0u) {
-                    ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area, samples_clean);
+                    ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area, samples_clean, prof);
                     batch_pos += 1u;
                 } else {
                     CmdFill fill;
@@ -1316,6 +1384,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     fill.backdrop = (int32_t)rd(cmd_ix + 3u);
                     fill_path_ms<AA>(sh, sh_samples, segments, mask_lut, fill, lane, area);
                     samples_clean = false;
+                    prof.mark(FP_FILL_UNBATCHED);
                 }
             }
             cmd_ix += 4u;
@@ -1325,6 +1394,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
 #pragma unroll
                 for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
                 cmd_ix += 2u;
+                prof.mark(FP_BLEND);
             }
         } else if (tag == CMD_SOLID) {
 #pragma unroll
@@ -1361,8 +1431,11 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             }
             clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
             cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
+            prof.mark(FP_RARE);
         }
     }
+    prof.mark(FP_INTERP);
+    prof.store(blend_spill, cfg.blend_size, n_tiles, tile_ix, lane);
     // fine.wgsl:1386-1397: un-premultiplied RGBA8
     const uint32_t px0 = tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD;
     const uint32_t py = tile_y * TILE_HEIGHT + ly;
