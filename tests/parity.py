@@ -175,11 +175,11 @@ def compare_segment_slices(name, seg_h, seg_o, fh, fo, fn):
 def compare_back_half(engine, oracle, packed, layout, width, height, base_color, aa, name, ramps=None, ref=None):
     """Renders once more with occlusion culling off (VELLO_HIP_DEBUG_NO_CULL): every counter must then equal the
     oracle's, and bin lists, SegmentCounts, PTCL and segment slices are diffed."""
-    engine.set_debug_flags(no_cull=True)
+    engine.update_debug_flags(no_cull=True)
     try:
         img, bump = engine.render(packed, layout, width, height, base_color, aa, ramps=ramps)
     finally:
-        engine.set_debug_flags(no_cull=False)
+        engine.update_debug_flags(no_cull=False)
     ob = oracle.bump()
     # bump.ptcl is the one counter that is not the reference's: the engine stores a tile's commands in exact-fit regions
     # linked by CMD_JUMP instead of 256-word chunks (DESIGN.md 3, k_coarse); the command words themselves are diffed below

@@ -2,6 +2,7 @@
 against the SIMT emulator (tests/simt_emu), must agree with the CPU oracle stage by stage.  This checks
 indexing / scan / allocation logic; memory-model behaviour is only checked on hardware (test_gpu_parity.py)."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -891,3 +892,32 @@ def test_emu_write_image_between_frames(emu_engine):
                 assert tuple(img[4 + 2 * ty + 1, 4 + 2 * 7 + 1]) == tuple(frames[k][ty, 7]), (k, ty)
     finally:
         emu_engine.set_frames_in_flight(1)
+
+
+def _pipeline_cases():
+    m = sys.modules[__name__]
+    cases = [("tiger", lambda e: m.test_emu_tiger_small(e)),
+             ("stroke_styles", lambda e: m.test_emu_stroke_styles(e, AaConfig.Msaa16)),
+             ("clip_blend", lambda e: m.test_emu_clip_blend(e, AaConfig.Msaa8)),
+             ("brushes", lambda e: m.test_emu_gradient_image_blur_brushes(e, AaConfig.Msaa16)),
+             ("thousands_of_segments", lambda e: m.test_emu_thousands_of_segments_in_one_tile(e)),
+             ("fuzz", lambda e: m.test_emu_fuzz_whole_api(e)),
+             ("fuzz_sizes", lambda e: m.test_emu_fuzz_target_sizes_and_long_scenes(e)),
+             ("nested_clips", lambda e: m.test_emu_layers_nested_300_deep(e, "clip")),
+             ("nested_blends", lambda e: m.test_emu_layers_nested_300_deep(e, "blend"))]
+    cases += [(f"rules_{seed}", lambda e, seed=seed: m.test_emu_fill_rules_interleaved_in_one_tile(e, seed)) for seed in (11, 12, 13)]
+    cases += [(w, lambda e, w=w: m.test_emu_reference_brush_and_layer_scenes(e, w)) for w in ("blend_grid", "deep_blend", "many_clips", "gradient_extend")]
+    cases += [(w, lambda e, w=w: m.test_emu_reference_test_scenes(e, w)) for w in ("fill_types", "tricky_strokes")]
+    return cases
+
+
+@pytest.mark.parametrize("name,body", _pipeline_cases(), ids=[c[0] for c in _pipeline_cases()])
+def test_emu_fine_pipeline(emu_engine, name, body):
+    # k_fine_pipe (VELLO_HIP_DEBUG_FINE_PIPELINE: one wave stages a tile's fills, a second one replays and composites them)
+    # through the same oracle comparisons as the one-wave kernel: batches, fills that do not fit a batch, both fill rules, clip /
+    # blend stacks beyond the register window, brushes, the fuzzers
+    emu_engine.set_debug_flags(fine_pipeline=True)
+    try:
+        body(emu_engine)
+    finally:
+        emu_engine.set_debug_flags()

@@ -102,6 +102,7 @@ struct Frame {
     uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which k_flatten_strokes takes them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that k_flatten_strokes would exit at once
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
+    bool fine_pipeline;  // VELLO_HIP_DEBUG_FINE_PIPELINE: k_fine_pipe (two waves per tile) for the MSAA modes
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;

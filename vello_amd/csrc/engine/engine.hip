@@ -353,6 +353,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
+    f.fine_pipeline = (c->debug_flags & VELLO_HIP_DEBUG_FINE_PIPELINE) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;

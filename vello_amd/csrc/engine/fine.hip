@@ -510,10 +510,10 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
 // window (any other commands in between are skipped over: coverage does not depend on them), load all their segments
 // with one instruction, count, scan, and write one record per crossing.  Returns the number of fills staged (0 when
 // the first fill alone does not fit: > 64 segments or > MS_ITEM_CAP crossings).
-template <int AA>
+template <int AA, bool WANT_AFTER_FIT = false>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t lane, uint32_t &after_batch, FineProf &pf) {
+                                   uint32_t lane, uint32_t &after_batch, FineProf &pf, uint32_t *after_fit = nullptr) {
     // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
     // its hazard slots, cost 600+ issue slots per batch).  Lane i looks at word i as if a command started there:
     // next[i] = i + its size, stopping at END / JUMP / unknown tags and where a FILL's four words would leave the window.
@@ -623,6 +623,8 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     const unsigned long long fits = __ballot(lane < n && bt.item_end[lane + 1u] <= MS_ITEM_CAP);  // (ends are non-decreasing)
     const uint32_t n_fit = fits ? 64u - (uint32_t)__clzll((long long)fits) : 0u;
     if (n_fit == 0u) return 0u;
+    // (two waves per tile: the builder goes on behind the last fill it STAGED, which may lie before the last one it saw)
+    if constexpr (WANT_AFTER_FIT) *after_fit = win_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)src_pos, (int)(n_fit - 1u))) + 4u;
     const uint32_t total = bt.item_end[n_fit];
     const uint32_t n_staged = tot_segs;
     pf.mark(FP_BATCH_SEGS);
@@ -1458,10 +1460,231 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     }
 }
 
+
+// ---------------- two waves per tile: builder | player (EXPERIMENTAL, VELLO_HIP_DEBUG_FINE_PIPELINE) ----------------
+// k_fine's launch is as long as its longest tile, and a tile is ONE wave's chain of fills.  Cutting the
+// tile's pixels over several waves replicates the per-fill work (measured: 2x slower).  This kernel cuts the WORK instead:
+// wave 0 walks the command list for FILLs and stages batches (ms_build_batch: scan, segment loads, one record per crossing)
+// into one of two FineBatch buffers; wave 1 interprets the list as k_fine does and replays the staged fills
+// (ms_fill_from_batch), blends, handles clips / brushes.  One workgroup barrier per batch hands a buffer over; the builder
+// runs at most one batch ahead.  By instruction count a fill is 1/3 staging, 2/3 replay.  Same functions, same integer
+// operations on the same values as k_fine: bit-identical output (tests/test_emu_parity.py).  Not the default: it has not
+// been timed on the GPU yet.
+constexpr uint32_t PIPE_END = 0u, PIPE_BATCH = 1u, PIPE_SINGLE = 2u;
+
+template <int AA, bool BRUSHES>
+__global__ void __launch_bounds__(128, BRUSHES ? 3 : 4) k_fine_pipe(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+                                                  const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
+                                                  uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
+                                                  const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
+                                                  uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
+                                                  const uint32_t *__restrict__ tile_order) {
+    static_assert(AA != 0, "area AA has no batches to stage");
+    __shared__ FineShared sh_build, sh_play;
+    __shared__ uint32_t sh_samples[AA == 2 ? 1024 : 512];
+    __shared__ FineBatch bt[2];
+    __shared__ uint32_t hdr[2][2];  // per buffer: PIPE_*, fills staged
+    if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
+    const uint32_t lane = threadIdx.x & 63u, role = threadIdx.x >> 6;
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
+    uint32_t tile_ix = blockIdx.x;
+    {
+        uint32_t rest = blockIdx.x;
+        bool found = false;
+#pragma unroll
+        for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
+            const uint32_t cnt = minu(work_count[b], n_tiles);
+            if (!found && rest < cnt) {
+                tile_ix = tile_order[(uint32_t)b * n_tiles + rest];
+                found = true;
+            }
+            if (!found) rest -= cnt;
+        }
+        if (!found || tile_ix >= n_tiles) return;
+    }
+    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
+    uint32_t win_base = cmd_ix;
+    uint32_t win = ptcl[win_base + lane];
+    auto rd = [&](uint32_t ix) -> uint32_t {
+        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
+    };
+    auto ensure = [&](uint32_t ix, uint32_t n_words) {
+        if (ix + n_words > win_base + 64u) {
+            win_base = ix;
+            uint32_t a = win_base + lane;
+            win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+        }
+    };
+    const uint32_t blend_offset = rd(cmd_ix);
+#ifndef VELLO_SIMT_EMU
+    if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
+#endif
+    cmd_ix += 1u;
+    FineProf prof;
+    prof.start();
+
+    if (role == 0u) {
+        // ---- builder: FILL after FILL into bt[unit & 1]
+        uint32_t unit = 0u;
+        for (;;) {
+            bool found = false;
+            for (;;) {  // the next FILL at or after cmd_ix
+                ensure(cmd_ix, 4u);
+                const uint32_t tag = rd(cmd_ix);
+                if (tag == CMD_FILL) {
+                    found = true;
+                    break;
+                }
+                if (tag == CMD_END) break;
+                if (tag == CMD_JUMP) cmd_ix = rd(cmd_ix + 1u);
+                else if (tag == CMD_COLOR || tag == CMD_IMAGE) cmd_ix += 2u;
+                else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) cmd_ix += 3u;
+                else cmd_ix += 1u;  // SOLID, BEGIN_CLIP; unknown tags as rare_command skips them
+            }
+            uint32_t kind = PIPE_END, n = 0u;
+            if (found) {
+                if (cmd_ix != win_base) {  // (the scan wants to see as far ahead as possible)
+                    win_base = cmd_ix;
+                    uint32_t a = win_base + lane;
+                    win = a < cfg.ptcl_size ? ptcl[a] : 0u;
+                }
+                uint32_t after_batch = 0xffffffffu, after_fit = cmd_ix + 4u;
+                n = (uint32_t)__builtin_amdgcn_readfirstlane(
+                    (int)ms_build_batch<AA, true>(sh_build, bt[unit & 1u], segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, &after_fit));
+                kind = n != 0u ? PIPE_BATCH : PIPE_SINGLE;
+                cmd_ix = n != 0u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)after_fit) : cmd_ix + 4u;
+            }
+            if (lane == 0u) {
+                hdr[unit & 1u][0] = kind;
+                hdr[unit & 1u][1] = n;
+            }
+            __syncthreads();  // the buffer is the player's; bt[(unit + 1) & 1] is free: the player was done with it before it came here
+            if (!found) break;
+            unit += 1u;
+        }
+        return;
+    }
+
+    // ---- player: k_fine's interpreter, batches taken from the builder
+    const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
+    const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
+    const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
+    vec4 rgba[4];
+    const vec4 base_color = unpack4x8unorm(cfg.base_color);
+#pragma unroll
+    for (int i = 0; i < 4; i++) rgba[i] = base_color;
+    uint32_t blend_stack[BLEND_STACK_SPLIT][4];
+    uint32_t clip_depth = 0u;
+    float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t batch_n = 0u, batch_pos = 0u, units = 0u, cur = 0u;
+    bool samples_clean = false;
+    for (;;) {
+        ensure(cmd_ix, 4u);
+        const uint32_t tag = rd(cmd_ix);
+        if (tag == CMD_END) break;
+        if (tag == CMD_FILL) {
+            if (batch_pos == batch_n) {
+                __syncthreads();  // the builder has staged this FILL (and what follows it) in bt[units & 1]
+                cur = units & 1u;
+                units += 1u;
+                const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[cur][0]);
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[cur][1]);
+                batch_n = kind == PIPE_BATCH ? n : 0u;
+                batch_pos = 0u;
+            }
+            if (batch_n != 0u) {
+                ms_fill_from_batch<AA>(sh_play, bt[cur], sh_samples, batch_pos, lane, area, samples_clean, prof);
+                batch_pos += 1u;
+            } else {
+                CmdFill fill;
+                fill.size_and_rule = rd(cmd_ix + 1u);
+                fill.seg_data = rd(cmd_ix + 2u);
+                fill.backdrop = (int32_t)rd(cmd_ix + 3u);
+                fill_path_ms<AA>(sh_play, sh_samples, segments, mask_lut, fill, lane, area);
+                samples_clean = false;
+            }
+            cmd_ix += 4u;
+            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {
+                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
+#pragma unroll
+                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                cmd_ix += 2u;
+            }
+        } else if (tag == CMD_SOLID) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) area[i] = 1.0f;
+            cmd_ix += 1u;
+            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {
+                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
+#pragma unroll
+                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                cmd_ix += 2u;
+            }
+        } else if (tag == CMD_COLOR) {
+            const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
+#pragma unroll
+            for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+            cmd_ix += 2u;
+        } else if (tag == CMD_JUMP) {
+            cmd_ix = rd(cmd_ix + 1u);
+        } else {
+            RareState st;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                st.rgba[i] = rgba[i];
+                st.area[i] = area[i];
+            }
+            st.clip_depth = clip_depth;
+            st.cmd_ix = cmd_ix;
+            rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+                                  atlas_texels, atlas_w, atlas_h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                rgba[i] = st.rgba[i];
+                area[i] = st.area[i];
+            }
+            clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
+            cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
+        }
+    }
+    __syncthreads();  // the builder's PIPE_END
+    const uint32_t px0 = tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD;
+    const uint32_t py = tile_y * TILE_HEIGHT + ly;
+    if (py < cfg.target_height && px0 < cfg.target_width) {
+        uint32_t packed[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            vec4 fg = rgba[i];
+            float a_inv = 1.0f / maxf(fg.w, 1e-6f);
+            packed[i] = pack4x8unorm(vec4{fg.x * a_inv, fg.y * a_inv, fg.z * a_inv, fg.w});
+        }
+        uint8_t *row = output + (size_t)py * out_stride + (size_t)px0 * 4u;
+        if (px0 + 4u <= cfg.target_width && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0u)) {
+            *reinterpret_cast<uint4 *>(row) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++)
+                if (px0 + i < cfg.target_width) reinterpret_cast<uint32_t *>(row)[i] = packed[i];
+        }
+    }
+}
+
 template <int AA>
 static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_lut) {
     dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles);
     uint32_t stride = (uint32_t)f.out_stride;
+    if constexpr (AA != 0) {
+        if (f.fine_pipeline) {  // VELLO_HIP_DEBUG_FINE_PIPELINE: two waves per tile
+            if (f.brushes)
+                hipLaunchKernelGGL((k_fine_pipe<AA, true>), grid, dim3(128), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+                                   stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
+            else
+                hipLaunchKernelGGL((k_fine_pipe<AA, false>), grid, dim3(128), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
+                                   stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
+            return;
+        }
+    }
     if (f.brushes)
         hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
                            stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);

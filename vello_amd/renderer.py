@@ -209,12 +209,22 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False):
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_pipeline=False):
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
         runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
-        stack machine instead of the partitioned kernels."""
-        flags = (1 if no_cull else 0) | (2 if stroke_kernel else 0) | (4 if seq_clip else 0)
+        stack machine instead of the partitioned kernels; fine_pipeline renders the MSAA modes with the experimental
+        two-waves-per-tile form of fine.  Flags not named are cleared (update_debug_flags keeps them)."""
+        self._debug = {"no_cull": bool(no_cull), "stroke_kernel": bool(stroke_kernel), "seq_clip": bool(seq_clip),
+                       "fine_pipeline": bool(fine_pipeline)}
+        d = self._debug
+        flags = (1 if d["no_cull"] else 0) | (2 if d["stroke_kernel"] else 0) | (4 if d["seq_clip"] else 0) | (8 if d["fine_pipeline"] else 0)
         self._check(self._lib.vello_hip_set_debug_flags(self._h, flags), "set_debug_flags")
+
+    def update_debug_flags(self, **changes):
+        """set_debug_flags with the flags not named left as they are."""
+        d = dict(getattr(self, "_debug", {}))
+        d.update(changes)
+        self.set_debug_flags(**d)
 
     def last_render_attempts(self):
         return int(self._lib.vello_hip_last_render_attempts(self._h))
