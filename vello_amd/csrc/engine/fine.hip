@@ -1485,7 +1485,9 @@ __global__ void __launch_bounds__(128, BRUSHES ? 3 : 4) k_fine_pipe(Config cfg, 
     __shared__ FineBatch bt[2];
     __shared__ uint32_t hdr[2][2];  // per buffer: PIPE_*, fills staged
     if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
-    const uint32_t lane = threadIdx.x & 63u, role = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    // (a scalar: the two roles are two code paths with workgroup barriers in them, no wave may walk the other's with an empty mask)
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t lx = lane & 3u, ly = lane >> 2;
     const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
     uint32_t tile_ix = blockIdx.x;
