@@ -1,6 +1,6 @@
 #!/bin/bash
 # The first GPU session after round 2 (about 3 minutes): where k_fine's cycles go, then same-box A/B of the in-tree build (A)
-# against the three patched builds (B merged restore, C one LDS entry per staged fill, D graded priority) and against the
+# against the patched builds (B merged restore, C one LDS entry per staged fill, D graded priority, E path_count chunks of 2048 lines) and against the
 # two-waves-per-tile kernel (P = the in-tree library with VELLO_FINE_PIPELINE=1).  Everything under `timeout`: k_fine_pipe has
 # never run on hardware.        scripts/prepare_experiments.sh && scripts/grun.sh --timeout 300 -- 'bash scripts/gpu_experiments.sh'
 set -u
@@ -25,7 +25,7 @@ for aa in (AaConfig.Msaa8, AaConfig.Msaa16):
     print("k_fine_pipe", int(aa), "image equal to k_fine's:", bool(np.array_equal(a, b)))
 PY
 for rep in 1 2; do
-  for w in A B C D; do
+  for w in A B C D E; do
     timeout 60 python scripts/ab_bench.py $w --steps 80 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | line $w | tee -a $OUT/ab.txt
   done
   VELLO_FINE_PIPELINE=1 timeout 60 python scripts/ab_bench.py A --steps 80 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | line P | tee -a $OUT/ab.txt

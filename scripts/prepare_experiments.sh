@@ -7,4 +7,5 @@ scripts/build_prof.sh
 scripts/variant.sh fine_merged_restore B
 scripts/variant.sh fine_slot_b128 C
 scripts/variant.sh fine_graded_prio D
+scripts/variant.sh path_count_chunk8 E
 ls -la ab_tmp
