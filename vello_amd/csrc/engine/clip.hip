@@ -74,8 +74,7 @@ struct ClipScratch {
 };
 
 __device__ __forceinline__ ClipScratch clip_scratch(uint32_t *p, uint32_t n_clips) {
-    uint32_t parts = (n_clips + CLIP_PART - 1u) / CLIP_PART;
-    uint32_t n_pad = clip_parts_pad(parts);
+    const uint32_t parts = (n_clips + CLIP_PART - 1u) / CLIP_PART;
     ClipScratch s;
     s.els = (ClipEl *)p;
     p += (size_t)parts * CLIP_PART * (sizeof(ClipEl) / 4u);
@@ -85,8 +84,7 @@ __device__ __forceinline__ ClipScratch clip_scratch(uint32_t *p, uint32_t n_clip
     p += (size_t)parts * 2u;
     s.height = p;
     p += parts;
-    s.tree = (int32_t *)p;
-    (void)n_pad;
+    s.tree = (int32_t *)p;  // 2 * clip_parts_pad(parts) entries
     return s;
 }
 
