@@ -43,4 +43,9 @@ def gpu_engine(built):
     import vello_amd._lib as L
 
     L._use_library(None)
-    return vello_amd.Engine(device=0)
+    try:
+        return vello_amd.Engine(device=0)
+    except RuntimeError as e:  # vello_hip_create: VELLO_HIP_E_NO_DEVICE (-3): no MI355X here -- the -m gpu tests do not apply
+        if "no usable HIP device" in str(e) or "-3" in str(e):
+            pytest.skip("no HIP device: " + str(e))
+        raise

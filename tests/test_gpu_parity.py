@@ -718,3 +718,41 @@ def test_write_image_is_ordered_with_frames_in_flight(built):
         for ty in (0, k, k + 7, k + 8 if k + 8 < 64 else 0, 63):
             for tx in (0, 31, 63):
                 assert tuple(got[8 + 6 * ty + 3, 8 + 6 * tx + 3]) == tuple(frames[k][ty, tx]), (k, ty, tx)
+
+
+def test_atlas_clear_is_ordered_with_the_uploads_that_follow(built):
+    # vello_hip_resize_image_atlas cleared the new atlas with hipMemset on the null stream while
+    # vello_hip_write_image transfers on a non-blocking upload stream -- nothing ordered the upload behind the clear, and a
+    # clear that lands late zeroes the texels (the brushes test failed that way on one fresh box).  A large atlas makes the
+    # clear long (8192^2 x 4 B = 256 MB) and the upload follows at once: every round must sample the uploaded texels.
+    import torch
+    import vello_amd
+    from vello_amd import Affine, ImageBrush, ImageData, ImageQuality, Scene
+
+    px = np.full((64, 64, 4), 255, dtype=np.uint8)
+    px[:, :, 0] = np.arange(64, dtype=np.uint8)[None, :] * 3
+    px[:, :, 1] = np.arange(64, dtype=np.uint8)[:, None] * 2 + 9
+    s = Scene()
+    s.draw_image(ImageBrush(ImageData(px), quality=ImageQuality.Low), Affine.translate(8.0, 8.0) * Affine.scale(6.0))
+    r = vello_amd.Resolver().resolve(s)
+    (x, y, _), = r.uploads
+    eng = vello_amd.Engine()
+    eng.upload_scene(r.packed, r.layout, r.ramps)
+    target = torch.zeros((400, 400, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for rnd in range(12):
+        side = 8192 if rnd % 2 == 0 else 4096  # alternating sizes: a fresh allocation and a reused one
+        eng.resize_image_atlas(side, side)
+        eng.write_image(x, y, px)
+        eng.render_resident(400, 400, BLACK, AaConfig.Msaa16, out=target)
+        assert eng.sync() == 0
+        got = target.cpu().numpy()
+        for ty in (0, 17, 63):
+            for tx in (0, 31, 63):
+                assert tuple(got[8 + 6 * ty + 3, 8 + 6 * tx + 3]) == tuple(px[ty, tx]), (rnd, ty, tx)
+    # texels never uploaded read as transparent black: the clear itself happened
+    eng.resize_image_atlas(4096, 4096)
+    eng.render_resident(400, 400, BLACK, AaConfig.Msaa16, out=target)
+    assert eng.sync() == 0
+    got = target.cpu().numpy()
+    assert tuple(got[8 + 6 * 17 + 3, 8 + 6 * 31 + 3]) == (0, 0, 0, 255)

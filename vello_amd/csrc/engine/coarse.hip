@@ -722,6 +722,16 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
 #endif
 }
 
+// k_coarse's dynamic LDS is beyond the 64 KB a kernel gets without asking; function attributes are per device, so every
+// context asks once for its own (vello_hip_create, after hipSetDevice) and reports a refusal there.
+int enable_coarse_lds() {
+#ifndef VELLO_SIMT_EMU
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CoarseLds));
+#else
+    return 0;
+#endif
+}
+
 void launch_coarse(const Frame &f, hipStream_t s) {
     const uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
     if (wb * hb == 0) return;
@@ -733,11 +743,6 @@ void launch_coarse(const Frame &f, hipStream_t s) {
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
-#ifndef VELLO_SIMT_EMU
-    static const hipError_t lds_enabled =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_coarse), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(CoarseLds));
-    (void)lds_enabled;  // (a refusal shows up as the launch error the engine reports)
-#endif
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order);
 }

@@ -120,6 +120,7 @@ void launch_tile_alloc(const Frame &f, hipStream_t s);
 void launch_path_count(const Frame &f, hipStream_t s);
 void launch_backdrop(const Frame &f, hipStream_t s);
 void launch_coarse(const Frame &f, hipStream_t s);
+int enable_coarse_lds();  // hipError_t of the per-device dynamic-LDS opt-in
 void launch_path_tiling(const Frame &f, hipStream_t s);
 void launch_fine(const Frame &f, hipStream_t s);
 

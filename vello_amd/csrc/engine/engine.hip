@@ -66,6 +66,7 @@ struct Lane {
     };
     std::vector<EvPair> events;
     bool used = false;
+    bool flatten_ran = false;  // the control block holds flatten's counts (a partial vello_hip_run_stages range may stop before it)
     uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
     uint64_t atlas_epoch_seen = 0;  // ctx::atlas_epoch the lane's stream has been ordered behind
 };
@@ -161,6 +162,15 @@ int sync_uploads(vello_hip_ctx *c) {
     return 0;
 }
 
+// the upload stream and its events (created on first use)
+int ensure_upload_stream(vello_hip_ctx *c) {
+    if (c->upload_stream) return 0;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->atlas_ready, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->lane_mark, hipEventDisableTiming));
+    return 0;
+}
+
 // a pinned block of >= bytes that no DMA is reading
 int acquire_staging(vello_hip_ctx *c, size_t bytes, Staging *&out) {
     size_t held = 0;
@@ -208,6 +218,34 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
     if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_plane_words(d.tiles) * 3u * 4u))) return r;
     return 0;
+}
+
+// bytes alloc_lane_pools asks for, per lane
+size_t pool_bytes(const vello_hip_capacities &d) {
+    return (size_t)d.lines * sizeof(LineSoup) + (size_t)d.bin_data * 4u + (size_t)d.tiles * sizeof(Tile) +
+           (size_t)d.seg_counts * sizeof(SegmentCount) + (size_t)d.segments * sizeof(Segment) + (size_t)d.blend_spill * 4u +
+           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u;
+}
+
+// Makes `d` the context's capacities, or leaves the context as it was: ensure() frees a buffer before it allocates the
+// larger one, so after a failed hipMalloc the lane holds a null pool -- the old sizes are put back (they fitted before)
+// and c->caps keeps describing what the lanes really hold.  Callers have drained the lanes.
+int commit_caps(vello_hip_ctx *c, const vello_hip_capacities &d) {
+    const vello_hip_capacities old = c->caps;
+    c->caps = d;
+    int r = 0;
+    for (auto &l : c->lanes)
+        if ((r = alloc_lane_pools(c, l))) break;
+    if (!r) return 0;
+    (void)hipGetLastError();
+    const std::string err = c->last_error;
+    c->caps = old;
+    for (auto &l : c->lanes) {
+        int r2 = alloc_lane_pools(c, l);
+        if (r2) return r2;  // not even the old pools: nothing left to render into, the error stands
+    }
+    c->last_error = "growing the pools failed, capacities unchanged: " + err;
+    return r;
 }
 
 SceneSlot &slot_of(vello_hip_ctx *c, Lane &l) { return l.use_own ? l.own : c->shared; }
@@ -294,10 +332,10 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
                 return VELLO_HIP_E_INVALID;
             }
             if ((r = sync_all(c))) return r;
-            if (need_ptcl > c->caps.ptcl) c->caps.ptcl = (uint32_t)(need_ptcl + need_ptcl / 4u);
-            if (need_bin > c->caps.bin_data) c->caps.bin_data = (uint32_t)(need_bin + need_bin / 4u);
-            for (auto &ln : c->lanes)
-                if ((r = alloc_lane_pools(c, ln))) return r;
+            vello_hip_capacities d = c->caps;
+            if (need_ptcl > d.ptcl) d.ptcl = (uint32_t)(need_ptcl + need_ptcl / 4u);
+            if (need_bin > d.bin_data) d.bin_data = (uint32_t)(need_bin + need_bin / 4u);
+            if ((r = commit_caps(c, d))) return r;
         }
     }
     r = configure(c, sc, p, f.cfg);
@@ -384,9 +422,13 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f, int first, int la
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
             HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, slot_of(c, l).zero_bytes, st));
+            l.flatten_ran = false;
             launch_pathtag_scan(f, st);
             break;
-        case VELLO_HIP_STAGE_FLATTEN: launch_flatten(f, st); break;
+        case VELLO_HIP_STAGE_FLATTEN:
+            launch_flatten(f, st);
+            l.flatten_ran = true;
+            break;
         case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, st); break;
         case VELLO_HIP_STAGE_CLIP: launch_clip(f, st); break;
         case VELLO_HIP_STAGE_BINNING: launch_binning(f, st); break;
@@ -514,6 +556,10 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
         vello_hip_destroy(c);
         return VELLO_HIP_E_HIP;
     };
+    if (int le = enable_coarse_lds()) {
+        c->last_error = std::string("hipFuncSetAttribute(k_coarse, MaxDynamicSharedMemorySize): ") + hipGetErrorString((hipError_t)le);
+        return fail("coarse LDS opt-in");
+    }
     c->lanes.resize(1);
     if (alloc_lane_pools(c, c->lanes[0])) return fail("pool allocation");
     if (ensure(c, c->config, sizeof(Config))) return fail("config");
@@ -729,7 +775,13 @@ int vello_hip_resize_image_atlas(vello_hip_ctx *c, uint32_t width, uint32_t heig
     if (width == 0 || height == 0) return VELLO_HIP_OK;
     size_t bytes = (size_t)width * height * 4u;
     if ((r = ensure(c, c->atlas, bytes))) return r;
-    HIP_TRY(c, hipMemset(c->atlas.ptr, 0, bytes));
+    // Every writer of the atlas is ordered on the upload stream: hipMemset on the null stream is asynchronous to the host
+    // for device memory and the (non-blocking) upload stream does not synchronise with it, so a clear issued there could
+    // land AFTER the uploads that follow this call.  Frames wait for `atlas_ready` like they do after an upload.
+    if ((r = ensure_upload_stream(c))) return r;
+    HIP_TRY(c, hipMemsetAsync(c->atlas.ptr, 0, bytes, c->upload_stream));
+    HIP_TRY(c, hipEventRecord(c->atlas_ready, c->upload_stream));
+    c->atlas_epoch += 1u;
     c->atlas_w = width;
     c->atlas_h = height;
     return VELLO_HIP_OK;
@@ -745,16 +797,12 @@ int vello_hip_write_image(vello_hip_ctx *c, uint32_t x, uint32_t y, uint32_t wid
     if (width == 0 || height == 0) return VELLO_HIP_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     if (stride == 0) stride = (size_t)width * 4u;
-    if (!c->upload_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->atlas_ready, hipEventDisableTiming));
-        HIP_TRY(c, hipEventCreateWithFlags(&c->lane_mark, hipEventDisableTiming));
-    }
+    int r = ensure_upload_stream(c);
+    if (r) return r;
     // the caller owns the pixels only for the duration of the call: into pinned memory now, DMA later
     const size_t row_bytes = (size_t)width * 4u;
     Staging *st = nullptr;
-    int r = acquire_staging(c, row_bytes * height, st);
-    if (r) return r;
+    if ((r = acquire_staging(c, row_bytes * height, st))) return r;
     for (uint32_t row = 0; row < height; row++) std::memcpy((char *)st->host + row * row_bytes, rgba8 + row * stride, row_bytes);
     // frames already enqueued may sample the texels this upload replaces: it runs behind all of them
     for (auto &l : c->lanes) {
@@ -825,7 +873,7 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
     Lane &l = c->lanes[(c->last_lane + n - age) % n];
     HIP_TRY(c, hipStreamSynchronize(l.stream));
     // (once per scene: what flatten counted, so that later frames can leave out a launch that would exit at once)
-    if (l.used && l.zero_region.ptr && slot_of(c, l).stroke_lines < 0 && l.frame_generation == slot_of(c, l).generation) {
+    if (l.used && l.flatten_ran && l.zero_region.ptr && slot_of(c, l).stroke_lines < 0 && l.frame_generation == slot_of(c, l).generation) {
         Control ctl;
         HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
         if (ctl.bump.failed == 0u) slot_of(c, l).stroke_lines = (int64_t)ctl.heavy_count[2];
@@ -844,7 +892,7 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
     std::memcpy(&b, &ctl.bump, sizeof b);
     if (b.failed == 0u) {
         SceneSlot &sc = slot_of(c, l);
-        if (l.frame_generation == sc.generation) sc.stroke_lines = (int64_t)ctl.heavy_count[2];  // (flatten ran to its end)
+        if (l.flatten_ran && l.frame_generation == sc.generation) sc.stroke_lines = (int64_t)ctl.heavy_count[2];  // (flatten ran to its end)
         return VELLO_HIP_OK;
     }
     if ((b.failed & FAILED_SCENE) != 0u) {
@@ -924,11 +972,8 @@ int vello_hip_grow_pools(vello_hip_ctx *c, const vello_hip_bump *demand, vello_h
     }
     int r = sync_all(c);
     if (r) return r;
-    c->caps = d;
-    for (auto &l : c->lanes) {
-        if ((r = alloc_lane_pools(c, l))) return r;
-        l.used = false;  // the frames rendered into the old pools are void; their failure has been acted upon
-    }
+    if ((r = commit_caps(c, d))) return r;
+    for (auto &l : c->lanes) l.used = false;  // the frames rendered into the old pools are void; their failure has been acted upon
     return VELLO_HIP_OK;
 }
 
@@ -1016,11 +1061,16 @@ static int presize_pools(vello_hip_ctx *c, const uint8_t *scene, size_t scene_le
     want(d.ptcl, est.ptcl);
     if (d.segments < d.seg_counts) d.segments = d.seg_counts;
     if (!grew) return VELLO_HIP_OK;
+    // The estimate comes from caller-supplied geometry (up to 0xffff0000 elements per pool): one that the device cannot
+    // hold is not an error of this frame -- the pools stay and the overflow-and-grow loop of vello_hip_render finds the
+    // real demand, which is usually far below the estimator's bound.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VELLO_HIP_OK;
+    const size_t n_lanes = c->lanes.size(), held = pool_bytes(c->caps) * n_lanes, asked = pool_bytes(d) * n_lanes;
+    if (asked > held && asked - held > free_b - free_b / 8u) return VELLO_HIP_OK;
     int r = sync_all(c);
     if (r) return r;
-    c->caps = d;
-    for (auto &l : c->lanes)
-        if ((r = alloc_lane_pools(c, l))) return r;
+    if (commit_caps(c, d)) c->last_error.clear();  // capacities unchanged (commit_caps), fall back to the loop
     return VELLO_HIP_OK;
 }
 
