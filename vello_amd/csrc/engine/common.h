@@ -219,13 +219,61 @@ __device__ __forceinline__ uint32_t lane_value(uint32_t v) {
 #endif
 }
 
+// number of set bits of a (wave-uniform) 64-bit mask below this lane: v_mbcnt_lo / _hi on the GPU
+__device__ __forceinline__ uint32_t mask_rank_below(unsigned long long m, uint32_t lane) {
+#ifdef VELLO_SIMT_EMU
+    return (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+#else
+    (void)lane;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#endif
+}
+
+// Inclusive scans over the wave.  On the GPU: Hillis-Steele inside the rows of 16 lanes with DPP row shifts (a lane whose
+// source lies outside its row gets 0), then the row totals by row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows
+// 2 and 3 -- twelve VALU operations, no trip through the LDS crossbar (ds_bpermute per step: address, wait, select, add).
+#ifndef VELLO_SIMT_EMU
+#define VK_DPP0(v, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rows), 0xf, false))
+#endif
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#ifdef VELLO_SIMT_EMU
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
         uint32_t o = __shfl_up(v, d);
         if (lane >= d) v += o;
     }
     return v;
+#else
+    (void)lane;
+    v += VK_DPP0(v, 0x111, 0xf);
+    v += VK_DPP0(v, 0x112, 0xf);
+    v += VK_DPP0(v, 0x114, 0xf);
+    v += VK_DPP0(v, 0x118, 0xf);
+    v += VK_DPP0(v, 0x142, 0xa);
+    v += VK_DPP0(v, 0x143, 0xc);
+    return v;
+#endif
+}
+// the same with max (values >= 0: the filler 0 is neutral)
+__device__ __forceinline__ uint32_t wave_incl_scan_max_u32(uint32_t v, int lane) {
+#ifdef VELLO_SIMT_EMU
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v = v > o ? v : o;
+    }
+    return v;
+#else
+    (void)lane;
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, VK_DPP0(v, 0x111, 0xf));
+    v = mx(v, VK_DPP0(v, 0x112, 0xf));
+    v = mx(v, VK_DPP0(v, 0x114, 0xf));
+    v = mx(v, VK_DPP0(v, 0x118, 0xf));
+    v = mx(v, VK_DPP0(v, 0x142, 0xa));
+    v = mx(v, VK_DPP0(v, 0x143, 0xc));
+    return v;
+#endif
 }
 
 // Inclusive scan over a 256-thread workgroup (4 waves): wave shuffles + one LDS hop.
