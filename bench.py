@@ -153,8 +153,6 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
         import torch.distributed as dist
     dev = f"cuda:{local_rank}"
     engine = vello_amd.Engine(device=local_rank, capacities=wl.caps)
-    if os.environ.get("VELLO_FINE_PIPELINE") == "1":  # experiment switch (scripts/experiments/README.md); never set by the driver
-        engine.set_debug_flags(fine_pipeline=True)
     engine.upload_scene(wl.packed, wl.layout)
     aa = vello_amd.AaConfig.Msaa16
     nif = max(1, min(args.in_flight, 8))
@@ -461,7 +459,7 @@ def main():
             "workload": head["describe"],
             "baseline_config": "configs[2]",
             "commit": git_head(),
-            "fine_kernel": "k_fine_pipe (experiment: two waves per tile)" if os.environ.get("VELLO_FINE_PIPELINE") == "1" else "k_fine",
+            "fine_kernel": "k_fine",
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
             "exchange_alone_ms": None if head["exchange_ms"] is None else round(head["exchange_ms"], 4),

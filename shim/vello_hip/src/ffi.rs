@@ -74,7 +74,7 @@ pub const VELLO_HIP_E_CAPACITY: c_int = -4;
 pub const VELLO_HIP_DEBUG_NO_CULL: u32 = 1;
 pub const VELLO_HIP_DEBUG_STROKE_KERNEL: u32 = 2;
 pub const VELLO_HIP_DEBUG_SEQ_CLIP: u32 = 4;
-pub const VELLO_HIP_DEBUG_FINE_PIPELINE: u32 = 8;
+pub const VELLO_HIP_DEBUG_FINE_SLICES: u32 = 8;
 pub const VELLO_HIP_STAGE_COUNT: usize = 11;
 
 unsafe extern "C" {

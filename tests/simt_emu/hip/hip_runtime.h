@@ -200,3 +200,5 @@ static inline T atomicMax(T *p, T v) { T o = *p; *p = std::max(o, v); return o; 
 #define __HIP_MEMORY_SCOPE_AGENT 0
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+template <typename T, typename V>
+static inline T __hip_atomic_fetch_add(T *p, V v, int, int) { T o = *p; *p = (T)(o + (T)v); return o; }

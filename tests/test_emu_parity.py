@@ -912,12 +912,14 @@ def _pipeline_cases():
 
 
 @pytest.mark.parametrize("name,body", _pipeline_cases(), ids=[c[0] for c in _pipeline_cases()])
-def test_emu_fine_pipeline(emu_engine, name, body):
-    # k_fine_pipe (VELLO_HIP_DEBUG_FINE_PIPELINE: one wave stages a tile's fills, a second one replays and composites them)
-    # through the same oracle comparisons as the one-wave kernel: batches, fills that do not fit a batch, both fill rules, clip /
-    # blend stacks beyond the register window, brushes, the fuzzers
-    emu_engine.set_debug_flags(fine_pipeline=True)
+def test_emu_fine_slices(emu_engine, name, body):
+    # fine's sliced path (VELLO_HIP_DEBUG_FINE_SLICES: every tile's list cut into slices of 4 fills, coverage by one wave per
+    # slice, the last one to finish composites) through the same oracle comparisons as the one-wave path: batches, fills that
+    # do not fit a batch, both fill rules, clip / blend stacks beyond the register window, brushes, the fuzzers
+    emu_engine.set_debug_flags(fine_slices=True)
     try:
         body(emu_engine)
+        if name in ("tiger", "rules_11", "blend_grid"):  # (the flag did take these frames through the sliced path)
+            assert emu_engine.control_words()[24] > 0, "no tile was cut into slices"
     finally:
         emu_engine.set_debug_flags()

@@ -198,6 +198,10 @@ def test_config_c3_d2_scene_full_size(built):
     img, ref, bump = compare_frame(eng, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, "gpu_paris_d2", oracle=Oracle(capacity_scale=8))
     assert bump["failed"] == 0 and bump["lines"] > (1 << 21) and bump["seg_counts"] > (1 << 21)
     assert (img[:, :, 3] == 255).all()
+    # the scene has tiles of >= 64 fills: fine cut them into slices (engine.h FINE_SLICE_FILLS) -- the last frame compare_frame
+    # rendered is the NO_CULL one, whose lists are the longest
+    ctl = eng.control_words()
+    assert ctl[24] > 100 and ctl[25] > 0, "no tile of the d2 scene went through fine's sliced path"
 
 
 def test_config_c4_mmark_reduced(gpu_engine):
@@ -756,3 +760,69 @@ def test_atlas_clear_is_ordered_with_the_uploads_that_follow(built):
     assert eng.sync() == 0
     got = target.cpu().numpy()
     assert tuple(got[8 + 6 * 17 + 3, 8 + 6 * 31 + 3]) == (0, 0, 0, 255)
+
+
+def _slice_cases():
+    import vello_amd
+
+    def tiger(e):
+        d = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+        compare_frame(e, d["packed"], Layout(*[int(v) for v in d["layout"]]), 1024, 1024, WHITE, AaConfig.Msaa8, "gpu_tiger_slices")
+
+    def random_clips(e):
+        packed, layout = workloads.random_test_scene(2, n_paths=1500, size=768.0, strokes=True, clips=True).resolve()
+        compare_frame(e, packed, layout, 768, 768, BLACK, AaConfig.Msaa16, "gpu_random_slices")
+
+    def brushes(e):
+        r = vello_amd.Resolver().resolve(workloads.brushes_scene())
+        compare_frame(e, r.packed, r.layout, 256, 256, WHITE, AaConfig.Msaa16, "gpu_brushes_slices", resolved=r)
+
+    def clip_blend(e):
+        packed, layout = workloads.clip_blend_scene().resolve()
+        compare_frame(e, packed, layout, 256, 256, BLACK, AaConfig.Msaa8, "gpu_clips_slices")
+
+    def r1mix(e):
+        packed, layout = workloads.paris_like_scene().resolve()
+        compare_frame(e, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, "gpu_paris_slices", check_stages=False, back_half=False)
+
+    return [("tiger", tiger), ("random_clips", random_clips), ("brushes", brushes), ("clip_blend", clip_blend), ("r1mix", r1mix)]
+
+
+@pytest.mark.parametrize("name,body", _slice_cases(), ids=[c[0] for c in _slice_cases()])
+def test_fine_slices_forced(gpu_engine, name, body):
+    # fine's sliced path on the MI355X with EVERY tile cut into slices of 4 fills (VELLO_HIP_DEBUG_FINE_SLICES): the slices of a
+    # tile run on whatever CUs / XCDs the dispatcher picks, the last one to finish composites from the coverage scratch --
+    # the cross-workgroup hand-off the emulator cannot say anything about.  Images bit-exact against the oracle.
+    gpu_engine.set_debug_flags(fine_slices=True)
+    try:
+        body(gpu_engine)
+        assert name == "brushes" or gpu_engine.control_words()[24] > 0, "no tile was cut into slices"  # (brushes: < 5 fills per tile)
+    finally:
+        gpu_engine.set_debug_flags()
+
+
+def test_fine_slices_repeatable_across_frames_in_flight(built):
+    # 4 frames in flight, all tiles sliced: every lane has its own slice items / counters / coverage scratch, and 12 frames of
+    # the same scene must be the same image (a stale counter or a scratch shared between lanes would show)
+    import torch
+    import vello_amd
+
+    packed, layout = workloads.random_test_scene(5, n_paths=1200, size=640.0, strokes=True, clips=True).resolve()
+    eng = vello_amd.Engine()
+    eng.set_debug_flags(fine_slices=True)
+    eng.set_frames_in_flight(4)
+    eng.upload_scene(packed, layout)
+    targets = [torch.zeros((640, 640, 4), dtype=torch.uint8, device="cuda:0") for _ in range(12)]
+    torch.cuda.synchronize()
+    for t in targets:
+        eng.render_resident(640, 640, BLACK, AaConfig.Msaa16, out=t)
+    assert eng.sync() == 0
+    first = targets[0].cpu().numpy()
+    eng.set_debug_flags()
+    ref = torch.zeros((640, 640, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.render_resident(640, 640, BLACK, AaConfig.Msaa16, out=ref)
+    assert eng.sync() == 0
+    assert np.array_equal(first, ref.cpu().numpy())
+    for t in targets[1:]:
+        assert np.array_equal(first, t.cpu().numpy())

@@ -109,7 +109,7 @@ def test_rust_ffi_matches_the_c_header():
     assert rs["vello_hip_ctx"] == [("_private", "[u8; 0]")]
     for k, v in rc.items():
         assert cc.get(k) == v, f"constant {k}: header {cc.get(k)} vs shim {v}"
-    for k in ("VELLO_HIP_AA_AREA", "VELLO_HIP_AA_MSAA16", "VELLO_HIP_E_CAPACITY", "VELLO_HIP_DEBUG_NO_CULL", "VELLO_HIP_DEBUG_STROKE_KERNEL", "VELLO_HIP_DEBUG_SEQ_CLIP", "VELLO_HIP_DEBUG_FINE_PIPELINE", "VELLO_HIP_STAGE_COUNT"):
+    for k in ("VELLO_HIP_AA_AREA", "VELLO_HIP_AA_MSAA16", "VELLO_HIP_E_CAPACITY", "VELLO_HIP_DEBUG_NO_CULL", "VELLO_HIP_DEBUG_STROKE_KERNEL", "VELLO_HIP_DEBUG_SEQ_CLIP", "VELLO_HIP_DEBUG_FINE_SLICES", "VELLO_HIP_STAGE_COUNT"):
         assert k in rc
 
 

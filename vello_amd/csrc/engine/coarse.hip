@@ -189,7 +189,9 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
 __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
                                                 const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
                                                 const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
-                                                uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order) {
+                                                uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order,
+                                                SliceItem *slice_items, uint32_t *slice_counters, uint32_t slice_cap, uint32_t cov_cap,
+                                                uint32_t slice_fills, uint32_t slice_min_fills) {
 #ifdef VELLO_SIMT_EMU
     __shared__ CoarseLds sh;
 #else
@@ -246,6 +248,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     uint32_t room = INITIAL_ROOM;    // words left in the current region in front of its two-word tail
     bool dead = false;               // the tile's list ran out of PTCL pool: nothing more is written
     uint32_t words_total = 0u;       // command words of the tile's list so far
+    uint32_t fills_total = 0u;       // CMD_FILLs among them
     uint32_t clip_zero_depth = 0u, clip_depth = 0u, render_blend_depth = 0u, max_blend_depth = 0u;
 
     // ---- the bin's element stream: bin headers merged PART_CHUNK partitions at a time (coarse.wgsl:218-263) ----
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             sh.em[wave][lane][0] = (uint32_t)em; sh.em[wave][lane][1] = (uint32_t)(em >> 32);
             sh.gm[wave][lane][0] = (uint32_t)gmask; sh.gm[wave][lane][1] = (uint32_t)(gmask >> 32);
             sh.pend[wave][lane] = pair_incl;
-            sh.S[wave][lane] = words_of(em, gmask, k1, k2, k3);
+            sh.S[wave][lane] = words_of(em, gmask, k1, k2, k3) | (popc64(gmask) << 16);  // (<= 448 words, <= 64 fills)
             wave_lds_sync();
             const uint32_t n_iter = (total_pairs + 63u) / 64u;
             // pair p of the slice, tile-major: which tile, which object, does it have segments
@@ -571,18 +574,22 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             // ALLOCATE (wave 0, lane = tile): one PTCL region per tile that needs one behind ONE atomic; the command sizes
             // follow from the bitmaps alone, so no Tile has been read yet
             if (wave == 0u) {
-                uint32_t s_w[NW], W = 0u;
+                uint32_t s_w[NW], W = 0u, n_fill = 0u;
 #pragma unroll
                 for (uint32_t w = 0; w < NW; w++) {
-                    s_w[w] = sh.S[w][lane];
+                    const uint32_t s = sh.S[w][lane];
+                    s_w[w] = s & 0xffffu;
                     W += s_w[w];
+                    n_fill += s >> 16;
                 }
                 if (tile_killed && !dead) {  // everything emitted so far is covered: restart the list in the tile's own block
                     cur = list_start;
                     room = INITIAL_ROOM;
                     words_total = 0u;
+                    fills_total = 0u;
                 }
                 words_total += W;
+                fills_total += n_fill;
                 const bool need = W > room && !dead;
                 const uint32_t rsize = need ? W + 2u + REGION_SLACK : 0u;
                 const uint32_t r_incl = wave_incl_scan_u32(rsize, (int)lane);
@@ -701,7 +708,32 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
         // ... and the tile's index in the bucket of its length class, so that long lists are started first (one atomic
         // per bucket and workgroup: 10 000 tiles bumping eight counters one by one cost the kernel 50 us)
         const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
-        const uint32_t bucket = in_target ? minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5)))) : NONE;
+        uint32_t bucket = in_target ? minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5)))) : NONE;
+        // A long list (MSAA modes) is cut into slices of slice_fills FILLs, each a work item of fine's that comes before all
+        // unsliced tiles; the tile then stays out of the buckets.  One atomic per counter and workgroup; a tile whose slices or
+        // coverage scratch do not fit is rendered unsliced, its place in the item array marked as a hole.
+        uint32_t n_sl = 0u;
+        if (in_target && !dead && slice_min_fills != 0u && fills_total >= slice_min_fills) n_sl = minu((fills_total + slice_fills - 1u) / slice_fills, 0xffffu);
+        if (__ballot(n_sl != 0u) != 0ull) {
+            const uint32_t cov_need = n_sl != 0u ? n_sl * slice_fills * 64u + 64u : 0u;  // 64 words per FILL + one fill of slack
+            const uint32_t it_incl = wave_incl_scan_u32(n_sl, (int)lane), cv_incl = wave_incl_scan_u32(cov_need, (int)lane);
+            uint32_t it_base = 0u, cv_base = 0u;
+            if (lane == 63u) {
+                it_base = atomicAdd(&work_count[FINE_WORK_BUCKETS], it_incl);      // Control::slice_items
+                cv_base = atomicAdd(&work_count[FINE_WORK_BUCKETS + 1u], cv_incl);  // Control::cov_words
+            }
+            it_base = (uint32_t)__shfl((int)it_base, 63) + (it_incl - n_sl);
+            cv_base = (uint32_t)__shfl((int)cv_base, 63) + (cv_incl - cov_need);
+            if (n_sl != 0u) {
+                const bool fits = it_base + n_sl <= slice_cap && it_base + n_sl >= it_base && cv_base + cov_need <= cov_cap && cv_base + cov_need >= cv_base;
+                for (uint32_t k = 0; k < n_sl && it_base + k < slice_cap && it_base + k >= it_base; k++)
+                    slice_items[it_base + k] = SliceItem{fits ? this_tile_ix : ~0u, k | (n_sl << 16), cv_base, it_base};
+                if (fits) {
+                    slice_counters[it_base] = 0u;
+                    bucket = NONE;
+                }
+            }
+        }
         for (uint32_t bk = 0; bk < FINE_WORK_BUCKETS; bk++) {
             const u64 m = __ballot(bucket == bk);
             if (m == 0ull) continue;
@@ -744,7 +776,8 @@ void launch_coarse(const Frame &f, hipStream_t s) {
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
-                       f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order);
+                       f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,
+                       f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills);
 }
 
 }  // namespace vk

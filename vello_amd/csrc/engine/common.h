@@ -219,6 +219,47 @@ __device__ __forceinline__ uint32_t lane_value(uint32_t v) {
 #endif
 }
 
+// A pointer known to point to global memory.  Through the parameter of an out-of-line function a pointer is generic, its
+// loads are FLAT instructions, and a flat load counts on lgkmcnt as well as vmcnt: the counter that cannot be waited for
+// out of order -- using the oldest of sixteen loads in flight waits for all sixteen.
+#ifdef VELLO_SIMT_EMU
+#define VK_GLOBAL
+#else
+#define VK_GLOBAL __attribute__((address_space(1)))
+#endif
+template <typename T>
+__device__ __forceinline__ const VK_GLOBAL T *as_global(const T *p) {
+    return (const VK_GLOBAL T *)p;
+}
+
+// The value, with its origin hidden from the optimiser: arithmetic on a loop-invariant (the lane number, say) is hoisted out
+// of the loop and, when registers are short, SPILLED to scratch and reloaded -- dearer by far than the one or two VALU
+// operations it saves.  What is derived from opaque(x) inside a loop stays there.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) {
+#ifndef VELLO_SIMT_EMU
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// v of lane `src` (0..63), any lane per lane: ds_bpermute with the byte address src * 4.  (hip's __shfl also folds its
+// `width` argument in -- a lane-id v_mbcnt the compiler hoists out of every loop and then spills.)
+__device__ __forceinline__ uint32_t wave_shfl(uint32_t v, uint32_t src) {
+#ifdef VELLO_SIMT_EMU
+    return (uint32_t)__shfl((int)v, (int)src);
+#else
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v);
+#endif
+}
+// v of the lane `src`, the same for every lane (a scalar): v_readlane
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, uint32_t src) {
+#ifdef VELLO_SIMT_EMU
+    return (uint32_t)__shfl((int)v, (int)src);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)src));
+#endif
+}
+
 // number of set bits of a (wave-uniform) 64-bit mask below this lane: v_mbcnt_lo / _hi on the GPU
 __device__ __forceinline__ uint32_t mask_rank_below(unsigned long long m, uint32_t lane) {
 #ifdef VELLO_SIMT_EMU

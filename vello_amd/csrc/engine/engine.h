@@ -30,6 +30,18 @@ constexpr uint32_t FINE_WORK_BUCKETS = 8;
 constexpr uint32_t FLATTEN_STROKE_KERNEL_MIN_LINES = 2u * 256u * 12u * 64u;
 // command words from which a tile counts as long: its wave raises its issue priority (s_setprio) in k_fine
 constexpr uint32_t FINE_HEAVY_WORDS = 384;
+// fine, MSAA modes: a tile whose list holds >= FINE_SLICE_MIN_FILLS FILLs is cut into slices of FINE_SLICE_FILLS fills; every
+// slice is a work item of its own (one wave computes the coverage of its fills into the coverage scratch), and the wave that
+// finishes a tile's last slice composites the tile from the scratch (fine.hip).  k_fine's launch is as long as its longest
+// tile's chain of fills otherwise (d2: 137 fills, 258 us against 117 us of balanced work).
+constexpr uint32_t FINE_SLICE_FILLS = 32, FINE_SLICE_MIN_FILLS = 96;
+constexpr uint32_t FINE_SLICE_FILLS_FORCED = 4, FINE_SLICE_MIN_FILLS_FORCED = 5;  // VELLO_HIP_DEBUG_FINE_SLICES
+struct SliceItem {
+    uint32_t tile_ix;     // ~0: a hole left by a tile whose slices did not fit the capacity
+    uint32_t k_and_n;     // slice | slices of the tile << 16
+    uint32_t cov_base;    // first word of the tile's coverage scratch: 64 words (one byte per pixel) per FILL
+    uint32_t first_item;  // index of the tile's first item: its arrival counter is slice_counters[first_item]
+};
 // clip matching (clip.hip): clips per partition (a thread each) and the most partitions the one-workgroup stack pass holds
 // in LDS; beyond CLIP_PART * CLIP_MAX_PARTS clips the one-wave stack machine (draw.hip) runs instead
 constexpr uint32_t CLIP_PART = 256;
@@ -58,7 +70,9 @@ struct Control {
     uint32_t heavy_count[3];  // flatten: tags queued by k_flatten_light: [0] fill curves, [1] strokes, [2] stroked lines
     uint32_t pad[3];
     uint32_t work_count[FINE_WORK_BUCKETS];  // coarse -> fine: tiles per bucket of command-list length (k_fine runs the long ones first)
-    uint32_t pad2[16 - FINE_WORK_BUCKETS];
+    uint32_t slice_items;   // coarse -> fine: SliceItems handed out (may run past the capacity: fine clamps); work_count[BUCKETS]
+    uint32_t cov_words;     // coarse -> fine: words of the coverage scratch handed out
+    uint32_t pad2[16 - FINE_WORK_BUCKETS - 2];
 };
 static_assert(sizeof(Control) == 128, "Control");
 
@@ -92,6 +106,11 @@ struct Frame {
     uint32_t *tile_bits;     // coarse: three bit planes over the tile pool (segments present / backdrop zero / backdrop even)
     uint32_t tile_bits_plane_words;
     uint32_t *tile_order;    // coarse -> fine: [bucket][n_tiles] tile indices, filled up to control->work_count[bucket]
+    SliceItem *slice_items;  // coarse -> fine: the slices of the long tiles (MSAA modes), slice_cap entries
+    uint32_t *slice_counters;  // per first item: slices of the tile that have finished
+    uint32_t *cov;           // fine: coverage scratch of the sliced tiles, cov_cap words
+    uint32_t slice_cap, cov_cap;
+    uint32_t slice_fills, slice_min_fills;  // 0 / 0: no slicing (area AA)
     uint32_t *clip_stack;  // clip_scratch_words(n_clips): scratch of the partitioned clip kernels / spill area of the sequential one
     uint8_t *output;
     size_t out_stride;
@@ -102,7 +121,6 @@ struct Frame {
     uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which k_flatten_strokes takes them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that k_flatten_strokes would exit at once
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
-    bool fine_pipeline;  // VELLO_HIP_DEBUG_FINE_PIPELINE: k_fine_pipe (two waves per tile) for the MSAA modes
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;

@@ -46,6 +46,7 @@ struct SceneSlot {
     // stroked-line tags of the scene as k_flatten_light counted them in an earlier frame (-1: not known yet).  A property of
     // the scene alone; lets the host leave out a k_flatten_strokes launch that would exit at once.
     int64_t stroke_lines = -1;
+    int64_t slice_demand = -1;  // slice items coarse asked for in a finished MSAA frame of this scene (max seen), -1 unknown
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
 };
 
@@ -59,6 +60,7 @@ struct Lane {
     DevBuf coarse_el;                 // coarse: CoarseEl per draw object
     DevBuf tile_bits;                 // coarse: 3 bit planes over the tile pool
     DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
+    DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
     DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
     struct EvPair {
         int stage;
@@ -66,6 +68,7 @@ struct Lane {
     };
     std::vector<EvPair> events;
     bool used = false;
+    bool slices_on = false;   // the lane's latest frame ran with fine's slices enabled (an MSAA frame)
     bool flatten_ran = false;  // the control block holds flatten's counts (a partial vello_hip_run_stages range may stop before it)
     uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
     uint64_t atlas_epoch_seen = 0;  // ctx::atlas_epoch the lane's stream has been ordered behind
@@ -201,6 +204,10 @@ int acquire_staging(vello_hip_ctx *c, size_t bytes, Staging *&out) {
     return 0;
 }
 
+// fine's coverage scratch (sliced tiles): 64 words per FILL of a sliced tile.  A FILL is >= 5 command words, so 2 x the
+// PTCL pool holds the fills of lists that add up to a sixth of the pool; tiles that do not fit are rendered unsliced.
+uint32_t cov_cap_words(const vello_hip_capacities &d) { return d.ptcl > 0x7fffffffu ? 0xfffffff0u : d.ptcl * 2u; }
+
 // words of one coarse bit plane: 2 per 64 tiles + 2 of slack for the 64-bit windows read at the last tiles
 uint32_t tile_bits_plane_words(uint32_t tiles) { return (tiles + 63u) / 64u * 2u + 2u; }
 
@@ -217,6 +224,7 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
     if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_plane_words(d.tiles) * 3u * 4u))) return r;
+    if ((r = ensure(c, l.cov, (size_t)cov_cap_words(d) * 4u))) return r;
     return 0;
 }
 
@@ -224,7 +232,7 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
 size_t pool_bytes(const vello_hip_capacities &d) {
     return (size_t)d.lines * sizeof(LineSoup) + (size_t)d.bin_data * 4u + (size_t)d.tiles * sizeof(Tile) +
            (size_t)d.seg_counts * sizeof(SegmentCount) + (size_t)d.segments * sizeof(Segment) + (size_t)d.blend_spill * 4u +
-           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u;
+           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u + (size_t)cov_cap_words(d) * 4u;
 }
 
 // Makes `d` the context's capacities, or leaves the context as it was: ensure() frees a buffer before it allocates the
@@ -256,7 +264,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     int r;
     if ((r = ensure(c, l.zero_region, sc.zero_bytes))) return r;
     l.buf[VELLO_HIP_BUF_BUMP].ptr = l.zero_region.ptr;
-    l.buf[VELLO_HIP_BUF_BUMP].size = sizeof(Bump);
+    l.buf[VELLO_HIP_BUF_BUMP].size = sizeof(Control);  // (vello_hip_read_buffer: the bump allocators first, then the engine's own counters)
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(sc.n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATH_BBOXES], (size_t)(L.n_paths + 1u) * sizeof(PathBbox)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_DRAW_MONOIDS], (size_t)(L.n_draw_objects + 1u) * sizeof(DrawMonoid)))) return r;
@@ -349,6 +357,17 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
     if (!out_device && (r = ensure(c, l.buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
     if ((r = ensure(c, l.tile_order, (size_t)f.cfg.width_in_tiles * f.cfg.height_in_tiles * FINE_WORK_BUCKETS * 4u))) return r;
+    // fine launches one (at once exiting) workgroup per slice item it MIGHT be given in front of the tiles' workgroups:
+    // as many as the scene asked for in an earlier frame (+ 1/8), a quarter of the tiles while that is unknown.  Coarse
+    // cuts a tile into slices only if its items fit (the rest are rendered unsliced), so any number is correct.
+    const uint32_t n_tiles_target = f.cfg.width_in_tiles * f.cfg.height_in_tiles;
+    if ((r = ensure(c, l.slice_items, (size_t)n_tiles_target * sizeof(SliceItem)))) return r;
+    if ((r = ensure(c, l.slice_counters, (size_t)n_tiles_target * 4u))) return r;
+    {
+        uint64_t want = sc.slice_demand < 0 ? n_tiles_target / 4u : (uint64_t)sc.slice_demand + (uint64_t)sc.slice_demand / 8u + 16u;
+        if (want < 64u) want = 64u;
+        f.slice_cap = want > n_tiles_target ? n_tiles_target : (uint32_t)want;
+    }
     // kernels take the ConfigUniform by value (kernarg); the device copy only serves the test seam
     if (upload_cfg) HIP_TRY(c, hipMemcpy(c->config.ptr, &f.cfg, sizeof(Config), hipMemcpyHostToDevice));
     f.n_tag_words = sc.n_tag_words;
@@ -378,6 +397,17 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.tile_bits = (uint32_t *)l.tile_bits.ptr;
     f.tile_bits_plane_words = tile_bits_plane_words(c->caps.tiles);
     f.tile_order = (uint32_t *)l.tile_order.ptr;
+    f.slice_items = (SliceItem *)l.slice_items.ptr;
+    f.slice_counters = (uint32_t *)l.slice_counters.ptr;
+    f.cov = (uint32_t *)l.cov.ptr;
+    f.cov_cap = cov_cap_words(c->caps);
+    f.slice_fills = f.slice_min_fills = 0u;
+    l.slices_on = p->aa != 0u;
+    if (p->aa != 0u) {
+        const bool forced = (c->debug_flags & VELLO_HIP_DEBUG_FINE_SLICES) != 0u;
+        f.slice_fills = forced ? FINE_SLICE_FILLS_FORCED : FINE_SLICE_FILLS;
+        f.slice_min_fills = forced ? FINE_SLICE_MIN_FILLS_FORCED : FINE_SLICE_MIN_FILLS;
+    }
     f.heavy_list = (uint32_t *)l.heavy_list.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
@@ -391,7 +421,6 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
-    f.fine_pipeline = (c->debug_flags & VELLO_HIP_DEBUG_FINE_PIPELINE) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;
@@ -617,6 +646,8 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.coarse_el.ptr) (void)hipFree(l.coarse_el.ptr);
         if (l.tile_bits.ptr) (void)hipFree(l.tile_bits.ptr);
         if (l.tile_order.ptr) (void)hipFree(l.tile_order.ptr);
+        for (DevBuf *b : {&l.slice_items, &l.slice_counters, &l.cov})
+            if (b->ptr) (void)hipFree(b->ptr);
         if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
@@ -692,6 +723,7 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
     sc.brushes = false;
     sc.stroke_lines = -1;
+    sc.slice_demand = -1;
     sc.generation += 1u;
     {
         // The same pass checks what draw_leaf / clip_leaf will index with (shared/drawtag.wgsl:47-54: bit 0 = clip,
@@ -873,10 +905,14 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
     Lane &l = c->lanes[(c->last_lane + n - age) % n];
     HIP_TRY(c, hipStreamSynchronize(l.stream));
     // (once per scene: what flatten counted, so that later frames can leave out a launch that would exit at once)
-    if (l.used && l.flatten_ran && l.zero_region.ptr && slot_of(c, l).stroke_lines < 0 && l.frame_generation == slot_of(c, l).generation) {
+    SceneSlot &sc = slot_of(c, l);
+    if (l.used && l.flatten_ran && l.zero_region.ptr && l.frame_generation == sc.generation && (sc.stroke_lines < 0 || (l.slices_on && sc.slice_demand < 0))) {
         Control ctl;
         HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
-        if (ctl.bump.failed == 0u) slot_of(c, l).stroke_lines = (int64_t)ctl.heavy_count[2];
+        if (ctl.bump.failed == 0u) {
+            sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
+        }
     }
     return VELLO_HIP_OK;
 }
@@ -892,7 +928,10 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
     std::memcpy(&b, &ctl.bump, sizeof b);
     if (b.failed == 0u) {
         SceneSlot &sc = slot_of(c, l);
-        if (l.flatten_ran && l.frame_generation == sc.generation) sc.stroke_lines = (int64_t)ctl.heavy_count[2];  // (flatten ran to its end)
+        if (l.flatten_ran && l.frame_generation == sc.generation) {  // (flatten ran to its end)
+            sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
+        }
         return VELLO_HIP_OK;
     }
     if ((b.failed & FAILED_SCENE) != 0u) {
@@ -1018,6 +1057,10 @@ int vello_hip_gather_wait(vello_hip_ctx *const *ctxs, uint32_t n) {
 
 int vello_hip_set_debug_flags(vello_hip_ctx *c, uint32_t flags) {
     if (!c) return VELLO_HIP_E_INVALID;
+    if ((c->debug_flags ^ flags) & VELLO_HIP_DEBUG_FINE_SLICES) {  // what earlier frames asked for says nothing about the other slice size
+        c->shared.slice_demand = -1;
+        for (auto &l : c->lanes) l.own.slice_demand = -1;
+    }
     c->debug_flags = flags;
     return VELLO_HIP_OK;
 }

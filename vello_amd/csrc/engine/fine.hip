@@ -72,6 +72,34 @@ struct FineProf {
 };
 #endif
 
+// Measurement build only (EXTRA=-DVELLO_FINE_TIMELINE, scripts/fine_timeline.py): every wave of k_fine logs when it started
+// and ended (wall clock, 100 MHz), where it ran (HW_ID) and what it was (tile / slice / slice + compositing pass) into the
+// tail of the blend-spill pool: the occupancy of the chip over the launch.  Nothing without the macro.
+#ifdef VELLO_FINE_TIMELINE
+constexpr uint32_t TL_MAX = 40000u;
+struct FineTimeline {
+    uint32_t t0;
+    __device__ __forceinline__ void start() { t0 = (uint32_t)wall_clock64(); }
+    __device__ __forceinline__ void log(uint32_t *blend_spill, uint32_t blend_size, uint32_t lane, uint32_t kind, uint32_t fills, uint32_t tile_ix) {
+        if (blend_size < 6u * TL_MAX + 1u || lane != 0u) return;
+        const uint32_t slot = atomicAdd(&blend_spill[blend_size - 1u], 1u);
+        if (slot >= TL_MAX) return;
+        uint32_t *dst = blend_spill + (blend_size - 1u - 6u * TL_MAX) + slot * 6u;
+        dst[0] = t0;
+        dst[1] = (uint32_t)wall_clock64();
+        dst[2] = __builtin_amdgcn_s_getreg((23 << 0) | (0 << 6) | (31 << 11));  // HW_ID, all 32 bits
+        dst[3] = kind | (fills << 8);
+        dst[4] = tile_ix;
+        dst[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
+};
+#else
+struct FineTimeline {
+    __device__ __forceinline__ void start() {}
+    __device__ __forceinline__ void log(uint32_t *, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {}
+};
+#endif
+
 struct vec4 {
     float x, y, z, w;
 };
@@ -201,12 +229,18 @@ constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP
 
 struct FineBatch {
     uint32_t item[MS_ITEM_CAP];
-    uint32_t seg_slot[64];                     // fill slot of each staged segment
+    uint32_t seg_slot[64];                     // scratch of the slot-source scatter (lane numbers of the kept fills by rank)
     uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
-    uint32_t item_end[MS_BATCH_FILLS + 1u];    // item range of slot k = [item_end[k], item_end[k + 1])
-    uint32_t rule_backdrop[MS_BATCH_FILLS][2];
     uint32_t color[MS_BATCH_FILLS];            // the CMD_COLOR word behind slot k's FILL (valid for the slots of the regular prefix)
 };
+// What a staged fill's replay needs besides its records lives in two registers of lane `slot` (read with v_readlane, no
+// LDS round trip at the head of every fill): its record range [begin, end) and fill rule, packed, and its backdrop.
+struct SlotRegs {
+    uint32_t pack;      // begin | end << 10 | even_odd << 20
+    uint32_t backdrop;
+};
+constexpr uint32_t SLOT_END_SHIFT = 10u, SLOT_EO_SHIFT = 20u, SLOT_IX_MASK = 0x3ffu;
+static_assert(MS_ITEM_CAP <= SLOT_IX_MASK, "record indices are packed in 10 bits");
 
 // fine.wgsl:222-330 computes, for every pixel crossing, the line setup of its segment and then the crossing itself.
 // The setup (one IEEE division, the robustness fix-up, the LUT row) depends on the segment alone: ms_setup runs once
@@ -514,11 +548,12 @@ __device__ void fill_path_ms(FineShared &sh, uint32_t *sh_samples, const Segment
 // `n_fast` / `after_fast`: the batch's REGULAR PREFIX -- the list from cmd_ix on reads FILL, COLOR, FILL, COLOR, ... for the
 // first n_fast staged fills (what coarse emits for a run of solid-colour paths): the caller replays those slots in a loop of
 // its own, blends bt.color[slot] and goes on at after_fast, without a trip round the interpreter per command.
-template <int AA, bool WANT_AFTER_FIT = false>
+template <int AA>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
-                                   uint32_t lane, uint32_t &after_batch, FineProf &pf, uint32_t &n_fast, uint32_t &after_fast,
-                                   uint32_t *after_fit = nullptr) {
+                                   uint32_t lane_in, uint32_t &after_batch, FineProf &pf, uint32_t &n_fast, uint32_t &after_fast,
+                                   SlotRegs &slots) {
+    const uint32_t lane = opaque(lane_in);  // (the LDS addresses and lane tests below are recomputed per batch, not held)
     n_fast = 0u;
     after_fast = 0u;
     // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
@@ -537,13 +572,13 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     uint32_t pos = s0;
 #pragma unroll
     for (uint32_t bit = 0; bit < 6u; bit++) {
-        const uint32_t hop = (uint32_t)__shfl((int)jump, (int)pos);
+        const uint32_t hop = wave_shfl(jump, pos);
         if ((lane >> bit) & 1u) pos = hop;
-        jump = (uint32_t)__shfl((int)jump, (int)jump);
+        jump = wave_shfl(jump, jump);
     }
     // lane k: the k-th command of the list sits at `pos`
-    const uint32_t tag_k = (uint32_t)__shfl((int)win, (int)pos);
-    const uint32_t rule_k = (uint32_t)__shfl((int)win, (int)minu(pos + 1u, 63u));
+    const uint32_t tag_k = wave_shfl(win, pos);
+    const uint32_t rule_k = wave_shfl(win, minu(pos + 1u, 63u));
     bool is_fill = tag_k == CMD_FILL && pos <= 60u;
     const uint32_t segs_k = is_fill ? rule_k >> 1 : 0u;
     const uint32_t seg_incl = wave_incl_scan_u32(segs_k, (int)lane);
@@ -569,11 +604,11 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         wave_lds_sync();
         if (lane < n) src = bt.seg_slot[lane];
     }
-    const uint32_t src_pos = (uint32_t)__shfl((int)pos, (int)src);
-    uint32_t my_rule_n = (uint32_t)__shfl((int)win, (int)minu(src_pos + 1u, 63u));
-    uint32_t my_seg_data = (uint32_t)__shfl((int)win, (int)minu(src_pos + 2u, 63u));
-    uint32_t my_backdrop = (uint32_t)__shfl((int)win, (int)minu(src_pos + 3u, 63u));
-    uint32_t my_seg_start = (uint32_t)__shfl((int)(seg_incl - segs_k), (int)src);
+    const uint32_t src_pos = wave_shfl(pos, src);
+    uint32_t my_rule_n = wave_shfl(win, minu(src_pos + 1u, 63u));
+    uint32_t my_seg_data = wave_shfl(win, minu(src_pos + 2u, 63u));
+    uint32_t my_backdrop = wave_shfl(win, minu(src_pos + 3u, 63u));
+    uint32_t my_seg_start = wave_shfl(seg_incl - segs_k, src);
     if (lane >= n) {
         my_rule_n = 0u; my_seg_data = 0u; my_backdrop = 0u; my_seg_start = 0u;
     }
@@ -584,20 +619,18 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         const unsigned long long bad = __ballot(!ok);
         pairs = (bad ? (uint32_t)__ffsll((long long)bad) - 1u : 64u) >> 1;
     }
-    const uint32_t color_pos = (uint32_t)__shfl((int)pos, (int)minu(2u * lane + 1u, 63u));
-    const uint32_t my_color = (uint32_t)__shfl((int)win, (int)minu(color_pos + 1u, 63u));
+    const uint32_t color_pos = wave_shfl(pos, minu(2u * lane + 1u, 63u));
+    const uint32_t my_color = wave_shfl(win, minu(color_pos + 1u, 63u));
     // segments of the kept fills: the inclusive count at the last kept fill
     uint32_t tot_segs = 0u;
-    if (n != 0u) tot_segs = (uint32_t)__shfl((int)seg_incl, 63 - __clzll((long long)fills));
+    if (n != 0u) tot_segs = wave_read(seg_incl, (uint32_t)(63 - __clzll((long long)fills)));
     if (n == 0u) return 0u;
     // the word behind the last FILL seen: where the caller points its window prefetch (if fewer fills fit, the prefetch
     // is simply not used)
-    after_batch = win_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pos, 63 - __clzll((long long)fills))) + 4u;
+    after_batch = win_base + wave_read(pos, (uint32_t)(63 - __clzll((long long)fills))) + 4u;
     wave_lds_sync();
     if (lane < n) {
         const bool eo = (my_rule_n & 1u) != 0u;
-        bt.rule_backdrop[lane][0] = my_rule_n;
-        bt.rule_backdrop[lane][1] = my_backdrop;
         bt.color[lane] = my_color;
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
@@ -609,18 +642,17 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
 #pragma unroll
     for (uint32_t step = 8u; step >= 1u; step >>= 1) {
         const uint32_t probe = slot + step;
-        const uint32_t st = (uint32_t)__shfl((int)my_seg_start, (int)minu(probe, 63u));
+        const uint32_t st = wave_shfl(my_seg_start, minu(probe, 63u));
         if (probe < n && st <= lane) slot = probe;
     }
-    const uint32_t seg_data = (uint32_t)__shfl((int)my_seg_data, (int)slot);
-    const uint32_t seg_start = (uint32_t)__shfl((int)my_seg_start, (int)slot);
-    const uint32_t rule = (uint32_t)__shfl((int)my_rule_n, (int)slot);
+    const uint32_t seg_data = wave_shfl(my_seg_data, slot);
+    const uint32_t seg_start = wave_shfl(my_seg_start, slot);
+    const uint32_t rule = wave_shfl(my_rule_n, slot);
     wave_lds_sync();
     pf.mark(FP_BATCH_SCAN);
     uint32_t count = 0u;
     if (lane < tot_segs) {
         Segment sg = segments[seg_data + (lane - seg_start)];
-        bt.seg_slot[lane] = slot;
         count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
         const MsSetup su = ms_setup<AA>(sg, (rule & 1u) != 0u);
         sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.xy0y[lane] = su.xy0y; sh.su.xy1y[lane] = su.xy1y;
@@ -628,22 +660,25 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     }
     uint32_t incl = wave_incl_scan_u32(count, (int)lane);
     // item range ends per slot: the inclusive count at the slot's last segment (or the previous end for empty fills)
+    uint32_t my_end;
     {
         const uint32_t last_seg = my_seg_start + (my_rule_n >> 1);  // one past the slot's last staged segment (0 for lanes >= n)
-        const uint32_t end = (uint32_t)__shfl(incl, (int)(last_seg ? last_seg - 1u : 0u));
-        if (lane < n) bt.item_end[lane + 1u] = last_seg ? end : 0u;
-        if (lane == 0u) bt.item_end[0] = 0u;
+        const uint32_t end = wave_shfl(incl, last_seg ? last_seg - 1u : 0u);
+        my_end = last_seg ? end : 0u;
     }
-    wave_lds_sync();
     // keep only the fills whose records fit
-    const unsigned long long fits = __ballot(lane < n && bt.item_end[lane + 1u] <= MS_ITEM_CAP);  // (ends are non-decreasing)
+    const unsigned long long fits = __ballot(lane < n && my_end <= MS_ITEM_CAP);  // (ends are non-decreasing)
     const uint32_t n_fit = fits ? 64u - (uint32_t)__clzll((long long)fits) : 0u;
     if (n_fit == 0u) return 0u;
-    // (two waves per tile: the builder goes on behind the last fill it STAGED, which may lie before the last one it saw)
-    if constexpr (WANT_AFTER_FIT) *after_fit = win_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)src_pos, (int)(n_fit - 1u))) + 4u;
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[n_fit]);
+    const uint32_t total = wave_read(my_end, n_fit - 1u);
+    {
+        uint32_t my_begin = wave_shfl(my_end, lane - 1u & 63u);  // (only lanes < 12 matter)
+        if (lane == 0u) my_begin = 0u;
+        slots.pack = (my_begin & SLOT_IX_MASK) | ((my_end & SLOT_IX_MASK) << SLOT_END_SHIFT) | ((my_rule_n & 1u) << SLOT_EO_SHIFT);
+        slots.backdrop = my_backdrop;
+    }
     n_fast = minu(n_fit, pairs);
-    if (n_fast != 0u) after_fast = win_base + (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)pos, (int)(2u * n_fast - 1u))) + 2u;
+    if (n_fast != 0u) after_fast = win_base + wave_read(pos, 2u * n_fast - 1u) + 2u;
     pf.mark(FP_BATCH_SEGS);
     pf.count(FP_N_ITEMS, total);
     // Which segment owns record i?  fine.wgsl searches the scanned counts per record (six dependent LDS reads).  Here every
@@ -729,15 +764,21 @@ __device__ __forceinline__ float ms_pixel_area(uint32_t ez, uint32_t samples0, u
 // clean for the next fill without a clearing pass (`clean` tracks that across fills; the even-odd and the
 // one-fill-at-a-time paths clear for themselves and leave the counters dirty).  Two records on one pixel compute and
 // store the same value.  Same integer operations on the same counter values as the dense resolve: bit-identical.
+// `pre` / `pre_begin`: the records [pre_begin, pre_begin + 64) as the PREVIOUS fill requested them while it worked (one
+// LDS round trip less at the head of this fill's chain); ~0 when nothing was requested.  On return they describe the
+// request made for the fill that follows.
 template <int AA>
-__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, uint32_t lane, float (&area)[4],
-                                   bool &clean, FineProf &pf) {
+__device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, const SlotRegs &slots, uint32_t lane,
+                                   float (&area)[4], bool &clean, uint32_t &pre, uint32_t &pre_begin, FineProf &pf) {
     constexpr uint32_t SWPP = AA == 2 ? 4u : 2u;
     // (uniform values: in scalar registers the rule's branches are real branches, not lane masks)
-    const bool even_odd = ((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][0]) & 1u) != 0u;
-    const int32_t backdrop = __builtin_amdgcn_readfirstlane((int)bt.rule_backdrop[slot][1]);
-    const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot]);
-    const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)bt.item_end[slot + 1u]);
+    const uint32_t pack = (uint32_t)__builtin_amdgcn_readlane((int)slots.pack, (int)slot);
+    const int32_t backdrop = __builtin_amdgcn_readlane((int)slots.backdrop, (int)slot);
+    const bool even_odd = ((pack >> SLOT_EO_SHIFT) & 1u) != 0u;
+    const uint32_t begin = pack & SLOT_IX_MASK, end = (pack >> SLOT_END_SHIFT) & SLOT_IX_MASK;
+    const uint32_t had = pre, had_begin = pre_begin;
+    pre = bt.item[minu(end + lane, MS_ITEM_CAP - 1u)];  // the next fill's records start where this one's end
+    pre_begin = end;
     if (even_odd) {
         wave_lds_sync();
         ms_clear(sh, sh_samples, true, lane, SWPP);
@@ -759,7 +800,9 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     const bool one_round = end - begin <= 64u;
     uint32_t rec0 = 0u;
     if (one_round) {
-        if (begin + lane < end) rec0 = bt.item[begin + lane];
+        if (had_begin == begin) rec0 = had;
+        else rec0 = bt.item[minu(begin + lane, MS_ITEM_CAP - 1u)];
+        if (begin + lane >= end) rec0 = 0u;
         ms_apply<AA>(rec0, false, sh.winding, sh_samples);  // (a zero record does nothing)
     } else {
         for (uint32_t i = begin + lane; i < end; i += 64u) ms_apply<AA>(bt.item[i], false, sh.winding, sh_samples);
@@ -1314,6 +1357,175 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
     st.cmd_ix = cmd_ix;
 }
 
+// The compositing pass of a sliced tile (k_fine, FINE_SLICE_FILLS): the tile's whole list once more, every FILL's
+// coverage read back from the coverage scratch (a byte per pixel, the number of covered samples).  Out of line, called
+// once per sliced tile by the wave that finished the tile's last slice -- and the only thing left of the launch's longest
+// tiles by then, so what counts is instructions per FILL: a wave pays ~4 ns per instruction whatever it is.
+//  * Runs of FILL, COLOR pairs (what a run of solid-colour paths is) are found with ONE parallel scan per 64-word window
+//    (next-command pointers doubled over the lanes, as ms_build_batch does); lane j unpacks the colour of pair j once, and
+//    the loop over the pairs is a coverage read, four v_readlane and the blend: ~45 instructions per FILL against ~260
+//    through a scalar interpreter that decodes every word with readlane.
+//  * The window behind the run is requested before the run is composited.
+//  * Coverage comes in chunks of COV_CHUNK FILLs: while one chunk is composited out of LDS (the wave's sample counters
+//    are idle in this pass), the loads of the next are in flight into registers nothing touches until the hand-over.
+//    (Agent-scope loads: they see what the slices' waves wrote through.  One load a fill ahead made the pass as long as
+//    its fills' memory round trips; a register ring rotated per fill waits for every load it moves; through a generic
+//    pointer the loads are FLAT and any wait for one waits for all.)
+// Everything that is not such a pair goes through the one-command-at-a-time arm below, with rare_command as in k_fine.
+struct BlendPassOut {
+    vec4 rgba[4];
+};
+template <int AA, bool BRUSHES>
+__device__ __attribute__((noinline)) void blend_pass(BlendPassOut &out, uint32_t tile_ix, uint32_t base_color_u, uint32_t ptcl_size, uint32_t blend_size,
+                                                     const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info, uint32_t *blend_spill,
+                                                     const uint32_t *cov_tile, uint32_t *lds_chunk, uint32_t fill_room, uint32_t lane, float xy_x, float xy_y,
+                                                     const uint32_t *__restrict__ ramps, uint32_t n_ramps, const uint32_t *__restrict__ atlas_texels,
+                                                     uint32_t atlas_w, uint32_t atlas_h) {
+    constexpr float COV_SCALE = AA == 2 ? 0.0625f : 0.125f;
+    constexpr uint32_t COV_CHUNK = AA == 2 ? 16u : 8u;  // x 64 words: the size of sh_samples
+    vec4 rgba[4];
+    float area[4];
+    {
+        const vec4 base_color = unpack4x8unorm(base_color_u);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rgba[i] = base_color;
+            area[i] = 0.0f;
+        }
+    }
+    uint32_t blend_stack[BLEND_STACK_SPLIT][4];
+    uint32_t clip_depth = 0u;
+    const VK_GLOBAL uint32_t *ptcl_g = as_global(ptcl);
+    const VK_GLOBAL uint32_t *cov_g = as_global(cov_tile);
+    auto window_at = [&](uint32_t base) -> uint32_t {
+        const uint32_t a = base + lane;
+        return a < ptcl_size ? ptcl_g[a] : 0u;
+    };
+    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
+    uint32_t win_base = cmd_ix, win = window_at(cmd_ix);
+    uint32_t pf_base = 0xffffffffu, pf_win = 0u;  // the window requested ahead
+    const uint32_t blend_offset = wave_read(win, 0u);
+    cmd_ix += 1u;
+#ifndef VELLO_SIMT_EMU
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    uint32_t fill_no = 0u;
+    uint32_t next[COV_CHUNK];
+    auto request_chunk = [&](uint32_t first_fill) {
+#pragma unroll
+        for (uint32_t j = 0; j < COV_CHUNK; j++)  // (the scratch has a fill of slack behind the last)
+            next[j] = __hip_atomic_load(&cov_g[minu(first_fill + j, fill_room) * 64u + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    request_chunk(0u);
+    // coverage of the FILL fill_no -> area
+    auto fill_area = [&]() {
+        if (fill_no % COV_CHUNK == 0u) {  // hand the chunk over and request the one behind it
+            wave_lds_sync();
+#pragma unroll
+            for (uint32_t j = 0; j < COV_CHUNK; j++) lds_chunk[j * 64u + lane] = next[j];
+            request_chunk(fill_no + COV_CHUNK);
+            wave_lds_sync();
+        }
+        const uint32_t b = lds_chunk[(fill_no % COV_CHUNK) * 64u + lane];
+        fill_no += 1u;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) area[i] = (float)((b >> (8u * i)) & 0xffu) * COV_SCALE;
+    };
+    for (;;) {
+        // a window that starts at the command
+        if (cmd_ix != win_base) {
+            if (cmd_ix == pf_base) win = pf_win;
+            else win = window_at(cmd_ix);
+            win_base = cmd_ix;
+            pf_base = 0xffffffffu;
+        }
+        // FILL, COLOR pairs from here on: lane i takes word i for the start of a command, next[i] = i + its size (a fixed
+        // point where the command is not one of the two or would leave the window); doubling gives lane k the k-th command
+        uint32_t pairs;
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f, ca = 0.0f;
+        uint32_t after = cmd_ix;
+        {
+            uint32_t sz = 0u;
+            if (win == CMD_FILL && lane <= 60u) sz = 4u;
+            else if (win == CMD_COLOR && lane <= 62u) sz = 2u;
+            uint32_t jump = sz == 0u ? lane : minu(lane + sz, 63u);
+            uint32_t pos = 0u;
+#pragma unroll
+            for (uint32_t bit = 0; bit < 6u; bit++) {
+                const uint32_t hop = wave_shfl(jump, pos);
+                if ((lane >> bit) & 1u) pos = hop;
+                jump = wave_shfl(jump, jump);
+            }
+            const uint32_t tag_k = wave_shfl(win, pos);
+            const bool ok = (lane & 1u) != 0u ? (tag_k == CMD_COLOR && pos <= 62u) : (tag_k == CMD_FILL && pos <= 60u);
+            const unsigned long long bad = __ballot(!ok);
+            pairs = (bad ? (uint32_t)__ffsll((long long)bad) - 1u : 64u) >> 1;
+            // (two equal positions in a row -- the chain stuck at a word that is neither -- fail the alternation by themselves:
+            // a FILL cannot sit where a COLOR is wanted)
+            if (pairs != 0u) {
+                const uint32_t color_pos = wave_shfl(pos, minu(2u * lane + 1u, 63u));
+                const vec4 c = unpack4x8unorm(wave_shfl(win, minu(color_pos + 1u, 63u)));
+                cr = c.x; cg = c.y; cb = c.z; ca = c.w;
+                after = win_base + wave_read(pos, 2u * pairs - 1u) + 2u;
+                pf_base = after;
+                pf_win = window_at(after);  // arrives while the run is composited
+            }
+        }
+        if (pairs != 0u) {
+            for (uint32_t j = 0; j < pairs; j++) {
+                fill_area();
+                vec4 fg;
+                fg.x = __uint_as_float(wave_read(__float_as_uint(cr), j));
+                fg.y = __uint_as_float(wave_read(__float_as_uint(cg), j));
+                fg.z = __uint_as_float(wave_read(__float_as_uint(cb), j));
+                fg.w = __uint_as_float(wave_read(__float_as_uint(ca), j));
+#pragma unroll
+                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+            }
+            cmd_ix = after;
+            continue;
+        }
+        // one command, as k_fine's interpreter takes it (the window starts at it: its words are lanes 0 ..)
+        const uint32_t tag = wave_read(win, 0u);
+        if (tag == CMD_END) break;
+        if (tag == CMD_FILL) {
+            fill_area();
+            cmd_ix += 4u;
+        } else if (tag == CMD_SOLID) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) area[i] = 1.0f;
+            cmd_ix += 1u;
+        } else if (tag == CMD_COLOR) {
+            const vec4 fg = unpack4x8unorm(wave_read(win, 1u));
+#pragma unroll
+            for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+            cmd_ix += 2u;
+        } else if (tag == CMD_JUMP) {
+            cmd_ix = wave_read(win, 1u);
+        } else {
+            RareState st;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                st.rgba[i] = rgba[i];
+                st.area[i] = area[i];
+            }
+            st.clip_depth = clip_depth;
+            st.cmd_ix = cmd_ix;
+            rare_command<BRUSHES>(st, blend_stack, tag, ptcl_size, blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+                                  atlas_texels, atlas_w, atlas_h);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                rgba[i] = st.rgba[i];
+                area[i] = st.area[i];
+            }
+            clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
+            cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out.rgba[i] = rgba[i];
+}
+
 // BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
 // on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
 // solid-colour interpreter does not pay their registers.
@@ -1323,19 +1535,41 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
                                              const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
                                              uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
-                                             const uint32_t *__restrict__ tile_order) {
+                                             const uint32_t *__restrict__ tile_order, const SliceItem *__restrict__ slice_items,
+                                             uint32_t *slice_counters, uint32_t *cov, uint32_t slice_blocks, uint32_t slice_fills) {
     __shared__ FineShared sh;
     __shared__ uint32_t sh_samples[AA == 2 ? 1024 : (AA == 1 ? 512 : 1)];
     __shared__ FineBatch bt;
     if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
     const uint32_t lane = threadIdx.x;
     const uint32_t lx = lane & 3u, ly = lane >> 2;
-    // Workgroups are dispatched in index order: index -> tile through coarse's buckets of command-list length, longest
+    // Workgroups are dispatched in index order: first the slices of the long tiles (MSAA modes, see FINE_SLICE_FILLS), then
+    // index -> tile through coarse's buckets of command-list length, longest
     // lists first, so that the tile that takes longest starts first instead of wherever row-major order puts it.
     const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
     uint32_t tile_ix = blockIdx.x;
-    {
-        uint32_t rest = blockIdx.x;
+    // A slice's wave runs the interpreter in MODE_COV: it skips to its first FILL, computes the coverage of its fills as
+    // any tile's wave does and writes it to the coverage scratch (a byte per pixel: the number of covered samples),
+    // ignoring everything else in the list.  The wave that finishes a tile's LAST slice runs the interpreter once more in
+    // MODE_BLEND: the whole list, every FILL's coverage read back from the scratch.  Same integer coverage, same f32
+    // compositing in the same order as the unsliced tile: bit-identical pixels.
+    constexpr uint32_t MODE_NORMAL = 0u, MODE_COV = 1u;
+    uint32_t mode = MODE_NORMAL, fill_lo = 0u, fill_hi = 0xffffffffu, fill_room = 0u, cov_base = 0u, slice_n = 0u, first_item = 0u;
+    if (AA != 0 && blockIdx.x < slice_blocks) {
+        if (blockIdx.x >= minu(work_count[FINE_WORK_BUCKETS], slice_blocks)) return;  // Control::slice_items
+        const SliceItem it = slice_items[blockIdx.x];
+        if (it.tile_ix >= n_tiles) return;  // a hole
+        tile_ix = it.tile_ix;
+        const uint32_t k = it.k_and_n & 0xffffu;
+        slice_n = it.k_and_n >> 16;
+        mode = MODE_COV;
+        fill_lo = k * slice_fills;
+        fill_hi = k + 1u == slice_n ? 0xffffffffu : (k + 1u) * slice_fills;
+        fill_room = slice_n * slice_fills;  // fills the tile's scratch has room for
+        cov_base = it.cov_base;
+        first_item = it.first_item;
+    } else {
+        uint32_t rest = blockIdx.x - (AA != 0 ? slice_blocks : 0u);
         bool found = false;
 #pragma unroll
         for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
@@ -1352,18 +1586,15 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
     const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
     vec4 rgba[4];
-    const vec4 base_color = unpack4x8unorm(cfg.base_color);
-#pragma unroll
-    for (int i = 0; i < 4; i++) rgba[i] = base_color;
     uint32_t blend_stack[BLEND_STACK_SPLIT][4];
-    uint32_t clip_depth = 0u;
-    float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
+    uint32_t clip_depth;
+    float area[4];
+    uint32_t cmd_ix;
     // The command stream is read 64 words at a time by the whole wave (one 256-B transaction; the tile's
     // initial PTCL block is exactly one window) and decoded with readlane, instead of a dependent scalar
     // load per word.  The segments of the NEXT fill are requested while the current one is rasterized.
-    uint32_t win_base = cmd_ix;
-    uint32_t win = ptcl[win_base + lane];
+    uint32_t win_base;
+    uint32_t win;
     auto rd = [&](uint32_t ix) -> uint32_t {
         return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
     };
@@ -1374,15 +1605,43 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             win = a < cfg.ptcl_size ? ptcl[a] : 0u;
         }
     };
-    const uint32_t blend_offset = rd(cmd_ix);
     FineProf prof;
     prof.start();
-    prof.count(FP_N_WORDS, rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u));  // the tile's list length, as coarse left it
+    FineTimeline tl;
+    tl.start();
+    uint32_t blend_offset;
+    constexpr float COV_SCALE = AA == 2 ? 0.0625f : 0.125f;  // coverage = covered samples / samples
+    uint32_t fill_no = 0u;   // sliced tiles: FILLs of the list passed so far
+    auto start_list = [&]() {
+        const vec4 base_color = unpack4x8unorm(cfg.base_color);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rgba[i] = base_color;
+            area[i] = 0.0f;
+        }
+        clip_depth = 0u;
+        cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
+        win_base = cmd_ix;
+        win = ptcl[win_base + lane];
+        blend_offset = rd(cmd_ix);
+        cmd_ix += 1u;
+        fill_no = 0u;
+    };
+    // a slice's product: covered samples per pixel, a byte each (coverage is k / 8 or k / 16 exactly), for the FILL fill_no
+    auto store_cov = [&]() {
+        uint32_t b = 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) b |= (uint32_t)(area[i] * (1.0f / COV_SCALE)) << (8u * i);
+        // (an agent-scope relaxed store: written through to where every XCD sees it, no release fence later)
+        if (fill_no < fill_room) __hip_atomic_store(&cov[cov_base + fill_no * 64u + lane], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fill_no += 1u;
+    };
+    start_list();
+    prof.count(FP_N_WORDS, rd(cmd_ix + PTCL_INITIAL_ALLOC - 2u));  // the tile's list length, as coarse left it
 #ifndef VELLO_SIMT_EMU
     // A long list is the launch's critical path: its wave issues ahead of the waves it shares the SIMD with.
-    if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
+    if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 2u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
 #endif
-    cmd_ix += 1u;
     Segment pre;
     pre.p0x = 0.0f; pre.p0y = 0.0f; pre.p1x = 0.0f; pre.p1y = 0.0f; pre.y_edge = 0.0f; pre.pad = 0u;
     uint32_t pre_seg_data = ~0u;
@@ -1390,6 +1649,8 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     bool samples_clean = false;             // MSAA: the sample counters hold their cleared (non-zero rule) value
     uint32_t pf_win = 0u, pf_base = 0xffffffffu;  // MSAA: the command window requested ahead for the next batch
     uint32_t fast_left = 0u, fast_after = 0u;     // MSAA: fills left in the batch's regular prefix / where the list goes on behind it
+    SlotRegs slots{0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
+    uint32_t rec_pre = 0u, rec_pre_begin = ~0u;   // MSAA: the records requested ahead for the next fill
     for (;;) {
         ensure(cmd_ix, 4u);
         const uint32_t tag = rd(cmd_ix);
@@ -1415,6 +1676,11 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                 }
                 fill_path_area(sh, segments, fill, lane, area, first);
             } else {
+                if (mode == MODE_COV && fill_no < fill_lo) {
+                    fill_no += 1u;  // in front of the slice
+                    cmd_ix += 4u;
+                    continue;
+                } else {
                 if (batch_pos == batch_n) {
                     // the scan wants to see as far ahead as possible: a window that starts at (or a draw command in front
                     // of) this command -- the one requested when the previous batch was staged, if the list went on there
@@ -1433,14 +1699,16 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     prof.count(FP_N_BATCHES, 1u);
                     uint32_t n_fast = 0u, after_fast = 0u;
                     batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, n_fast, after_fast));
+                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, n_fast, after_fast, slots));
                     batch_pos = 0u;
+                    rec_pre_begin = ~0u;
                     pf_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_batch);
                     if (pf_base != 0xffffffffu) {
                         const uint32_t a = pf_base + lane;
                         pf_win = a < cfg.ptcl_size ? ptcl[a] : 0u;  // arrives while the batch's fills are replayed
                     }
                     fast_left = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_fast);
+                    if (mode == MODE_COV) fast_left = minu(fast_left, fill_hi - fill_no);  // (the slice ends inside the batch)
                     fast_after = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_fast);
                 }
                 prof.mark(FP_INTERP);
@@ -1451,17 +1719,22 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     const bool fast = fast_left != 0u;
                     for (;;) {
                         prof.count(FP_N_FILLS, 1u);
-                        ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, lane, area, samples_clean, prof);
+                        ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, samples_clean, rec_pre, rec_pre_begin, prof);
                         batch_pos += 1u;
                         if (!fast) break;
-                        const vec4 fg = unpack4x8unorm((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.color[batch_pos - 1u]));
+                        if (mode == MODE_COV) {
+                            store_cov();
+                        } else {
+                            const vec4 fg = unpack4x8unorm((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.color[batch_pos - 1u]));
 #pragma unroll
-                        for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                            for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
+                        }
                         prof.mark(FP_BLEND);
                         fast_left -= 1u;
                         if (fast_left == 0u) break;
                     }
                     if (fast) {
+                        if (mode == MODE_COV && fill_no >= fill_hi) break;
                         cmd_ix = fast_after;
                         continue;
                     }
@@ -1475,6 +1748,13 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     samples_clean = false;
                     prof.mark(FP_FILL_UNBATCHED);
                 }
+                if (mode == MODE_COV) {
+                    store_cov();
+                    cmd_ix += 4u;
+                    if (fill_no >= fill_hi) break;
+                    continue;
+                }
+                }
             }
             cmd_ix += 4u;
             // FILL is followed by its draw command, CMD_COLOR as a rule: blend right away instead of going round the loop
@@ -1485,6 +1765,12 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                 cmd_ix += 2u;
                 prof.mark(FP_BLEND);
             }
+        } else if (AA != 0 && mode == MODE_COV && tag != CMD_JUMP) {
+            // a slice's wave wants the FILLs only (and must keep away from the blend stack's memory: it is the compositing
+            // pass's); sizes as the arms below and rare_command advance
+            if (tag == CMD_COLOR || tag == CMD_IMAGE) cmd_ix += 2u;
+            else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) cmd_ix += 3u;
+            else cmd_ix += 1u;  // SOLID, BEGIN_CLIP, unknown tags
         } else if (tag == CMD_SOLID) {
 #pragma unroll
             for (int i = 0; i < 4; i++) area[i] = 1.0f;
@@ -1523,8 +1809,35 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             prof.mark(FP_RARE);
         }
     }
+    if (AA != 0 && mode == MODE_COV) {
+    // The slice is done: take a ticket.  The in-launch hand-off of cdna_hip_programming.md section 6 guideline 16 in its
+    // write-through form: the coverage went out with agent-scope (sc1) stores, this wave drains them, then a relaxed
+    // agent-scope ticket; the wave that draws the last ticket reads every slice's bytes with agent-scope loads.  No
+    // release / acquire fences: a fence per slice writes back and invalidates whole caches under the other frames'
+    // kernels (measured: -15 % frames/s with four frames in flight).  Correct wherever the slices ran (other CUs, other
+    // XCDs); the counter was zeroed by coarse.
+#ifndef VELLO_SIMT_EMU
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    uint32_t ticket = 0u;
+    if (lane == 0u) ticket = __hip_atomic_fetch_add(&slice_counters[first_item], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    if (ticket + 1u != slice_n) {
+        tl.log(blend_spill, cfg.blend_size, lane, 1u, fill_no, tile_ix);
+        return;
+    }
+    // The tile's last slice has arrived: composite (out of line: the second interpreter must not cost the first its registers)
+    {
+        BlendPassOut bo;
+        blend_pass<AA, BRUSHES>(bo, tile_ix, cfg.base_color, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, cov + cov_base, sh_samples, fill_room, lane, xy_x, xy_y,
+                                ramps, n_ramps, atlas_texels, atlas_w, atlas_h);
+#pragma unroll
+        for (int i = 0; i < 4; i++) rgba[i] = bo.rgba[i];
+    }
+    }
     prof.mark(FP_INTERP);
     prof.store(blend_spill, cfg.blend_size, n_tiles, tile_ix, lane);
+    tl.log(blend_spill, cfg.blend_size, lane, AA != 0 && mode == MODE_COV ? 2u : 0u, fill_no, tile_ix);
     // fine.wgsl:1386-1397: un-premultiplied RGBA8
     const uint32_t px0 = tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD;
     const uint32_t py = tile_y * TILE_HEIGHT + ly;
@@ -1548,238 +1861,20 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
 }
 
 
-// ---------------- two waves per tile: builder | player (EXPERIMENTAL, VELLO_HIP_DEBUG_FINE_PIPELINE) ----------------
-// k_fine's launch is as long as its longest tile, and a tile is ONE wave's chain of fills.  Cutting the
-// tile's pixels over several waves replicates the per-fill work (measured: 2x slower).  This kernel cuts the WORK instead:
-// wave 0 walks the command list for FILLs and stages batches (ms_build_batch: scan, segment loads, one record per crossing)
-// into one of two FineBatch buffers; wave 1 interprets the list as k_fine does and replays the staged fills
-// (ms_fill_from_batch), blends, handles clips / brushes.  One workgroup barrier per batch hands a buffer over; the builder
-// runs at most one batch ahead.  By instruction count a fill is 1/3 staging, 2/3 replay.  Same functions, same integer
-// operations on the same values as k_fine: bit-identical output (tests/test_emu_parity.py).  Not the default: it has not
-// been timed on the GPU yet.
-constexpr uint32_t PIPE_END = 0u, PIPE_BATCH = 1u, PIPE_SINGLE = 2u;
-
-template <int AA, bool BRUSHES>
-__global__ void __launch_bounds__(128, BRUSHES ? 3 : 4) k_fine_pipe(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
-                                                  const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
-                                                  uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
-                                                  const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
-                                                  uint32_t atlas_w, uint32_t atlas_h, const uint32_t *__restrict__ work_count,
-                                                  const uint32_t *__restrict__ tile_order) {
-    static_assert(AA != 0, "area AA has no batches to stage");
-    __shared__ FineShared sh_build, sh_play;
-    __shared__ uint32_t sh_samples[AA == 2 ? 1024 : 512];
-    __shared__ FineBatch bt[2];
-    __shared__ uint32_t hdr[2][2];  // per buffer: PIPE_*, fills staged
-    if (ptcl[0] == ~0u) return;  // fine.wgsl:1070-1074
-    const uint32_t lane = threadIdx.x & 63u;
-    // (a scalar: the two roles are two code paths with workgroup barriers in them, no wave may walk the other's with an empty mask)
-    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t lx = lane & 3u, ly = lane >> 2;
-    const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
-    uint32_t tile_ix = blockIdx.x;
-    {
-        uint32_t rest = blockIdx.x;
-        bool found = false;
-#pragma unroll
-        for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
-            const uint32_t cnt = minu(work_count[b], n_tiles);
-            if (!found && rest < cnt) {
-                tile_ix = tile_order[(uint32_t)b * n_tiles + rest];
-                found = true;
-            }
-            if (!found) rest -= cnt;
-        }
-        if (!found || tile_ix >= n_tiles) return;
-    }
-    uint32_t cmd_ix = tile_ix * PTCL_INITIAL_ALLOC;
-    uint32_t win_base = cmd_ix;
-    uint32_t win = ptcl[win_base + lane];
-    auto rd = [&](uint32_t ix) -> uint32_t {
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)__builtin_amdgcn_readfirstlane((int)(ix - win_base)));
-    };
-    auto ensure = [&](uint32_t ix, uint32_t n_words) {
-        if (ix + n_words > win_base + 64u) {
-            win_base = ix;
-            uint32_t a = win_base + lane;
-            win = a < cfg.ptcl_size ? ptcl[a] : 0u;
-        }
-    };
-    const uint32_t blend_offset = rd(cmd_ix);
-#ifndef VELLO_SIMT_EMU
-    if (rd(cmd_ix + PTCL_INITIAL_ALLOC - 1u) >= FINE_HEAVY_WORDS) __builtin_amdgcn_s_setprio(3);
-#endif
-    cmd_ix += 1u;
-    FineProf prof;
-    prof.start();
-
-    if (role == 0u) {
-        // ---- builder: FILL after FILL into bt[unit & 1]
-        uint32_t unit = 0u;
-        for (;;) {
-            bool found = false;
-            for (;;) {  // the next FILL at or after cmd_ix
-                ensure(cmd_ix, 4u);
-                const uint32_t tag = rd(cmd_ix);
-                if (tag == CMD_FILL) {
-                    found = true;
-                    break;
-                }
-                if (tag == CMD_END) break;
-                if (tag == CMD_JUMP) cmd_ix = rd(cmd_ix + 1u);
-                else if (tag == CMD_COLOR || tag == CMD_IMAGE) cmd_ix += 2u;
-                else if (tag == CMD_END_CLIP || tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD || tag == CMD_BLUR_RECT) cmd_ix += 3u;
-                else cmd_ix += 1u;  // SOLID, BEGIN_CLIP; unknown tags as rare_command skips them
-            }
-            uint32_t kind = PIPE_END, n = 0u;
-            if (found) {
-                if (cmd_ix != win_base) {  // (the scan wants to see as far ahead as possible)
-                    win_base = cmd_ix;
-                    uint32_t a = win_base + lane;
-                    win = a < cfg.ptcl_size ? ptcl[a] : 0u;
-                }
-                uint32_t after_batch = 0xffffffffu, after_fit = cmd_ix + 4u, pipe_n_fast, pipe_after_fast;  // (the player interprets)
-                n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                    (int)ms_build_batch<AA, true>(sh_build, bt[unit & 1u], segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, pipe_n_fast, pipe_after_fast, &after_fit));
-                kind = n != 0u ? PIPE_BATCH : PIPE_SINGLE;
-                cmd_ix = n != 0u ? (uint32_t)__builtin_amdgcn_readfirstlane((int)after_fit) : cmd_ix + 4u;
-            }
-            if (lane == 0u) {
-                hdr[unit & 1u][0] = kind;
-                hdr[unit & 1u][1] = n;
-            }
-            __syncthreads();  // the buffer is the player's; bt[(unit + 1) & 1] is free: the player was done with it before it came here
-            if (!found) break;
-            unit += 1u;
-        }
-        return;
-    }
-
-    // ---- player: k_fine's interpreter, batches taken from the builder
-    const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
-    const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);
-    const float xy_y = (float)(tile_y * TILE_HEIGHT + ly);
-    vec4 rgba[4];
-    const vec4 base_color = unpack4x8unorm(cfg.base_color);
-#pragma unroll
-    for (int i = 0; i < 4; i++) rgba[i] = base_color;
-    uint32_t blend_stack[BLEND_STACK_SPLIT][4];
-    uint32_t clip_depth = 0u;
-    float area[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    uint32_t batch_n = 0u, batch_pos = 0u, units = 0u, cur = 0u;
-    bool samples_clean = false;
-    for (;;) {
-        ensure(cmd_ix, 4u);
-        const uint32_t tag = rd(cmd_ix);
-        if (tag == CMD_END) break;
-        if (tag == CMD_FILL) {
-            if (batch_pos == batch_n) {
-                __syncthreads();  // the builder has staged this FILL (and what follows it) in bt[units & 1]
-                cur = units & 1u;
-                units += 1u;
-                const uint32_t kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[cur][0]);
-                const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[cur][1]);
-                batch_n = kind == PIPE_BATCH ? n : 0u;
-                batch_pos = 0u;
-            }
-            if (batch_n != 0u) {
-                ms_fill_from_batch<AA>(sh_play, bt[cur], sh_samples, batch_pos, lane, area, samples_clean, prof);
-                batch_pos += 1u;
-            } else {
-                CmdFill fill;
-                fill.size_and_rule = rd(cmd_ix + 1u);
-                fill.seg_data = rd(cmd_ix + 2u);
-                fill.backdrop = (int32_t)rd(cmd_ix + 3u);
-                fill_path_ms<AA>(sh_play, sh_samples, segments, mask_lut, fill, lane, area);
-                samples_clean = false;
-            }
-            cmd_ix += 4u;
-            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {
-                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
-#pragma unroll
-                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
-                cmd_ix += 2u;
-            }
-        } else if (tag == CMD_SOLID) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) area[i] = 1.0f;
-            cmd_ix += 1u;
-            if (cmd_ix + 2u <= win_base + 64u && rd(cmd_ix) == CMD_COLOR) {
-                const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
-#pragma unroll
-                for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
-                cmd_ix += 2u;
-            }
-        } else if (tag == CMD_COLOR) {
-            const vec4 fg = unpack4x8unorm(rd(cmd_ix + 1u));
-#pragma unroll
-            for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
-            cmd_ix += 2u;
-        } else if (tag == CMD_JUMP) {
-            cmd_ix = rd(cmd_ix + 1u);
-        } else {
-            RareState st;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                st.rgba[i] = rgba[i];
-                st.area[i] = area[i];
-            }
-            st.clip_depth = clip_depth;
-            st.cmd_ix = cmd_ix;
-            rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
-                                  atlas_texels, atlas_w, atlas_h);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                rgba[i] = st.rgba[i];
-                area[i] = st.area[i];
-            }
-            clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
-            cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
-        }
-    }
-    __syncthreads();  // the builder's PIPE_END
-    const uint32_t px0 = tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD;
-    const uint32_t py = tile_y * TILE_HEIGHT + ly;
-    if (py < cfg.target_height && px0 < cfg.target_width) {
-        uint32_t packed[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            vec4 fg = rgba[i];
-            float a_inv = 1.0f / maxf(fg.w, 1e-6f);
-            packed[i] = pack4x8unorm(vec4{fg.x * a_inv, fg.y * a_inv, fg.z * a_inv, fg.w});
-        }
-        uint8_t *row = output + (size_t)py * out_stride + (size_t)px0 * 4u;
-        if (px0 + 4u <= cfg.target_width && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0u)) {
-            *reinterpret_cast<uint4 *>(row) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
-        } else {
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; i++)
-                if (px0 + i < cfg.target_width) reinterpret_cast<uint32_t *>(row)[i] = packed[i];
-        }
-    }
-}
-
 template <int AA>
 static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_lut) {
-    dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles);
+    // MSAA: slice_cap blocks for the slices of long tiles come first (blocks beyond the frame's count leave at once)
+    const uint32_t slice_blocks = AA != 0 && f.slice_min_fills != 0u ? f.slice_cap : 0u;
+    dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles + slice_blocks);
     uint32_t stride = (uint32_t)f.out_stride;
-    if constexpr (AA != 0) {
-        if (f.fine_pipeline) {  // VELLO_HIP_DEBUG_FINE_PIPELINE: two waves per tile
-            if (f.brushes)
-                hipLaunchKernelGGL((k_fine_pipe<AA, true>), grid, dim3(128), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                                   stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
-            else
-                hipLaunchKernelGGL((k_fine_pipe<AA, false>), grid, dim3(128), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                                   stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
-            return;
-        }
-    }
     if (f.brushes)
         hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order, f.slice_items,
+                           f.slice_counters, f.cov, slice_blocks, f.slice_fills);
     else
         hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order);
+                           stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order, f.slice_items,
+                           f.slice_counters, f.cov, slice_blocks, f.slice_fills);
 }
 
 void launch_fine(const Frame &f, hipStream_t s) {

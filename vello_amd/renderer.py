@@ -209,15 +209,15 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_pipeline=False):
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_slices=False):
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
         runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
-        stack machine instead of the partitioned kernels; fine_pipeline renders the MSAA modes with the experimental
-        two-waves-per-tile form of fine.  Flags not named are cleared (update_debug_flags keeps them)."""
+        stack machine instead of the partitioned kernels; fine_slices cuts every tile's command list into slices of
+        4 fills for fine's MSAA modes (normally only lists of >= 64 fills are cut).  Flags not named are cleared (update_debug_flags keeps them)."""
         self._debug = {"no_cull": bool(no_cull), "stroke_kernel": bool(stroke_kernel), "seq_clip": bool(seq_clip),
-                       "fine_pipeline": bool(fine_pipeline)}
+                       "fine_slices": bool(fine_slices)}
         d = self._debug
-        flags = (1 if d["no_cull"] else 0) | (2 if d["stroke_kernel"] else 0) | (4 if d["seq_clip"] else 0) | (8 if d["fine_pipeline"] else 0)
+        flags = (1 if d["no_cull"] else 0) | (2 if d["stroke_kernel"] else 0) | (4 if d["seq_clip"] else 0) | (8 if d["fine_slices"] else 0)
         self._check(self._lib.vello_hip_set_debug_flags(self._h, flags), "set_debug_flags")
 
     def update_debug_flags(self, **changes):
@@ -260,6 +260,11 @@ class Engine:
         out = np.zeros(n, dtype=np.uint8)
         self._check(self._lib.vello_hip_read_buffer(self._h, bid, out.ctypes.data, offset, n), f"read_buffer({name})")
         return out.view(dtype) if n % np.dtype(dtype).itemsize == 0 else out
+
+    def control_words(self):
+        """The last frame's 32-word control block (engine.h Control): bump allocators, tickets, flatten's list lengths, fine's
+        bucket counters [16:24], slice items [24] and coverage-scratch words [25] handed out by coarse."""
+        return self.read_buffer("bump", np.uint32, 128)
 
     def write_buffer(self, name, data, offset=0):
         bid = BUFFERS.index(name)
