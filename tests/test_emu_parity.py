@@ -920,6 +920,6 @@ def test_emu_fine_slices(emu_engine, name, body):
     try:
         body(emu_engine)
         if name in ("tiger", "rules_11", "blend_grid"):  # (the flag did take these frames through the sliced path)
-            assert emu_engine.control_words()[24] > 0, "no tile was cut into slices"
+            assert emu_engine.fine_slice_stats()[0] > 0, "no tile was cut into slices"
     finally:
         emu_engine.set_debug_flags()

@@ -200,8 +200,8 @@ def test_config_c3_d2_scene_full_size(built):
     assert (img[:, :, 3] == 255).all()
     # the scene has tiles of >= 64 fills: fine cut them into slices (engine.h FINE_SLICE_FILLS) -- the last frame compare_frame
     # rendered is the NO_CULL one, whose lists are the longest
-    ctl = eng.control_words()
-    assert ctl[24] > 100 and ctl[25] > 0, "no tile of the d2 scene went through fine's sliced path"
+    items, cov_words = eng.fine_slice_stats()
+    assert items > 100 and cov_words > 0, "no tile of the d2 scene went through fine's sliced path"
 
 
 def test_config_c4_mmark_reduced(gpu_engine):
@@ -796,7 +796,7 @@ def test_fine_slices_forced(gpu_engine, name, body):
     gpu_engine.set_debug_flags(fine_slices=True)
     try:
         body(gpu_engine)
-        assert name == "brushes" or gpu_engine.control_words()[24] > 0, "no tile was cut into slices"  # (brushes: < 5 fills per tile)
+        assert name == "brushes" or gpu_engine.fine_slice_stats()[0] > 0, "no tile was cut into slices"  # (brushes: < 5 fills per tile)
     finally:
         gpu_engine.set_debug_flags()
 

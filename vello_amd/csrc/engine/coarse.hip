@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
         // ... and the tile's index in the bucket of its length class, so that long lists are started first (one atomic
         // per bucket and workgroup: 10 000 tiles bumping eight counters one by one cost the kernel 50 us)
         const uint32_t n_tiles = cfg.width_in_tiles * cfg.height_in_tiles;
-        uint32_t bucket = in_target ? minu(FINE_WORK_BUCKETS - 1u, (uint32_t)(32 - __clz((int)(words_total >> 5)))) : NONE;
+        uint32_t bucket = in_target ? minu(FINE_WORK_BUCKETS - 1u, words_total >> 5) : NONE;
         // A long list (MSAA modes) is cut into slices of slice_fills FILLs, each a work item of fine's that comes before all
         // unsliced tiles; the tile then stays out of the buckets.  One atomic per counter and workgroup; a tile whose slices or
         // coverage scratch do not fit is rendered unsliced, its place in the item array marked as a hole.
@@ -734,17 +734,20 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
                 }
             }
         }
+        // (lane b owns bucket b: all the buckets' atomics are ONE instruction and one round trip, not one after the other)
+        static_assert(FINE_WORK_BUCKETS <= 64u, "a lane per bucket");
+        uint32_t my_count = 0u, my_rank = 0u;
         for (uint32_t bk = 0; bk < FINE_WORK_BUCKETS; bk++) {
             const u64 m = __ballot(bucket == bk);
-            if (m == 0ull) continue;
-            const uint32_t leader = (uint32_t)__ffsll((long long)m) - 1u;
-            uint32_t base = 0u;
-            if (lane == leader) base = atomicAdd(&work_count[bk], popc64(m));
-            base = (uint32_t)__shfl((int)base, (int)leader);
-            if (bucket == bk) {
-                const uint32_t pos = base + popc64(m & below64(lane));
-                if (pos < n_tiles) tile_order[bk * n_tiles + pos] = this_tile_ix;
-            }
+            if (lane == bk) my_count = popc64(m);
+            if (bucket == bk) my_rank = popc64(m & below64(lane));
+        }
+        uint32_t base = 0u;
+        if (lane < FINE_WORK_BUCKETS && my_count != 0u) base = atomicAdd(&work_count[lane], my_count);
+        base = (uint32_t)__shfl((int)base, (int)(bucket & 63u));
+        if (bucket != NONE) {
+            const uint32_t pos = base + my_rank;
+            if (pos < n_tiles) tile_order[bucket * n_tiles + pos] = this_tile_ix;
         }
     }
 #ifdef VELLO_COARSE_PROF

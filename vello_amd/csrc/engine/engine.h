@@ -24,7 +24,7 @@ constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a 
 // than the scene buffer / layout hold (WebGPU's robust buffer access makes this harmless upstream; HIP has none):
 // every later stage that would index with those counts bails out, the frame reports VELLO_HIP_E_INVALID
 constexpr uint32_t FAILED_SCENE = 0x40000000u;
-constexpr uint32_t FINE_WORK_BUCKETS = 8;
+constexpr uint32_t FINE_WORK_BUCKETS = 32;  // buckets of 32 command words (the last one: 992 and more)
 // Stroked lines get a kernel of their own (k_flatten_strokes) once they alone fill the chip twice over at its 12 waves per CU
 // (256 CUs x 12 x 64 lanes); below that they ride along in k_flatten_heavy, whose duration the curves set anyway.
 constexpr uint32_t FLATTEN_STROKE_KERNEL_MIN_LINES = 2u * 256u * 12u * 64u;
@@ -72,9 +72,9 @@ struct Control {
     uint32_t work_count[FINE_WORK_BUCKETS];  // coarse -> fine: tiles per bucket of command-list length (k_fine runs the long ones first)
     uint32_t slice_items;   // coarse -> fine: SliceItems handed out (may run past the capacity: fine clamps); work_count[BUCKETS]
     uint32_t cov_words;     // coarse -> fine: words of the coverage scratch handed out
-    uint32_t pad2[16 - FINE_WORK_BUCKETS - 2];
+    uint32_t pad2[48 - FINE_WORK_BUCKETS - 2];
 };
-static_assert(sizeof(Control) == 128, "Control");
+static_assert(sizeof(Control) == 256, "Control");
 
 struct Frame {
     Config cfg;  // host copy; kernels receive it by value

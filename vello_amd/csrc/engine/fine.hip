@@ -1571,16 +1571,19 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     } else {
         uint32_t rest = blockIdx.x - (AA != 0 ? slice_blocks : 0u);
         bool found = false;
+        uint32_t slot = 0u;  // (ONE load behind the loop: a load under a condition in an unrolled loop is waited for where it stands)
 #pragma unroll
         for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
             const uint32_t cnt = minu(work_count[b], n_tiles);
             if (!found && rest < cnt) {
-                tile_ix = tile_order[(uint32_t)b * n_tiles + rest];
+                slot = (uint32_t)b * n_tiles + rest;
                 found = true;
             }
             if (!found) rest -= cnt;
         }
-        if (!found || tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once)
+        if (!found) return;
+        tile_ix = tile_order[slot];
+        if (tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once)
     }
     const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
     const float xy_x = (float)(tile_x * TILE_WIDTH + lx * PIXELS_PER_THREAD);

@@ -262,9 +262,14 @@ class Engine:
         return out.view(dtype) if n % np.dtype(dtype).itemsize == 0 else out
 
     def control_words(self):
-        """The last frame's 32-word control block (engine.h Control): bump allocators, tickets, flatten's list lengths, fine's
-        bucket counters [16:24], slice items [24] and coverage-scratch words [25] handed out by coarse."""
-        return self.read_buffer("bump", np.uint32, 128)
+        """The last frame's 64-word control block (engine.h Control): bump allocators, tickets, flatten's list lengths, fine's
+        bucket counters [16:48], slice items [48] and coverage-scratch words [49] handed out by coarse."""
+        return self.read_buffer("bump", np.uint32, 256)
+
+    def fine_slice_stats(self):
+        """(slice items, coverage-scratch words) coarse handed out for the last frame."""
+        w = self.control_words()
+        return int(w[48]), int(w[49])
 
     def write_buffer(self, name, data, offset=0):
         bid = BUFFERS.index(name)
