@@ -1,0 +1,43 @@
+"""Where k_path_count's workgroups spend their time (measurement build: PROF_FLAGS=-DVELLO_PC_TIMELINE scripts/build_prof.sh):
+per chunk of 1024 lines the wall-clock stamps of start / pass 1 done / slots reserved / pass 2 done.
+    python scripts/pc_timeline.py [d2] [r1mix]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vello_amd._lib as L
+L._use_library(os.environ.get("VELLO_PROF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab_tmp", "libvello_hip_PROF.so")))
+import bench
+from vello_amd.renderer import Engine
+
+
+def report(key):
+    wl = bench.Workload(key, 0)
+    eng = Engine(0, 4, wl.caps)
+    eng.upload_scene(wl.packed, wl.layout)
+    for _ in range(3):
+        eng.render_resident(bench.WIDTH, bench.HEIGHT, bench.BASE_COLOR, 2)
+        eng.sync()
+    cap = eng.capacities()["seg_counts"]
+    n_lines = eng.bump()["lines"]
+    n_chunks = (n_lines + 1023) // 1024
+    raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 2 * 8192) * 2:cap * 2].reshape(-1, 4).astype(np.int64)[:n_chunks]
+    t0, t1, t2, t3 = (raw[:, i] for i in range(4))
+    base = t0.min()
+    us = lambda t: (t - base) / 100.0
+    print(f"{key}: {n_chunks} chunks; launch span {us(t3).max():.1f} us")
+    for name, a, b in (("pass 1", t0, t1), ("reserve (atomic + barrier)", t1, t2), ("pass 2", t2, t3), ("whole chunk", t0, t3)):
+        d = (b - a) / 100.0
+        print(f"  {name:28s} mean {d.mean():7.2f} us  p50 {np.median(d):7.2f}  p90 {np.percentile(d, 90):7.2f}  max {d.max():7.2f}   sum {d.sum():9.0f}")
+    step = 5.0
+    for a in np.arange(0.0, us(t3).max() + step, step):
+        b = a + step
+        res = np.clip(np.minimum(us(t3), b) - np.maximum(us(t0), a), 0, None).sum() / step
+        p1 = np.clip(np.minimum(us(t1), b) - np.maximum(us(t0), a), 0, None).sum() / step
+        rs = np.clip(np.minimum(us(t2), b) - np.maximum(us(t1), a), 0, None).sum() / step
+        print(f"  {a:6.0f} us: resident chunks {res:6.0f}  (pass 1 {p1:6.0f}, reserving {rs:6.0f}, pass 2 {res - p1 - rs:6.0f}) started {int(((us(t0) >= a) & (us(t0) < b)).sum())}")
+    del eng
+
+
+if __name__ == "__main__":
+    for k in sys.argv[1:] or ["d2"]:
+        report(k)

@@ -73,8 +73,23 @@ struct Control {
     uint32_t slice_items;   // coarse -> fine: SliceItems handed out (may run past the capacity: fine clamps); work_count[BUCKETS]
     uint32_t cov_words;     // coarse -> fine: words of the coverage scratch handed out
     uint32_t pad2[48 - FINE_WORK_BUCKETS - 2];
+    // flatten: arcs k_flatten_strokes set aside, counted in FLATTEN_ARC_SHARDS sub-lists (workgroup b appends to shard b mod
+    // 64): ONE counter took 2 800 same-address atomics of ~12 ns each in a burst -- 30 us on the road-map scene
+    uint32_t arc_count[64];
 };
-static_assert(sizeof(Control) == 256, "Control");
+static_assert(sizeof(Control) == 512, "Control");
+constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
+// k_flatten_strokes' grid for a scene of at most n_seg_max segments, and the arcs one shard of the arc list can be given
+// (256 per round of each of its workgroups); the list holds FLATTEN_ARC_SHARDS x that many 64-byte items
+inline uint32_t flatten_strokes_grid(uint32_t n_seg_max) {
+    uint32_t g = (n_seg_max + 255u) / 256u;
+    return g > 4096u ? 4096u : (g < 1u ? 1u : g);
+}
+inline uint32_t flatten_arc_shard_cap(uint32_t n_seg_max) {
+    const uint32_t grid = flatten_strokes_grid(n_seg_max);
+    const uint32_t rounds = ((n_seg_max + 255u) / 256u + grid - 1u) / grid;
+    return ((grid + FLATTEN_ARC_SHARDS - 1u) / FLATTEN_ARC_SHARDS) * (rounds < 1u ? 1u : rounds) * 256u;
+}
 
 struct Frame {
     Config cfg;  // host copy; kernels receive it by value
@@ -85,6 +100,7 @@ struct Frame {
     const uint32_t *scene;
     Control *control;
     uint32_t *heavy_list;   // flatten: tag indices that need the Euler-spiral / stroker path
+    uint32_t *arc_items;    // flatten: 16 words per round join / cap arc that k_flatten_strokes leaves to k_flatten_heavy
     unsigned long long *pathtag_state;  // [n_pathtag_parts][2][5]
     unsigned long long *draw_state;     // [n_draw_parts][2][4]
     TagMonoid *tag_monoids;

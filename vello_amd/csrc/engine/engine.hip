@@ -62,6 +62,7 @@ struct Lane {
     DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
     DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
     DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
+    DevBuf arc_items;                 // flatten: arcs left to k_flatten_heavy by k_flatten_strokes (64 B per segment, worst case)
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -275,6 +276,12 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     if ((r = ensure(c, l.clip_stack, clip_scratch_words(L.n_clips) * 4u))) return r;
     if ((r = ensure(c, l.coarse_el, (size_t)(L.n_draw_objects + 1u) * sizeof(CoarseEl)))) return r;
     if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 48u))) return r;  // 3 lists x 4 tags per word x u32
+    {
+        // one arc per stroked segment at most; a segment owns at least one word of path data (the tag stream is padded)
+        const size_t n_tags = (size_t)sc.n_tag_words * 4u, n_data = (size_t)L.draw_tag_base - L.path_data_base;
+        const uint32_t n_seg_max = (uint32_t)(n_tags < n_data ? n_tags : n_data);
+        if ((r = ensure(c, l.arc_items, (size_t)flatten_arc_shard_cap(n_seg_max) * FLATTEN_ARC_SHARDS * 64u))) return r;
+    }
     return 0;
 }
 
@@ -409,6 +416,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
         f.slice_min_fills = forced ? FINE_SLICE_MIN_FILLS_FORCED : FINE_SLICE_MIN_FILLS;
     }
     f.heavy_list = (uint32_t *)l.heavy_list.ptr;
+    f.arc_items = (uint32_t *)l.arc_items.ptr;
     if (out_device) {
         f.output = (uint8_t *)out_device;
         f.out_stride = out_stride ? out_stride : (size_t)p->width * 4u;
@@ -649,6 +657,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         for (DevBuf *b : {&l.slice_items, &l.slice_counters, &l.cov})
             if (b->ptr) (void)hipFree(b->ptr);
         if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);
+        if (l.arc_items.ptr) (void)hipFree(l.arc_items.ptr);
         if (l.stream) (void)hipStreamDestroy(l.stream);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);

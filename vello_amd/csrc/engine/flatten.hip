@@ -521,9 +521,10 @@ __device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end,
 }
 
 // flatten.wgsl:523-547
+template <bool WITH_ROUND = true>  // (false: the caller has taken the round style itself -- no arc code in its kernel)
 __device__ void draw_cap(Emitter &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
                          vec2 offset_tangent, const Xform &transform) {
-    if (cap_style == STYLE_FLAGS_CAP_ROUND) {
+    if (WITH_ROUND && cap_style == STYLE_FLAGS_CAP_ROUND) {
         flatten_arc(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
         return;
     }
@@ -559,6 +560,7 @@ __device__ float f16_to_f32(uint32_t bits) {
 }
 
 // flatten.wgsl:549-631
+template <bool WITH_ROUND = true>
 __device__ void draw_join(Emitter &em, uint32_t path_ix, uint32_t style_flags, vec2 p0, vec2 tan_prev, vec2 tan_next,
                           vec2 n_prev, vec2 n_next, const Xform &transform) {
     vec2 front0 = p0 + n_prev;
@@ -593,7 +595,7 @@ __device__ void draw_join(Emitter &em, uint32_t path_ix, uint32_t style_flags, v
         }
         em.write_xf(line_ix, path_ix, front0, front1, transform);
         em.write_xf(line_ix + 1u, path_ix, back0, back1, transform);
-    } else if (join == STYLE_FLAGS_JOIN_ROUND) {
+    } else if (WITH_ROUND && join == STYLE_FLAGS_JOIN_ROUND) {
         vec2 arc0, arc1, other0, other1;
         if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
         else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
@@ -903,8 +905,50 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
 // Same operations in the same order as flatten_tag -> flatten_euler's straight-segment shortcut -> draw_join / draw_cap.
 // Returns false (having emitted nothing) for a line flatten_euler would not take that shortcut for (degenerate, or offset
 // lines that fail the straight-segment test): the caller queues it for k_flatten_heavy.
-__device__ bool flatten_stroked_line(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix,
-                                     uint32_t &path_ix_out) {
+// An arc of a round join or cap whose lines cannot be told without the exact transcendentals (atan2, acos, sincos in fp64):
+// set aside by the lane of k_flatten_strokes that met it and flattened by a lane of its own in k_flatten_heavy, where such
+// arcs are dense (a few per cent of a road map's stroked lines: inline, nearly every wave walked the fp64 routines for its
+// one or two of them).  16 words; the workgroup collects its arcs in LDS and appends them to the frame's list behind ONE
+// atomic.
+constexpr uint32_t STROKE_ARCS = 256u;  // at most one per stroked line of a round
+constexpr uint32_t ARC_IS_CAP = 1u;
+struct __attribute__((aligned(16))) ArcItem {
+    uint32_t path_ix, trans_ix, flags, pad;
+    float bx, by, ex, ey;   // begin, end
+    float cx, cy, cr, d;    // center; the angle is |atan2(cr, d)| (pi for a cap)
+    float box[4];           // extent of the OTHER lines of the thread that met the arc: the thread's box is tested and merged as one
+};
+static_assert(sizeof(ArcItem) == 64, "ArcItem");
+struct ArcQueue {
+    ArcItem item[STROKE_ARCS];
+    uint32_t count, base;
+};
+
+// Round join or cap between `begin` and `end` about `center` (flatten_arc's arguments; the angle is |atan2(cr, d)|, pi for
+// a cap).  flatten_arc makes n = max(1, ceil(angle / theta)) lines with theta = 2 acos(1 - tol / radius): for the joins of
+// a road map n is 1 nearly always, and then neither the angle nor theta nor sincos(theta) is needed, only the fact.
+// angle < theta  <=>  cos(angle) > cos(theta) on [0, pi], with cos(angle) = d / |(cr, d)| and cos(theta) = 2 x^2 - 1:
+// one sqrt and one division.  The margin (1e-4 in the cosine: >= 3e-5 relative in the quotient angle / theta, against
+// < 1e-6 of rounding in everything the reference computes in f32) makes the shortcut safe, not tight: what it does not
+// decide goes to the queue and is flattened exactly.  Returns true when the arc was emitted here.
+__device__ __forceinline__ bool stroke_arc_one_line(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float cr, float d,
+                                                    const Xform &transform) {
+    const float tol = 0.25f;
+    const vec2 p0 = xf_apply(transform, begin);
+    const float radius = maxf(tol, length(p0 - xf_apply(transform, center)));
+    const float x = 1.0f - tol / radius;
+    const float cos_theta = 2.0f * x * x - 1.0f;
+    const float cos_angle = d / sqrtf(cr * cr + d * d);
+    if (!(cos_angle > cos_theta + 1.0e-4f)) return false;  // (NaNs land here too)
+    const uint32_t ix = em.alloc(1u);
+    em.write(ix, path_ix, p0, xf_apply(transform, end));
+    return true;
+}
+
+// One stroked LINETO (flatten_tag's stroke branch with flatten_euler reduced to its straight-segment shortcut).  Returns
+// false when the segment is not straight (the heavy kernel takes it).  Arcs that need the exact path are pushed to `q`.
+__device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+                                     uint32_t ix, uint32_t &path_ix_out) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     const uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
@@ -945,8 +989,42 @@ __device__ bool flatten_stroked_line(Emitter &em, const Config &cfg, const uint3
         em.write_xf(line_ix, path_ix, pts.p0 + n_start, pts.p3 + n_prev, transform);
         em.write_xf(line_ix + 1u, path_ix, pts.p3 - n_prev, pts.p0 - n_start, transform);
     }
-    if (do_join) draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
-    else draw_cap(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev, offset_tangent, transform);
+    // the arc of a round join / cap: here if it is certainly one line, else set aside (begin, end, center and what the
+    // angle is made of); everything else of draw_join / draw_cap as there
+    bool arc = false, arc_is_cap = false;
+    vec2 arc0 = v2(0.0f, 0.0f), arc1 = arc0;
+    float cr = 0.0f, d = 0.0f;
+    if (do_join && (style_flags & STYLE_FLAGS_JOIN_MASK) == STYLE_FLAGS_JOIN_ROUND) {
+        const vec2 p0 = pts.p3;
+        const vec2 front0 = p0 + n_prev, front1 = p0 + n_next, back0 = p0 - n_next, back1 = p0 - n_prev;
+        cr = tan_prev.x * tan_next.y - tan_prev.y * tan_next.x;
+        d = dot(tan_prev, tan_next);
+        vec2 other0, other1;
+        if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
+        else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
+        arc = !stroke_arc_one_line(em, path_ix, arc0, arc1, p0, cr, d, transform);
+        const uint32_t o = em.alloc(1u);
+        em.write_xf(o, path_ix, other0, other1, transform);
+    } else if (do_join) {
+        draw_join<false>(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+    } else if ((style_flags & STYLE_FLAGS_END_CAP_MASK) == STYLE_FLAGS_CAP_ROUND) {
+        arc = arc_is_cap = true;
+        arc0 = pts.p3 + n_prev;
+        arc1 = pts.p3 - n_prev;
+    } else {
+        draw_cap<false>(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev, offset_tangent, transform);
+    }
+    if (arc) {
+        const uint32_t k = atomicAdd(&q.count, 1u);  // (< STROKE_ARCS: one per thread and round at most)
+        ArcItem it;
+        it.path_ix = path_ix; it.trans_ix = tag.monoid.trans_ix; it.flags = arc_is_cap ? ARC_IS_CAP : 0u; it.pad = 0u;
+        it.bx = arc0.x; it.by = arc0.y; it.ex = arc1.x; it.ey = arc1.y;
+        it.cx = pts.p3.x; it.cy = pts.p3.y; it.cr = cr; it.d = d;
+        it.box[0] = em.bx0; it.box[1] = em.by0; it.box[2] = em.bx1; it.box[3] = em.by1;
+        q.item[k] = it;
+        // (this thread's box travels with the arc: the lane that flattens the arc tests and merges the whole)
+        em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+    }
     return true;
 }
 
@@ -958,8 +1036,10 @@ __device__ bool flatten_stroked_line(Emitter &em, const Config &cfg, const uint3
 constexpr uint32_t FLATTEN_STROKE_LDS_LINES = 1536u;  // 30 KB per workgroup
 __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                             const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                            Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines) {
+                                                            Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines,
+                                                            uint32_t *arc_items, uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_STROKE_LDS_LINES> sh;
+    __shared__ ArcQueue arcs;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_lines_q = control->heavy_count[2];  // final: written by k_flatten_light
     if (n_lines_q < min_lines) return;  // k_flatten_heavy takes them
@@ -967,6 +1047,7 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
+        arcs.count = 0u;
     }
     __syncthreads();
     Bump *bump = &control->bump;
@@ -985,13 +1066,25 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
         uint32_t tag_ix = 0u;
         if (e < n_lines_q) {
             tag_ix = heavy_list[2u * n_tags + e];
-            hand_on = !flatten_stroked_line(em, cfg, scene, tag_monoids, tag_ix, key);
+            hand_on = !flatten_stroked_line(em, arcs, cfg, scene, tag_monoids, tag_ix, key);
             if (hand_on) key = 0xffffffffu;
             else if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
         }
         if (hand_on) heavy_list[n_tags + atomicAdd(&control->heavy_count[1], 1u)] = tag_ix;  // (rare: one atomic each is fine)
+        // the round's arcs go to the frame's list behind one atomic
+        __syncthreads();
+        {
+            const uint32_t n_arcs = arcs.count;
+            const uint32_t shard = blockIdx.x % FLATTEN_ARC_SHARDS;
+            if (tid == 0u && n_arcs != 0u) arcs.base = atomicAdd(&control->arc_count[shard], n_arcs);
+            __syncthreads();
+            // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
+            if (tid < n_arcs && arcs.base + tid < arc_shard_cap) reinterpret_cast<ArcItem *>(arc_items)[shard * arc_shard_cap + arcs.base + tid] = arcs.item[tid];
+            __syncthreads();
+            if (tid == 0u) arcs.count = 0u;
+        }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
         flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     }
@@ -1002,13 +1095,19 @@ constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgr
 __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                           Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
-                                                          uint32_t stroke_kernel_min_lines) {
+                                                          uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
     const uint32_t tid = threadIdx.x;
     // final counts: written by the previous kernel on this stream
     const uint32_t n_curves = control->heavy_count[0], n_strokes = control->heavy_count[1];
     const uint32_t n_lines_q = control->heavy_count[2] < stroke_kernel_min_lines ? control->heavy_count[2] : 0u;  // else k_flatten_strokes' work
-    const uint32_t n_heavy = n_curves + n_strokes + n_lines_q;
+    // the arcs k_flatten_strokes set aside are the list's last section: shard s holds arc_incl[s] - arc_excl of them
+    static_assert(FLATTEN_ARC_SHARDS == 64u, "a lane per shard");
+    const uint32_t arc_n = minu(control->arc_count[tid & 63u], arc_shard_cap);
+    const uint32_t arc_incl = wave_incl_scan_u32(arc_n, (int)(tid & 63u));
+    const uint32_t n_arcs = wave_read(arc_incl, 63u);
+    const uint32_t n_tag_entries = n_curves + n_strokes + n_lines_q;
+    const uint32_t n_heavy = n_tag_entries + n_arcs;
     // Lanes of a wave walk DIFFERENT subdivision trees, so a wave executes the union of its lanes' loops: as long as the
     // launch has more waves than the list has entries to fill them, every wave takes only as many entries as it must
     // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
@@ -1036,13 +1135,37 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         uint32_t key = 0xffffffffu;
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
         const uint32_t e = base + wave * lpw + lane;
-        if (lane < lpw && e < n_heavy) {
+        // which arc of which shard entry e is (if it is one): the shards' inclusive counts sit one per lane; the search is
+        // taken by all lanes together (shuffles)
+        uint32_t arc_shard = 0u, arc_local = 0u;
+        if (n_arcs != 0u) {
+            const uint32_t a = e >= n_tag_entries ? e - n_tag_entries : 0u;
+#pragma unroll
+            for (uint32_t step = 32u; step >= 1u; step >>= 1)
+                if (wave_shfl(arc_incl, arc_shard + step - 1u) <= a) arc_shard += step;
+            arc_shard = minu(arc_shard, 63u);
+            arc_local = a - wave_shfl(arc_incl - arc_n, arc_shard);
+        }
+        if (lane < lpw && e < n_tag_entries) {
             const uint32_t tag_ix = e < n_curves               ? heavy_list[e]
                                     : e < n_curves + n_strokes ? heavy_list[n_tags + (e - n_curves)]
                                                                : heavy_list[2u * n_tags + (e - n_curves - n_strokes)];
             key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
+            }
+        } else if (lane < lpw && e < n_heavy) {
+            // an arc k_flatten_strokes set aside: flatten_arc as draw_join / draw_cap call it, then the box of the thread
+            // that met it -- its other lines' and this arc's -- tested and merged as one (flatten.wgsl:916-921)
+            const ArcItem it = reinterpret_cast<const ArcItem *>(arc_items)[arc_shard * arc_shard_cap + arc_local];
+            em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+            const Xform t = read_transform(scene, cfg.layout.transform_base, it.trans_ix);
+            const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(atan2_cr(it.cr, it.d));
+            flatten_arc(em, it.path_ix, v2(it.bx, it.by), v2(it.ex, it.ey), v2(it.cx, it.cy), angle, t);
+            key = it.path_ix;
+            const float mx0 = minf(em.bx0, it.box[0]), my0 = minf(em.by0, it.box[1]), mx1 = maxf(em.bx1, it.box[2]), my1 = maxf(em.by1, it.box[3]);
+            if (mx1 > mx0 || my1 > my0) {
+                x0 = mx0; y0 = my0; x1 = mx1; y1 = my1;
             }
         }
         // list entries of one source workgroup keep tag order, so equal path keys still come in runs
@@ -1067,14 +1190,14 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     if (grid_heavy > 2048u) grid_heavy = 2048u;
     if (grid_heavy < 4u) grid_heavy = 4u;
     // (exits at once when the scene has too few stroked lines for a kernel of their own)
-    uint32_t grid_strokes = (n_seg_max + 255u) / 256u;
-    if (grid_strokes > 4096u) grid_strokes = 4096u;
-    if (grid_strokes < 1u) grid_strokes = 1u;
+    const uint32_t grid_strokes = flatten_strokes_grid(n_seg_max);
+    const uint32_t arc_shard_cap = flatten_arc_shard_cap(n_seg_max);
     if (f.launch_stroke_kernel)
         hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
-                       f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines);
+                       f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines, f.arc_items, arc_shard_cap);
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                       f.lines, f.heavy_list, f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu);  // (not launched: every line is the heavy kernel's)
+                       f.lines, f.heavy_list, f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu,  // (not launched: every line is the heavy kernel's)
+                       f.arc_items, arc_shard_cap);
 }
 
 }  // namespace vk

@@ -153,6 +153,12 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
     if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
     const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
     for (uint32_t chunk = blockIdx.x * PATH_COUNT_CHUNK; chunk < n_lines; chunk += gridDim.x * PATH_COUNT_CHUNK) {
+#ifdef VELLO_PC_TIMELINE
+        // measurement build (scripts/pc_timeline.py): per chunk, wall-clock stamps (100 MHz) of start / pass 1 done / slots
+        // reserved / pass 2 done in the tail of the SegmentCount pool
+        const uint32_t tl0 = (uint32_t)wall_clock64();
+        uint32_t tl1 = 0u, tl2 = 0u;
+#endif
         uint32_t my_total = 0u;
 #pragma unroll 1
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
@@ -164,8 +170,14 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         }
         uint32_t total;
         uint32_t incl = block256_incl_scan_u32(my_total, sh_scan, &total);
+#ifdef VELLO_PC_TIMELINE
+        tl1 = (uint32_t)wall_clock64();
+#endif
         if (tid == 0u) sh_base = total ? atomicAdd(&bump->seg_counts, total) : 0u;
         __syncthreads();
+#ifdef VELLO_PC_TIMELINE
+        tl2 = (uint32_t)wall_clock64();
+#endif
         uint32_t seg_base = sh_base + (incl - my_total);
         const int lane = (int)(tid & 63u);
 #pragma unroll 1
@@ -267,6 +279,16 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
             seg_base += count;
         }
         __syncthreads();  // sh_base / sh_scan reuse in the next chunk
+#ifdef VELLO_PC_TIMELINE
+        if (tid == 0u) {
+            const uint32_t slot = chunk / PATH_COUNT_CHUNK;
+            if (cfg.seg_counts_size > 2u * 8192u && slot < 8192u) {
+                SegmentCount *dst = seg_counts + (cfg.seg_counts_size - 2u * 8192u) + 2u * slot;
+                dst[0].line_ix = tl0; dst[0].counts = tl1;
+                dst[1].line_ix = tl2; dst[1].counts = (uint32_t)wall_clock64();
+            }
+        }
+#endif
     }
 }
 
