@@ -192,6 +192,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
         raise SystemExit(f"frame failed: {rc} {engine.bump()}")
     engine.stage_ms()
     bump = engine.bump()
+    slice_items, cov_words = engine.fine_slice_stats()  # fine's long tiles cut into slices (engine.h FINE_SLICE_FILLS)
     # the dominant kernel = the stage with the longest launch when frames run one at a time (with frames in flight a
     # stage's events also span the other frames' kernels that share the CUs with it)
     for _ in range(10):
@@ -290,6 +291,8 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     ovl_ms = dom_ms / max(dom_n, 1)
     res = {
         "engine": engine, "frame": frame, "steps": steps, "elapsed": elapsed, "own_fps": own_fps, "bump": bump, "dominant": dominant,
+        "fine_slices": {"slice_work_items": slice_items, "coverage_scratch_bytes": cov_words * 4,
+                        "rule": "MSAA: a tile of >= 96 FILLs is cut into slices of 32 fills (coverage by one wave per slice, composited by the last to finish)"},
         "exchange_ms": exchange_ms, "pcie_fps": pcie_fps, "pcie_pipelined_fps": pcie_pipelined_fps,
         "describe": wl.describe(engine),
         "frame_ms": {"median": pct(intervals, 0.5), "p10": pct(intervals, 0.1), "p90": pct(intervals, 0.9), "n": len(intervals)},
@@ -460,6 +463,7 @@ def main():
             "baseline_config": "configs[2]",
             "commit": git_head(),
             "fine_kernel": "k_fine",
+            "fine_slices": head["fine_slices"],
             "parallelism": f"scenes{world}" if distributed else "single",
             "exchange": "RCCL gather of RGBA8 frames to rank 0 each step" if distributed else "none",
             "exchange_alone_ms": None if head["exchange_ms"] is None else round(head["exchange_ms"], 4),
@@ -486,6 +490,7 @@ def main():
             "frame_ms_pipelined": second["frame_ms"],
             "frame_ms_one_at_a_time": second["serial_ms"],
             "bump": second["bump"],
+            "fine_slices": second["fine_slices"],
             "roofline": second["roofline"],
         }
     if world == 1 and not args.no_cpu_baseline and not args.timed_only:

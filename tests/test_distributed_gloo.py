@@ -228,6 +228,9 @@ def _bench_worker(rank, world, port, out_path):
         def bump(self):
             return {"failed": 0, "binning": 10, "ptcl": 1000, "tile": 100, "seg_counts": 50, "segments": 50, "blend": 0, "lines": 60}
 
+        def fine_slice_stats(self):
+            return 0, 0
+
     vello_amd.Engine = FakeEngine
     real_scene = workloads.paris_like_scene
     workloads.paris_like_scene = lambda seed: real_scene(seed, n_paths=60, size=1600.0)

@@ -923,3 +923,23 @@ def test_emu_fine_slices(emu_engine, name, body):
             assert emu_engine.fine_slice_stats()[0] > 0, "no tile was cut into slices"
     finally:
         emu_engine.set_debug_flags()
+
+
+def test_emu_fine_slices_survive_split_stage_ranges(emu_engine):
+    # vello_hip_run_stages seam: COARSE in one call, FINE in a later one.  Coarse cuts tiles into slices according to the
+    # number of slice blocks fine is going to launch; between the two calls the engine learns the scene's demand (sync reads
+    # the control block) and would size fine's grid differently -- fine must launch with what coarse was told.
+    packed, layout = workloads.random_test_scene(4, n_paths=500, size=256.0, strokes=True, clips=True).resolve()
+    emu_engine.set_debug_flags(fine_slices=True)
+    try:
+        ref, bump = emu_engine.render(packed, layout, 256, 256, BLACK, AaConfig.Msaa16)
+        assert bump["failed"] == 0 and emu_engine.fine_slice_stats()[0] > 0
+        emu_engine.upload_scene(packed, layout)   # (the demand is unknown again: a quarter of the tiles' worth of blocks)
+        emu_engine.run_stages(256, 256, BLACK, AaConfig.Msaa16, "pathtag_scan", "coarse")
+        assert emu_engine.sync() == 0             # (reads the control block: the demand is known now)
+        emu_engine.run_stages(256, 256, BLACK, AaConfig.Msaa16, "path_tiling", "fine")
+        assert emu_engine.sync() == 0
+        img = emu_engine.read_buffer("output", np.uint8, 256 * 256 * 4).reshape(256, 256, 4)
+        assert np.array_equal(img, ref)
+    finally:
+        emu_engine.set_debug_flags()

@@ -1,5 +1,6 @@
 // Engine-internal interface between the host driver (engine.hip) and the kernel translation units.
 #pragma once
+#include <cstddef>
 #include "common.h"
 
 namespace vk {
@@ -78,6 +79,9 @@ struct Control {
     uint32_t arc_count[64];
 };
 static_assert(sizeof(Control) == 512, "Control");
+// (coarse and fine reach slice_items / cov_words through the work_count pointer)
+static_assert(offsetof(Control, slice_items) == offsetof(Control, work_count) + 4u * FINE_WORK_BUCKETS, "Control::slice_items follows work_count");
+static_assert(offsetof(Control, cov_words) == offsetof(Control, slice_items) + 4u, "Control::cov_words follows slice_items");
 constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
 // k_flatten_strokes' grid for a scene of at most n_seg_max segments, and the arcs one shard of the arc list can be given
 // (256 per round of each of its workgroups); the list holds FLATTEN_ARC_SHARDS x that many 64-byte items

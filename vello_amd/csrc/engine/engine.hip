@@ -70,6 +70,7 @@ struct Lane {
     std::vector<EvPair> events;
     bool used = false;
     bool slices_on = false;   // the lane's latest frame ran with fine's slices enabled (an MSAA frame)
+    uint32_t slice_cap_coarse = 0;  // slice blocks the lane's latest COARSE launch was told of (a later FINE must launch as many)
     bool flatten_ran = false;  // the control block holds flatten's counts (a partial vello_hip_run_stages range may stop before it)
     uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
     uint64_t atlas_epoch_seen = 0;  // ctx::atlas_epoch the lane's stream has been ordered behind
@@ -445,8 +446,14 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     return 0;
 }
 
-int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f, int first, int last) {
+int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int last) {
     hipStream_t st = l.stream;
+    // coarse decides which tiles are cut into slices from the number of slice blocks fine is going to launch: a FINE that
+    // runs in a later call than its COARSE (vello_hip_run_stages) launches with the number COARSE was given, whatever
+    // the scene's demand is known to be by then
+    Frame f = f_in;
+    if (first > VELLO_HIP_STAGE_COARSE) f.slice_cap = l.slice_cap_coarse;
+    else l.slice_cap_coarse = f.slice_cap;
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
         Lane::EvPair ev{s, nullptr, nullptr};
