@@ -105,6 +105,7 @@ unsafe extern "C" {
     pub fn vello_hip_buffer_size(ctx: *mut vello_hip_ctx, buf_id: c_int) -> usize;
     pub fn vello_hip_set_profiling(ctx: *mut vello_hip_ctx, stage_mask: u32) -> c_int;
     pub fn vello_hip_get_stage_ms(ctx: *mut vello_hip_ctx, ms_out: *mut f32, count_out: *mut u32) -> c_int;
+    pub fn vello_hip_get_kernel_ms(ctx: *mut vello_hip_ctx, stage: c_int, ms_out: *mut f32, count_out: *mut u32) -> c_int;
     pub fn vello_hip_stage_name(stage: c_int) -> *const c_char;
     pub fn vello_hip_last_error(ctx: *mut vello_hip_ctx) -> *const c_char;
     pub fn vello_hip_make_mask_lut(out: *mut u8);

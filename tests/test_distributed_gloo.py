@@ -231,6 +231,11 @@ def _bench_worker(rank, world, port, out_path):
         def fine_slice_stats(self):
             return 0, 0
 
+        KERNELS = vello_amd.renderer.Engine.KERNELS
+
+        def kernel_ms(self):
+            return {k: (0.3, 10) for names in self.KERNELS.values() for k in names}
+
     vello_amd.Engine = FakeEngine
     real_scene = workloads.paris_like_scene
     workloads.paris_like_scene = lambda seed: real_scene(seed, n_paths=60, size=1600.0)

@@ -96,6 +96,7 @@ def load_library():
     sig("vello_hip_buffer_size", sz, [vp, i32])
     sig("vello_hip_set_profiling", i32, [vp, u32])
     sig("vello_hip_get_stage_ms", i32, [vp, c.POINTER(c.c_float), c.POINTER(u32)])
+    sig("vello_hip_get_kernel_ms", i32, [vp, i32, c.POINTER(c.c_float), c.POINTER(u32)])
     sig("vello_hip_stage_name", c.c_char_p, [i32])
     sig("vello_hip_last_error", c.c_char_p, [vp])
     sig("vello_hip_make_mask_lut", None, [vp])

@@ -767,7 +767,7 @@ int enable_coarse_lds() {
 #endif
 }
 
-void launch_coarse(const Frame &f, hipStream_t s) {
+void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     const uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
     if (wb * hb == 0) return;
     const uint32_t n_el_blocks = (f.cfg.layout.n_draw_objects + 255u) / 256u;
@@ -777,6 +777,7 @@ void launch_coarse(const Frame &f, hipStream_t s) {
     if (n_bit_blocks < 1u) n_bit_blocks = 1u;
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
+    if (mid) (void)hipEventRecord(mid[0], s);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,

@@ -149,7 +149,9 @@ struct Frame {
 };
 
 void launch_pathtag_scan(const Frame &f, hipStream_t s);
-void launch_flatten(const Frame &f, hipStream_t s);
+// (mid: when not null, an event is recorded behind every kernel of the stage but the last: per-KERNEL times of a stage of
+// several kernels, vello_hip_get_kernel_ms)
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr);
 void launch_draw_scan(const Frame &f, hipStream_t s);
 void launch_clip(const Frame &f, hipStream_t s);             // clip.hip
 void launch_clip_sequential(const Frame &f, hipStream_t s);  // draw.hip
@@ -157,7 +159,7 @@ void launch_binning(const Frame &f, hipStream_t s);
 void launch_tile_alloc(const Frame &f, hipStream_t s);
 void launch_path_count(const Frame &f, hipStream_t s);
 void launch_backdrop(const Frame &f, hipStream_t s);
-void launch_coarse(const Frame &f, hipStream_t s);
+void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr);
 int enable_coarse_lds();  // hipError_t of the per-device dynamic-LDS opt-in
 void launch_path_tiling(const Frame &f, hipStream_t s);
 void launch_fine(const Frame &f, hipStream_t s);

@@ -66,6 +66,7 @@ struct Lane {
     struct EvPair {
         int stage;
         hipEvent_t a, b;
+        hipEvent_t mid[2];  // behind the stage's first / second kernel when it has more than one (flatten: 3, coarse: 2)
     };
     std::vector<EvPair> events;
     bool used = false;
@@ -118,6 +119,8 @@ struct vello_hip_ctx {
     std::vector<hipEvent_t> event_pool;
     float stage_ms[VELLO_HIP_STAGE_COUNT] = {};
     uint32_t stage_count[VELLO_HIP_STAGE_COUNT] = {};
+    float kernel_ms[VELLO_HIP_STAGE_COUNT][3] = {};  // per kernel of the stages that are several (flatten, coarse)
+    uint32_t kernel_count[VELLO_HIP_STAGE_COUNT] = {};
     std::string last_error;
 };
 
@@ -456,10 +459,12 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     else l.slice_cap_coarse = f.slice_cap;
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
-        Lane::EvPair ev{s, nullptr, nullptr};
+        Lane::EvPair ev{s, nullptr, nullptr, {nullptr, nullptr}};
         if (prof) {
             ev.a = get_event(c);
             ev.b = get_event(c);
+            if (s == VELLO_HIP_STAGE_FLATTEN || s == VELLO_HIP_STAGE_COARSE) ev.mid[0] = get_event(c);
+            if (s == VELLO_HIP_STAGE_FLATTEN) ev.mid[1] = get_event(c);
             HIP_TRY(c, hipEventRecord(ev.a, st));
         }
         switch (s) {
@@ -470,7 +475,7 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             launch_pathtag_scan(f, st);
             break;
         case VELLO_HIP_STAGE_FLATTEN:
-            launch_flatten(f, st);
+            launch_flatten(f, st, prof ? ev.mid : nullptr);
             l.flatten_ran = true;
             break;
         case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, st); break;
@@ -479,7 +484,7 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, st); break;
         case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, st); break;
         case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, st); break;
-        case VELLO_HIP_STAGE_COARSE: launch_coarse(f, st); break;
+        case VELLO_HIP_STAGE_COARSE: launch_coarse(f, st, prof ? ev.mid : nullptr); break;
         case VELLO_HIP_STAGE_PATH_TILING: launch_path_tiling(f, st); break;
         case VELLO_HIP_STAGE_FINE: launch_fine(f, st); break;
         default: return VELLO_HIP_E_INVALID;
@@ -501,6 +506,17 @@ int drain_events(vello_hip_ctx *c) {
             HIP_TRY(c, hipEventElapsedTime(&ms, ev.a, ev.b));
             c->stage_ms[ev.stage] += ms;
             c->stage_count[ev.stage] += 1;
+            if (ev.mid[0]) {  // a -> mid[0] (-> mid[1]) -> b: the stage's kernels one by one
+                hipEvent_t pts[4] = {ev.a, ev.mid[0], ev.mid[1] ? ev.mid[1] : ev.b, ev.b};
+                const int n_k = ev.mid[1] ? 3 : 2;
+                for (int k = 0; k < n_k; k++) {
+                    float kms = 0.f;
+                    if (hipEventElapsedTime(&kms, pts[k], pts[k + 1]) == hipSuccess) c->kernel_ms[ev.stage][k] += kms;
+                }
+                c->kernel_count[ev.stage] += 1;
+                c->event_pool.push_back(ev.mid[0]);
+                if (ev.mid[1]) c->event_pool.push_back(ev.mid[1]);
+            }
             c->event_pool.push_back(ev.a);
             c->event_pool.push_back(ev.b);
         }
@@ -1217,6 +1233,20 @@ int vello_hip_get_stage_ms(vello_hip_ctx *c, float ms_out[VELLO_HIP_STAGE_COUNT]
         c->stage_ms[i] = 0.f;
         c->stage_count[i] = 0;
     }
+    return VELLO_HIP_OK;
+}
+
+int vello_hip_get_kernel_ms(vello_hip_ctx *c, int stage, float ms_out[3], uint32_t *count_out) {
+    if (!c || stage < 0 || stage >= VELLO_HIP_STAGE_COUNT || !ms_out) return VELLO_HIP_E_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = drain_events(c);
+    if (r) return r;
+    for (int k = 0; k < 3; k++) {
+        ms_out[k] = c->kernel_ms[stage][k];
+        c->kernel_ms[stage][k] = 0.f;
+    }
+    if (count_out) *count_out = c->kernel_count[stage];
+    c->kernel_count[stage] = 0;
     return VELLO_HIP_OK;
 }
 

@@ -1174,12 +1174,13 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     }
 }
 
-void launch_flatten(const Frame &f, hipStream_t s) {
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     uint32_t n_tags = f.n_tag_words * 4u;
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
     if (grid == 0) return;
     hipLaunchKernelGGL(k_flatten_light, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list);
+    if (mid) (void)hipEventRecord(mid[0], s);
     // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
     // (workgroups beyond the list exit at once)
     // (a segment owns at least one word of path data, so the path-data stream bounds the list even though the tag stream
@@ -1195,6 +1196,7 @@ void launch_flatten(const Frame &f, hipStream_t s) {
     if (f.launch_stroke_kernel)
         hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
                        f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines, f.arc_items, arc_shard_cap);
+    if (mid) (void)hipEventRecord(mid[1], s);
     hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                        f.lines, f.heavy_list, f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu,  // (not launched: every line is the heavy kernel's)
                        f.arc_items, arc_shard_cap);

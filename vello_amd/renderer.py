@@ -288,6 +288,19 @@ class Engine:
         self._check(self._lib.vello_hip_get_stage_ms(self._h, ms, cnt), "get_stage_ms")
         return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES))}
 
+    KERNELS = {"flatten": ("k_flatten_light", "k_flatten_strokes", "k_flatten_heavy"), "coarse": ("k_coarse_prep", "k_coarse")}
+
+    def kernel_ms(self):
+        """vello_hip_get_kernel_ms for the stages that are several kernels: {kernel: (summed ms, profiled launches)}."""
+        out = {}
+        for stage, names in self.KERNELS.items():
+            ms = (ctypes.c_float * 3)()
+            cnt = ctypes.c_uint32()
+            self._check(self._lib.vello_hip_get_kernel_ms(self._h, STAGES.index(stage), ms, ctypes.byref(cnt)), "get_kernel_ms")
+            for k, n in enumerate(names):
+                out[n] = (ms[k], cnt.value)
+        return out
+
 
 def estimate_capacities(packed, layout, width, height):
     """vello_hip_estimate_capacities: conservative pool sizes (dict) for a packed scene at a target size (host only)."""
