@@ -1569,20 +1569,18 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
         cov_base = it.cov_base;
         first_item = it.first_item;
     } else {
-        uint32_t rest = blockIdx.x - (AA != 0 ? slice_blocks : 0u);
-        bool found = false;
-        uint32_t slot = 0u;  // (ONE load behind the loop: a load under a condition in an unrolled loop is waited for where it stands)
-#pragma unroll
-        for (int b = (int)FINE_WORK_BUCKETS - 1; b >= 0; b--) {
-            const uint32_t cnt = minu(work_count[b], n_tiles);
-            if (!found && rest < cnt) {
-                slot = (uint32_t)b * n_tiles + rest;
-                found = true;
-            }
-            if (!found) rest -= cnt;
-        }
-        if (!found) return;
-        tile_ix = tile_order[slot];
+        const uint32_t rest = blockIdx.x - (AA != 0 ? slice_blocks : 0u);
+        // which bucket, which place in it: lane b holds the count of bucket 31 - b (longest lists first), a wave scan gives
+        // the buckets' ends, the first end beyond `rest` is the bucket (a scalar walk over the 32 counters was 450 SALU
+        // instructions at the head of every tile's wave)
+        static_assert(FINE_WORK_BUCKETS <= 64u, "a lane per bucket");
+        const uint32_t cnt = lane < FINE_WORK_BUCKETS ? minu(work_count[FINE_WORK_BUCKETS - 1u - lane], n_tiles) : 0u;
+        const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+        const unsigned long long beyond = __ballot(incl > rest);
+        if (beyond == 0ull) return;
+        const uint32_t bl = (uint32_t)__ffsll((long long)beyond) - 1u;  // (< FINE_WORK_BUCKETS: lanes beyond hold the total)
+        const uint32_t slot = (FINE_WORK_BUCKETS - 1u - bl) * n_tiles + (rest - wave_read(incl - cnt, bl));
+        tile_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_order[slot]);
         if (tile_ix >= n_tiles) return;  // (coarse registers every tile exactly once)
     }
     const uint32_t tile_x = tile_ix % cfg.width_in_tiles, tile_y = tile_ix / cfg.width_in_tiles;
