@@ -191,6 +191,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     if rc != 0:
         raise SystemExit(f"frame failed: {rc} {engine.bump()}")
     engine.stage_ms()
+    engine.kernel_ms()  # (both read-and-reset: what follows is measured one frame at a time)
     bump = engine.bump()
     slice_items, cov_words = engine.fine_slice_stats()  # fine's long tiles cut into slices (engine.h FINE_SLICE_FILLS)
     # the dominant kernel = the stage with the longest launch when frames run one at a time (with frames in flight a

@@ -231,13 +231,13 @@ struct FineBatch {
     uint32_t item[MS_ITEM_CAP];
     uint32_t seg_slot[64];                     // scratch of the slot-source scatter (lane numbers of the kept fills by rank)
     uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
-    uint32_t color[MS_BATCH_FILLS];            // the CMD_COLOR word behind slot k's FILL (valid for the slots of the regular prefix)
 };
 // What a staged fill's replay needs besides its records lives in two registers of lane `slot` (read with v_readlane, no
 // LDS round trip at the head of every fill): its record range [begin, end) and fill rule, packed, and its backdrop.
 struct SlotRegs {
     uint32_t pack;      // begin | end << 10 | even_odd << 20
     uint32_t backdrop;
+    uint32_t color;     // the CMD_COLOR word behind the slot's FILL (valid for the slots of the regular prefix)
 };
 constexpr uint32_t SLOT_END_SHIFT = 10u, SLOT_EO_SHIFT = 20u, SLOT_IX_MASK = 0x3ffu;
 static_assert(MS_ITEM_CAP <= SLOT_IX_MASK, "record indices are packed in 10 bits");
@@ -631,7 +631,6 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     wave_lds_sync();
     if (lane < n) {
         const bool eo = (my_rule_n & 1u) != 0u;
-        bt.color[lane] = my_color;
 #pragma unroll
         for (uint32_t k = 0; k < 4u; k++) bt.winding_y[lane][k] = eo ? 0u : 0x80808080u;
     }
@@ -676,6 +675,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         if (lane == 0u) my_begin = 0u;
         slots.pack = (my_begin & SLOT_IX_MASK) | ((my_end & SLOT_IX_MASK) << SLOT_END_SHIFT) | ((my_rule_n & 1u) << SLOT_EO_SHIFT);
         slots.backdrop = my_backdrop;
+        slots.color = my_color;
     }
     n_fast = minu(n_fit, pairs);
     if (n_fast != 0u) after_fast = win_base + wave_read(pos, 2u * n_fast - 1u) + 2u;
@@ -1650,7 +1650,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     bool samples_clean = false;             // MSAA: the sample counters hold their cleared (non-zero rule) value
     uint32_t pf_win = 0u, pf_base = 0xffffffffu;  // MSAA: the command window requested ahead for the next batch
     uint32_t fast_left = 0u, fast_after = 0u;     // MSAA: fills left in the batch's regular prefix / where the list goes on behind it
-    SlotRegs slots{0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
+    SlotRegs slots{0u, 0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
     uint32_t rec_pre = 0u, rec_pre_begin = ~0u;   // MSAA: the records requested ahead for the next fill
     for (;;) {
         ensure(cmd_ix, 4u);
@@ -1726,7 +1726,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                         if (mode == MODE_COV) {
                             store_cov();
                         } else {
-                            const vec4 fg = unpack4x8unorm((uint32_t)__builtin_amdgcn_readfirstlane((int)bt.color[batch_pos - 1u]));
+                            const vec4 fg = unpack4x8unorm(wave_read(slots.color, batch_pos - 1u));
 #pragma unroll
                             for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
                         }
