@@ -72,6 +72,7 @@ struct Lane {
     bool used = false;
     bool slices_on = false;   // the lane's latest frame ran with fine's slices enabled (an MSAA frame)
     uint32_t slice_cap_coarse = 0;  // slice blocks the lane's latest COARSE launch was told of (a later FINE must launch as many)
+    uint32_t slice_fills_coarse = 0;  // ... and the slice size it cut with (0: no slices -- an area-AA frame)
     bool flatten_ran = false;  // the control block holds flatten's counts (a partial vello_hip_run_stages range may stop before it)
     uint64_t frame_generation = 0;  // slot_of(...).generation when the lane's latest frame was set up
     uint64_t atlas_epoch_seen = 0;  // ctx::atlas_epoch the lane's stream has been ordered behind
@@ -455,8 +456,17 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     // runs in a later call than its COARSE (vello_hip_run_stages) launches with the number COARSE was given, whatever
     // the scene's demand is known to be by then
     Frame f = f_in;
-    if (first > VELLO_HIP_STAGE_COARSE) f.slice_cap = l.slice_cap_coarse;
-    else l.slice_cap_coarse = f.slice_cap;
+    if (first > VELLO_HIP_STAGE_COARSE) {
+        if (last >= VELLO_HIP_STAGE_FINE && l.slice_fills_coarse != f.slice_fills) {
+            // (coarse's sliced tiles are not in the work buckets: an area-AA fine would never render them)
+            c->last_error = "vello_hip_run_stages: fine's AA mode must be of the same kind (area / MSAA) as the one coarse ran with";
+            return VELLO_HIP_E_INVALID;
+        }
+        f.slice_cap = l.slice_cap_coarse;
+    } else if (last >= VELLO_HIP_STAGE_COARSE) {
+        l.slice_cap_coarse = f.slice_cap;
+        l.slice_fills_coarse = f.slice_fills;
+    }
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
         Lane::EvPair ev{s, nullptr, nullptr, {nullptr, nullptr}};
