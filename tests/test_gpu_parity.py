@@ -826,3 +826,32 @@ def test_fine_slices_repeatable_across_frames_in_flight(built):
     assert np.array_equal(first, ref.cpu().numpy())
     for t in targets[1:]:
         assert np.array_equal(first, t.cpu().numpy())
+
+
+def test_kernel_ms_splits_the_stages_of_several_kernels(built):
+    # vello_hip_get_kernel_ms: flatten (light / strokes / heavy) and coarse (prep / coarse) timed kernel by kernel with events
+    # between the launches; the parts add up to the stage (they share its first and last event)
+    import vello_amd
+    from vello_amd.renderer import STAGES
+
+    packed, layout = workloads.random_test_scene(9, n_paths=2000, size=1024.0, strokes=True, clips=True).resolve()
+    eng = vello_amd.Engine()
+    eng.upload_scene(packed, layout)
+    for _ in range(3):
+        eng.render_resident(1024, 1024, BLACK, AaConfig.Msaa16)
+        eng.sync()
+    eng.set_profiling(STAGES)
+    eng.stage_ms(); eng.kernel_ms()
+    n = 8
+    for _ in range(n):
+        eng.render_resident(1024, 1024, BLACK, AaConfig.Msaa16)
+        eng.sync_frame(0)
+    st, km = eng.stage_ms(), eng.kernel_ms()
+    eng.set_profiling([])
+    for stage, names in eng.KERNELS.items():
+        assert st[stage][1] == n and all(km[k][1] == n for k in names)
+        parts = sum(km[k][0] for k in names)
+        assert parts > 0.0 and abs(parts - st[stage][0]) <= 0.02 * st[stage][0] + 0.01, (stage, parts, st[stage][0])
+    assert km["k_flatten_light"][0] > 0.0 and km["k_coarse"][0] > km["k_coarse_prep"][0] * 0.1
+    # read-and-reset
+    assert all(v == (0.0, 0) for v in eng.kernel_ms().values())

@@ -1113,9 +1113,12 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
     // waves on four CUs); a long list fills the waves completely and strides.
     const uint32_t n_waves = gridDim.x * 4u;
-    // list entries per wave: full waves as soon as the list would otherwise need more waves than the chip holds (2048 at
-    // this kernel's 256 VGPRs); the workgroups are then scheduled one round each, dynamically
-    const uint32_t lpw = minu(maxu((n_heavy + 2047u) / 2048u, 1u), 64u);
+    // list entries per wave.  Up to 4 096 entries: ONE -- a wave per entry, two rounds of the chip's 2 048 wave slots at
+    // most, each wave as long as its own curve (a second entry in a wave makes the wave the union of two subdivision
+    // loops: tiger flatten 190 -> 146 us against two entries per wave).  Beyond: pack -- the launch is the sum of its
+    // waves, and denser waves are fewer of them (mmark-50k 334 -> 294 us with 49 entries per wave against 25; the road map
+    // pays 6 us one frame at a time and gains 3 % with frames in flight).  Round 3, measured over 1 / 2 / 4 K divisors.
+    const uint32_t lpw = n_heavy <= 4096u ? 1u : minu(maxu((n_heavy + 1023u) / 1024u, 1u), 64u);
     if (blockIdx.x * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
