@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
 // waves of a workgroup share the blocks of FOUR consecutive paths (block b of the group's path p goes to wave
 // (b + p) & 3): a typical path (99 tiles, one block) still gets a wave of its own, while the launch no longer ends with
 // one wave's chain of 97 dependent steps through the largest road (6 k tiles).
-constexpr uint32_t BACKDROP_BLOCK_TILES = 1024u;
+constexpr uint32_t BACKDROP_BLOCK_TILES = 512u;  // (round 3 sweep on d2: 2048 -> 52 us, 1024 -> 48, 512 -> 44.5, 256 -> 44.5)
 __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__restrict__ bump, const Path *__restrict__ paths, Tile *tiles) {
     if (bump->failed != 0u) return;
     const uint32_t lane = threadIdx.x & 63u, slice = threadIdx.x >> 6;
