@@ -250,7 +250,8 @@ size_t vello_hip_buffer_size(vello_hip_ctx *ctx, int buf_id);
 int vello_hip_set_profiling(vello_hip_ctx *ctx, uint32_t stage_mask);
 int vello_hip_get_stage_ms(vello_hip_ctx *ctx, float ms_out[VELLO_HIP_STAGE_COUNT], uint32_t count_out[VELLO_HIP_STAGE_COUNT]);
 /* The stages that are several kernels, kernel by kernel (events between the launches while the stage is profiled):
- * VELLO_HIP_STAGE_FLATTEN -> k_flatten_light, k_flatten_strokes, k_flatten_heavy; VELLO_HIP_STAGE_COARSE -> k_coarse_prep,
+ * VELLO_HIP_STAGE_FLATTEN -> k_flatten_light, k_flatten_main, k_flatten_tail with one frame in flight (k_flatten_light,
+ * k_flatten_strokes, k_flatten_heavy with several: vello_hip_set_frames_in_flight); VELLO_HIP_STAGE_COARSE -> k_coarse_prep,
  * k_coarse (third entry 0).  Summed milliseconds since the last call and the number of profiled launches of the stage;
  * zeros for a stage of one kernel (its time is vello_hip_get_stage_ms's).  Reading resets the sums. */
 int vello_hip_get_kernel_ms(vello_hip_ctx *ctx, int stage, float ms_out[3], uint32_t *count_out);

@@ -853,7 +853,12 @@ def test_emu_stroked_line_kernel(emu_engine, case):
     try:
         for aa in (AaConfig.Area, AaConfig.Msaa16):
             compare_frame(emu_engine, packed, layout, w, h, WHITE, aa, f"emu_strokekernel_{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+        # with frames in flight the stroke workgroups are a kernel of their own ahead of the heavy list's (k_flatten_strokes,
+        # k_flatten_heavy) instead of part of its launch (k_flatten_main, k_flatten_tail)
+        emu_engine.set_frames_in_flight(2)
+        compare_frame(emu_engine, packed, layout, w, h, WHITE, AaConfig.Msaa16, f"emu_strokekernel_{name}_2inflight")
     finally:
+        emu_engine.set_frames_in_flight(1)
         emu_engine.set_debug_flags()
         emu_engine.set_auto_grow(False)
 

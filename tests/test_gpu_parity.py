@@ -202,6 +202,21 @@ def test_config_c3_d2_scene_full_size(built):
     # rendered is the NO_CULL one, whose lists are the longest
     items, cov_words = eng.fine_slice_stats()
     assert items > 100 and cov_words > 0, "no tile of the d2 scene went through fine's sliced path"
+    # with frames in flight flatten launches the stroked lines' workgroups as a kernel of their own (k_flatten_strokes ->
+    # k_flatten_heavy) instead of beside the heavy list's (k_flatten_main -> k_flatten_tail, what compare_frame just checked):
+    # same lines, same image
+    import torch
+
+    eng.set_frames_in_flight(3)
+    eng.upload_scene(packed, layout)
+    targets = [torch.zeros((1600, 1600, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+    torch.cuda.synchronize()
+    for t in targets:
+        eng.render_resident(1600, 1600, WHITE, AaConfig.Msaa16, out=t)
+    assert eng.sync() == 0
+    assert eng.bump()["lines"] == bump["lines"]
+    for t in targets:
+        assert np.array_equal(t.cpu().numpy(), img)
 
 
 def test_config_c4_mmark_reduced(gpu_engine):
@@ -672,7 +687,12 @@ def test_gpu_stroked_line_kernel(gpu_engine, case):
     try:
         for aa in (AaConfig.Area, AaConfig.Msaa16):
             compare_frame(gpu_engine, packed, layout, w, h, 0xFFFFFFFF, aa, f"gpu_strokekernel_{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+        # with frames in flight the stroke workgroups are a kernel of their own ahead of the heavy list's (k_flatten_strokes,
+        # k_flatten_heavy) instead of part of its launch (k_flatten_main, k_flatten_tail)
+        gpu_engine.set_frames_in_flight(2)
+        compare_frame(gpu_engine, packed, layout, w, h, 0xFFFFFFFF, AaConfig.Msaa16, f"gpu_strokekernel_{name}_2inflight")
     finally:
+        gpu_engine.set_frames_in_flight(1)
         gpu_engine.set_debug_flags()
         gpu_engine.set_auto_grow(False)
 

@@ -26,8 +26,9 @@ constexpr uint32_t FAILED_INTERNAL = 0x80000000u;  // set in bump.failed when a 
 // every later stage that would index with those counts bails out, the frame reports VELLO_HIP_E_INVALID
 constexpr uint32_t FAILED_SCENE = 0x40000000u;
 constexpr uint32_t FINE_WORK_BUCKETS = 32;  // buckets of 32 command words (the last one: 992 and more)
-// Stroked lines get a kernel of their own (k_flatten_strokes) once they alone fill the chip twice over at its 12 waves per CU
-// (256 CUs x 12 x 64 lanes); below that they ride along in k_flatten_heavy, whose duration the curves set anyway.
+// Stroked lines get workgroups of their own (beside the heavy list's in k_flatten_main with one frame in flight, as
+// k_flatten_strokes ahead of k_flatten_heavy with several) once they alone fill the chip twice over at 12 waves per CU
+// (256 CUs x 12 x 64 lanes); below that they are entries of the heavy list, whose duration the curves set anyway.
 constexpr uint32_t FLATTEN_STROKE_KERNEL_MIN_LINES = 2u * 256u * 12u * 64u;
 // command words from which a tile counts as long: its wave raises its issue priority (s_setprio) in k_fine
 constexpr uint32_t FINE_HEAVY_WORDS = 384;
@@ -68,13 +69,14 @@ struct Control {
     Bump bump;              // must be first: VELLO_HIP_BUF_BUMP aliases it
     uint32_t ticket_pathtag;
     uint32_t ticket_draw;
-    uint32_t heavy_count[3];  // flatten: tags queued by k_flatten_light: [0] fill curves, [1] strokes, [2] stroked lines
-    uint32_t pad[3];
+    uint32_t heavy_count[4];  // flatten: tags queued by k_flatten_light: [0] fill curves, [1] strokes, [2] stroked lines; [3] stroked lines
+                              // the stroke workgroups of k_flatten_main hand on to k_flatten_tail
+    uint32_t pad[2];
     uint32_t work_count[FINE_WORK_BUCKETS];  // coarse -> fine: tiles per bucket of command-list length (k_fine runs the long ones first)
     uint32_t slice_items;   // coarse -> fine: SliceItems handed out (may run past the capacity: fine clamps); work_count[BUCKETS]
     uint32_t cov_words;     // coarse -> fine: words of the coverage scratch handed out
     uint32_t pad2[48 - FINE_WORK_BUCKETS - 2];
-    // flatten: arcs k_flatten_strokes set aside, counted in FLATTEN_ARC_SHARDS sub-lists (workgroup b appends to shard b mod
+    // flatten: arcs the stroke workgroups set aside, counted in FLATTEN_ARC_SHARDS sub-lists (workgroup b appends to shard b mod
     // 64): ONE counter took 2 800 same-address atomics of ~12 ns each in a burst -- 30 us on the road-map scene
     uint32_t arc_count[64];
 };
@@ -83,7 +85,7 @@ static_assert(sizeof(Control) == 512, "Control");
 static_assert(offsetof(Control, slice_items) == offsetof(Control, work_count) + 4u * FINE_WORK_BUCKETS, "Control::slice_items follows work_count");
 static_assert(offsetof(Control, cov_words) == offsetof(Control, slice_items) + 4u, "Control::cov_words follows slice_items");
 constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
-// k_flatten_strokes' grid for a scene of at most n_seg_max segments, and the arcs one shard of the arc list can be given
+// the stroke workgroups of a scene of at most n_seg_max segments, and the arcs one shard of the arc list can be given
 // (256 per round of each of its workgroups); the list holds FLATTEN_ARC_SHARDS x that many 64-byte items
 inline uint32_t flatten_strokes_grid(uint32_t n_seg_max) {
     uint32_t g = (n_seg_max + 255u) / 256u;
@@ -104,7 +106,7 @@ struct Frame {
     const uint32_t *scene;
     Control *control;
     uint32_t *heavy_list;   // flatten: tag indices that need the Euler-spiral / stroker path
-    uint32_t *arc_items;    // flatten: 16 words per round join / cap arc that k_flatten_strokes leaves to k_flatten_heavy
+    uint32_t *arc_items;    // flatten: 16 words per round join / cap arc that a stroke workgroup leaves to the heavy code
     unsigned long long *pathtag_state;  // [n_pathtag_parts][2][5]
     unsigned long long *draw_state;     // [n_draw_parts][2][4]
     TagMonoid *tag_monoids;
@@ -138,8 +140,9 @@ struct Frame {
     uint32_t n_ramps;
     const uint32_t *atlas;  // RGBA8 image atlas (render.rs:160-203), atlas_w x atlas_h texels
     uint32_t atlas_w, atlas_h;
-    uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which k_flatten_strokes takes them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
-    bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that k_flatten_strokes would exit at once
+    uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which stroke workgroups take them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
+    bool flatten_side_by_side;  // flatten: stroke workgroups in the heavy list's launch (one frame in flight) instead of a kernel before it
+    bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that stroke workgroups would exit at once
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)

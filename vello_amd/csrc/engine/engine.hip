@@ -44,7 +44,7 @@ struct SceneSlot {
     bool brushes = false;   // gradient / image / blurred-rect draw objects present (selects fine's specialisation)
     bool resident = false;
     // stroked-line tags of the scene as k_flatten_light counted them in an earlier frame (-1: not known yet).  A property of
-    // the scene alone; lets the host leave out a k_flatten_strokes launch that would exit at once.
+    // the scene alone; lets the host leave out stroke workgroups that would exit at once.
     int64_t stroke_lines = -1;
     int64_t slice_demand = -1;  // slice items coarse asked for in a finished MSAA frame of this scene (max seen), -1 unknown
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
@@ -61,8 +61,8 @@ struct Lane {
     DevBuf tile_bits;                 // coarse: 3 bit planes over the tile pool
     DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
     DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
-    DevBuf heavy_list;                // flatten: tag indices for k_flatten_heavy (one u32 per tag, worst case)
-    DevBuf arc_items;                 // flatten: arcs left to k_flatten_heavy by k_flatten_strokes (64 B per segment, worst case)
+    DevBuf heavy_list;                // flatten: tag indices for the heavy code, 4 lists (one u32 per tag each, worst case)
+    DevBuf arc_items;                 // flatten: arcs the stroke workgroups leave to the heavy code (64 B per segment, worst case)
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -280,7 +280,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PATHS], (size_t)(align_up(L.n_paths, 256u) + 256u) * sizeof(Path)))) return r;
     if ((r = ensure(c, l.clip_stack, clip_scratch_words(L.n_clips) * 4u))) return r;
     if ((r = ensure(c, l.coarse_el, (size_t)(L.n_draw_objects + 1u) * sizeof(CoarseEl)))) return r;
-    if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 48u))) return r;  // 3 lists x 4 tags per word x u32
+    if ((r = ensure(c, l.heavy_list, (size_t)(sc.n_tag_words + 1u) * 64u))) return r;  // 4 lists x 4 tags per word x u32
     {
         // one arc per stroked segment at most; a segment owns at least one word of path data (the tag stream is padded)
         const size_t n_tags = (size_t)sc.n_tag_words * 4u, n_data = (size_t)L.draw_tag_base - L.path_data_base;
@@ -435,6 +435,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
+    f.flatten_side_by_side = c->n_active == 1u;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;

@@ -798,7 +798,7 @@ __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t
 // line.  Inlined next to the Euler-spiral / stroker code they inherit its 256 VGPRs (2 waves per SIMD), and the
 // kernel is bound by the chain of dependent loads tag -> monoid -> style / transform / points with nothing to hide
 // it behind.  This kernel handles exactly those tags (and the PATH markers) with a small register budget; every
-// other segment tag is queued for k_flatten_heavy, curves and strokes on separate lists so that its waves are
+// other segment tag is queued for the heavy code, curves and strokes on separate lists so that its waves are
 // homogeneous (a wave mixing 8 cubics with 56 stroked lines runs the subdivision loop at 1/8 lane use).
 // Returns 0 = done, HEAVY_CURVE or HEAVY_STROKE.
 constexpr uint32_t HEAVY_CURVE = 1u, HEAVY_STROKE = 2u, HEAVY_STROKE_LINE = 3u;
@@ -894,8 +894,8 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     if (tid < 3u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
     __syncthreads();
-    // curves fill heavy_list[0, n_tags), strokes [n_tags, 2 n_tags) (k_flatten_strokes appends the lines it hands on there),
-    // stroked lines [2 n_tags, 3 n_tags)
+    // curves fill heavy_list[0, n_tags), strokes [n_tags, 2 n_tags), stroked lines [2 n_tags, 3 n_tags) (the stroke workgroups
+    // append the lines they hand on to [3 n_tags, 4 n_tags))
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
     for (uint32_t i = tid; i < sh_n_heavy[1]; i += 256u) heavy_list[n_tags + sh_heavy_base[1] + i] = sh_heavy[FLATTEN_BLOCK_TAGS - 1u - i];
     for (uint32_t i = tid; i < sh_n_heavy[2]; i += 256u) heavy_list[2u * n_tags + sh_heavy_base[2] + i] = sh_lines[i];
@@ -904,9 +904,9 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
 // ---- stroked lines: flatten_tag's stroke branch without the Euler-spiral flattener ------------------------------
 // Same operations in the same order as flatten_tag -> flatten_euler's straight-segment shortcut -> draw_join / draw_cap.
 // Returns false (having emitted nothing) for a line flatten_euler would not take that shortcut for (degenerate, or offset
-// lines that fail the straight-segment test): the caller queues it for k_flatten_heavy.
+// lines that fail the straight-segment test): the caller queues it for the heavy code.
 // An arc of a round join or cap whose lines cannot be told without the exact transcendentals (atan2, acos, sincos in fp64):
-// set aside by the lane of k_flatten_strokes that met it and flattened by a lane of its own in k_flatten_heavy, where such
+// set aside by the lane of the stroke workgroup that met it and flattened by a lane of its own of the heavy code, where such
 // arcs are dense (a few per cent of a road map's stroked lines: inline, nearly every wave walked the fp64 routines for its
 // one or two of them).  16 words; the workgroup collects its arcs in LDS and appends them to the frame's list behind ONE
 // atomic.
@@ -1028,22 +1028,32 @@ __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg
     return true;
 }
 
-// Runs between k_flatten_light and k_flatten_heavy when the scene has enough stroked lines to occupy the chip on their own
-// (FLATTEN_STROKE_KERNEL_MIN_LINES): a thread per line at 3 waves per SIMD and 30 KB of staging, instead of the heavy
-// kernel's 2 waves per SIMD (256 VGPRs, 60 KB).  One frame at a time this is a little slower (the curves of the heavy
-// kernel no longer have the lines to overlap with: d2 flatten 145 -> 164 us); with frames in flight, which is what the
-// chip time is for, d2 gains 4 %.
-constexpr uint32_t FLATTEN_STROKE_LDS_LINES = 1536u;  // 30 KB per workgroup
-__global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
-                                                            const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                            Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines,
-                                                            uint32_t *arc_items, uint32_t arc_shard_cap) {
-    __shared__ FlattenShared<FLATTEN_STROKE_LDS_LINES> sh;
-    __shared__ ArcQueue arcs;
+// ---- the kernels behind k_flatten_light ------------------------------------------------------------------------
+// k_flatten_main: two kinds of workgroups in ONE launch (round 3; they were two kernels one after the other: the heavy
+// list's long subdivision chains at a few waves per CU, 57-63 us on the road map, and the stroked lines' throughput
+// work, 47 us -- neither needs the other's result):
+//  * HEAVY workgroups [0, n_heavy_blocks): the lists k_flatten_light left -- curves, strokes and, below
+//    FLATTEN_STROKE_KERNEL_MIN_LINES, the stroked lines -- through flatten_tag (Euler-spiral flattener + stroker);
+//  * STROKE workgroups behind them (scenes with enough stroked lines to occupy the chip on their own): a thread per line,
+//    flatten_tag's stroke branch with flatten_euler reduced to its straight-segment shortcut, round joins that are one
+//    line emitted without transcendentals, the other arcs set aside (ArcItem), a line that is not straight after all
+//    handed on (heavy_list's fourth section).
+// k_flatten_tail: what the stroke workgroups set aside -- the arcs, densely, and the handed-on lines -- by the heavy
+// code once more.  Launched only with stroke workgroups.
+constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB of staging per workgroup; with a stroke workgroup's arc queue (16 KB) two fit a CU
+constexpr uint32_t FLATTEN_STROKE_ROUND_LINES = 1536u;  // what one round of a stroke workgroup (256 stroked lines) emits at most, nearly always
+constexpr size_t FLATTEN_ARCS_AT = (sizeof(FlattenShared<FLATTEN_LDS_LINES>) + 15u) & ~(size_t)15u;  // the stroke workgroups' arc queue behind the staging
+constexpr size_t FLATTEN_MAIN_LDS = FLATTEN_ARCS_AT + sizeof(ArcQueue);
+
+template <uint32_t CAP>
+__device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueue &arcs, uint32_t block, uint32_t n_blocks, const Config &cfg,
+                                 uint32_t n_tags, const uint32_t *__restrict__ scene, const TagMonoid *__restrict__ tag_monoids,
+                                 PathBbox *path_bboxes, Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines,
+                                 uint32_t *arc_items, uint32_t arc_shard_cap) {
     const uint32_t tid = threadIdx.x;
     const uint32_t n_lines_q = control->heavy_count[2];  // final: written by k_flatten_light
-    if (n_lines_q < min_lines) return;  // k_flatten_heavy takes them
-    if (blockIdx.x * 256u >= n_lines_q || (control->bump.failed & FAILED_SCENE) != 0u) return;
+    if (n_lines_q < min_lines) return;  // the heavy workgroups take them
+    if (block * 256u >= n_lines_q || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
@@ -1053,7 +1063,7 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
     Bump *bump = &control->bump;
     const uint32_t lane = tid & 63u;
 #pragma unroll 1
-    for (uint32_t base = blockIdx.x * 256u; base < n_lines_q; base += gridDim.x * 256u) {
+    for (uint32_t base = block * 256u; base < n_lines_q; base += n_blocks * 256u) {
         Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
@@ -1072,12 +1082,14 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
         }
-        if (hand_on) heavy_list[n_tags + atomicAdd(&control->heavy_count[1], 1u)] = tag_ix;  // (rare: one atomic each is fine)
+        // (rare: one atomic each is fine.  A list of its own: the heavy workgroups of this launch read the lengths of the
+        // other three while this one grows)
+        if (hand_on) heavy_list[3u * n_tags + atomicAdd(&control->heavy_count[3], 1u)] = tag_ix;
         // the round's arcs go to the frame's list behind one atomic
         __syncthreads();
         {
             const uint32_t n_arcs = arcs.count;
-            const uint32_t shard = blockIdx.x % FLATTEN_ARC_SHARDS;
+            const uint32_t shard = block % FLATTEN_ARC_SHARDS;
             if (tid == 0u && n_arcs != 0u) arcs.base = atomicAdd(&control->arc_count[shard], n_arcs);
             __syncthreads();
             // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
@@ -1086,50 +1098,58 @@ __global__ void __launch_bounds__(256, 3) k_flatten_strokes(Config cfg, uint32_t
             if (tid == 0u) arcs.count = 0u;
         }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
-        flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
+        // The soup's bump counter takes one atomic per flush, and the ~3 000 of a road map's rounds, all to one address, are
+        // 33 us of the chip's time whatever else the workgroups do: keep staging while another round still fits (two rounds
+        // per flush, nearly always).  (sh.count: every emit of the round is behind the barriers of the arc block above)
+        const bool last_round = base + n_blocks * 256u >= n_lines_q;
+        if (last_round || sh.count + FLATTEN_STROKE_ROUND_LINES > CAP) flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     }
 }
 
-// ---- heavy kernel: curves that need subdivision and everything stroked ----------------------------------------
-constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB per workgroup, 2 workgroups per CU
-__global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
-                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
-                                                          uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
-    __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
+// The heavy code over its list.  LISTS & HEAVY_FIRST: [curves | strokes | stroked lines below the threshold] as k_flatten_light
+// left them; LISTS & HEAVY_SET_ASIDE: [handed-on lines | arcs] as stroke workgroups -- of an EARLIER launch -- left them.
+constexpr uint32_t HEAVY_FIRST = 1u, HEAVY_SET_ASIDE = 2u;
+template <uint32_t LISTS>
+__device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES> &sh, uint32_t block, uint32_t n_blocks, const Config &cfg, uint32_t n_tags,
+                                                 const uint32_t *__restrict__ scene, const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                 Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
+                                                 uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
+    constexpr bool FIRST = (LISTS & HEAVY_FIRST) != 0u, ASIDE = (LISTS & HEAVY_SET_ASIDE) != 0u;
     const uint32_t tid = threadIdx.x;
     // final counts: written by the previous kernel on this stream
-    const uint32_t n_curves = control->heavy_count[0], n_strokes = control->heavy_count[1];
-    const uint32_t n_lines_q = control->heavy_count[2] < stroke_kernel_min_lines ? control->heavy_count[2] : 0u;  // else k_flatten_strokes' work
-    // the arcs k_flatten_strokes set aside are the list's last section: shard s holds arc_incl[s] - arc_excl of them
+    const uint32_t n_curves = FIRST ? control->heavy_count[0] : 0u;
+    const uint32_t n_strokes = FIRST ? control->heavy_count[1] : 0u;
+    const uint32_t n_handed = ASIDE ? control->heavy_count[3] : 0u;
+    const uint32_t n_lines_q = FIRST && control->heavy_count[2] < stroke_kernel_min_lines ? control->heavy_count[2] : 0u;  // else the stroke workgroups' work
+    // the arcs the stroke workgroups set aside are the list's last section: shard s holds arc_incl[s] - arc_excl of them
     static_assert(FLATTEN_ARC_SHARDS == 64u, "a lane per shard");
-    const uint32_t arc_n = minu(control->arc_count[tid & 63u], arc_shard_cap);
+    const uint32_t arc_n = ASIDE ? minu(control->arc_count[tid & 63u], arc_shard_cap) : 0u;
     const uint32_t arc_incl = wave_incl_scan_u32(arc_n, (int)(tid & 63u));
     const uint32_t n_arcs = wave_read(arc_incl, 63u);
-    const uint32_t n_tag_entries = n_curves + n_strokes + n_lines_q;
+    const uint32_t n_tag_entries = n_curves + n_strokes + n_handed + n_lines_q;
     const uint32_t n_heavy = n_tag_entries + n_arcs;
     // Lanes of a wave walk DIFFERENT subdivision trees, so a wave executes the union of its lanes' loops: as long as the
     // launch has more waves than the list has entries to fill them, every wave takes only as many entries as it must
     // (a 900-curve SVG gets a wave per curve on 900 of the chip's 2048 wave slots instead of 64 curves in each of 15
     // waves on four CUs); a long list fills the waves completely and strides.
-    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t n_waves = n_blocks * 4u;
     // list entries per wave.  Up to 4 096 entries: ONE -- a wave per entry, two rounds of the chip's 2 048 wave slots at
     // most, each wave as long as its own curve (a second entry in a wave makes the wave the union of two subdivision
     // loops: tiger flatten 190 -> 146 us against two entries per wave).  Beyond: pack -- the launch is the sum of its
     // waves, and denser waves are fewer of them (mmark-50k 334 -> 294 us with 49 entries per wave against 25; the road map
     // pays 6 us one frame at a time and gains 3 % with frames in flight).  Round 3, measured over 1 / 2 / 4 K divisors.
     const uint32_t lpw = n_heavy <= 4096u ? 1u : minu(maxu((n_heavy + 1023u) / 1024u, 1u), 64u);
-    if (blockIdx.x * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
+    if (block * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
         sh.lds_end = 0xffffffffu;
     }
     __syncthreads();
     Bump *bump = &control->bump;
-    const uint32_t lane = tid & 63u, wave = blockIdx.x * 4u + (tid >> 6);
+    const uint32_t lane = tid & 63u, wave = block * 4u + (tid >> 6);
     // no indirect dispatch in HIP: a fixed grid strides over the list
 #pragma unroll 1
-    for (uint32_t base = 0u; base + blockIdx.x * 4u * lpw < n_heavy; base += n_waves * lpw) {
+    for (uint32_t base = 0u; base + block * 4u * lpw < n_heavy; base += n_waves * lpw) {
         Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
@@ -1141,7 +1161,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
         // which arc of which shard entry e is (if it is one): the shards' inclusive counts sit one per lane; the search is
         // taken by all lanes together (shuffles)
         uint32_t arc_shard = 0u, arc_local = 0u;
-        if (n_arcs != 0u) {
+        if (ASIDE && n_arcs != 0u) {
             const uint32_t a = e >= n_tag_entries ? e - n_tag_entries : 0u;
 #pragma unroll
             for (uint32_t step = 32u; step >= 1u; step >>= 1)
@@ -1150,15 +1170,17 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
             arc_local = a - wave_shfl(arc_incl - arc_n, arc_shard);
         }
         if (lane < lpw && e < n_tag_entries) {
-            const uint32_t tag_ix = e < n_curves               ? heavy_list[e]
-                                    : e < n_curves + n_strokes ? heavy_list[n_tags + (e - n_curves)]
-                                                               : heavy_list[2u * n_tags + (e - n_curves - n_strokes)];
+            const uint32_t e1 = e - n_curves, e3 = e1 - n_strokes, e2 = e3 - n_handed;
+            const uint32_t tag_ix = e < n_curves     ? heavy_list[e]
+                                    : e1 < n_strokes ? heavy_list[n_tags + e1]
+                                    : e3 < n_handed  ? heavy_list[3u * n_tags + e3]
+                                                     : heavy_list[2u * n_tags + e2];
             key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
-        } else if (lane < lpw && e < n_heavy) {
-            // an arc k_flatten_strokes set aside: flatten_arc as draw_join / draw_cap call it, then the box of the thread
+        } else if (ASIDE && lane < lpw && e < n_heavy) {
+            // an arc a stroke workgroup set aside: flatten_arc as draw_join / draw_cap call it, then the box of the thread
             // that met it -- its other lines' and this arc's -- tested and merged as one (flatten.wgsl:916-921)
             const ArcItem it = reinterpret_cast<const ArcItem *>(arc_items)[arc_shard * arc_shard_cap + arc_local];
             em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
@@ -1177,6 +1199,55 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
     }
 }
 
+__global__ void __launch_bounds__(256, 2) k_flatten_main(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                         const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                         Control *control, LineSoup *lines, uint32_t *heavy_list,
+                                                         uint32_t stroke_kernel_min_lines, uint32_t *arc_items, uint32_t arc_shard_cap,
+                                                         uint32_t n_heavy_blocks) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[FLATTEN_MAIN_LDS];
+    if (blockIdx.x < n_heavy_blocks) {
+        heavy_workgroups<HEAVY_FIRST>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), blockIdx.x, n_heavy_blocks, cfg, n_tags, scene, tag_monoids,
+                                      path_bboxes, control, lines, heavy_list, stroke_kernel_min_lines, arc_items, arc_shard_cap);
+    } else {
+        stroke_workgroup(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), *reinterpret_cast<ArcQueue *>(smem + FLATTEN_ARCS_AT),
+                         blockIdx.x - n_heavy_blocks, gridDim.x - n_heavy_blocks, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines,
+                         heavy_list, stroke_kernel_min_lines, arc_items, arc_shard_cap);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_flatten_tail(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                         const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                         Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
+                                                         const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
+    __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
+    heavy_workgroups<HEAVY_SET_ASIDE>(sh, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, 0u, arc_items,
+                                      arc_shard_cap);
+}
+
+// ... and the same work as two launches one after the other, for frames in flight: what k_flatten_main gains by running the
+// two kinds side by side only matters to a frame that has the chip to itself, and its stroke workgroups hold the 256
+// registers and 76 KB its heavy ones need -- room the kernels of the other frames would use (76 registers, 47 KB here:
+// a road map renders 2.5 % faster with frames in flight this way, 6 % slower one at a time; round 3, same-box A/B).
+__global__ void __launch_bounds__(256) k_flatten_strokes(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                        const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes, Control *control,
+                                                        LineSoup *lines, uint32_t *heavy_list, uint32_t min_lines, uint32_t *arc_items,
+                                                        uint32_t arc_shard_cap) {
+    __shared__ FlattenShared<FLATTEN_STROKE_ROUND_LINES> sh;  // 30 KB of staging + 16 KB of arcs: three workgroups per CU
+    __shared__ ArcQueue arcs;
+    stroke_workgroup(sh, arcs, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, min_lines, arc_items,
+                     arc_shard_cap);
+}
+
+__global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
+                                                          uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items,
+                                                          uint32_t arc_shard_cap) {
+    __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
+    heavy_workgroups<HEAVY_FIRST | HEAVY_SET_ASIDE>(sh, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list,
+                                                    stroke_kernel_min_lines, arc_items, arc_shard_cap);
+}
+
 void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     uint32_t n_tags = f.n_tag_words * 4u;
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
@@ -1193,16 +1264,31 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     uint32_t grid_heavy = (n_seg_max + 3u) / 4u;
     if (grid_heavy > 2048u) grid_heavy = 2048u;
     if (grid_heavy < 4u) grid_heavy = 4u;
-    // (exits at once when the scene has too few stroked lines for a kernel of their own)
-    const uint32_t grid_strokes = flatten_strokes_grid(n_seg_max);
+    // (stroke workgroups leave at once when the scene has too few stroked lines for workgroups of their own; they are not
+    // launched at all once a finished frame of the scene has shown that)
+    const uint32_t grid_strokes = f.launch_stroke_kernel ? flatten_strokes_grid(n_seg_max) : 0u;
     const uint32_t arc_shard_cap = flatten_arc_shard_cap(n_seg_max);
-    if (f.launch_stroke_kernel)
-        hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
-                       f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines, f.arc_items, arc_shard_cap);
-    if (mid) (void)hipEventRecord(mid[1], s);
-    hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                       f.lines, f.heavy_list, f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu,  // (not launched: every line is the heavy kernel's)
-                       f.arc_items, arc_shard_cap);
+    const uint32_t min_lines = f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu;  // (no stroke workgroups: every line is the heavy ones')
+    if (f.flatten_side_by_side) {
+        hipLaunchKernelGGL(k_flatten_main, dim3(grid_heavy + grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
+                           f.control, f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap, grid_heavy);
+        if (mid) (void)hipEventRecord(mid[1], s);
+        // what the stroke workgroups set aside (arcs: a few per cent of the lines; handed-on lines: nearly none)
+        if (grid_strokes != 0u) {
+            uint32_t grid_tail = (n_seg_max / 16u + 3u) / 4u;
+            if (grid_tail > 1024u) grid_tail = 1024u;
+            if (grid_tail < 4u) grid_tail = 4u;
+            hipLaunchKernelGGL(k_flatten_tail, dim3(grid_tail), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                               f.lines, f.heavy_list, f.arc_items, arc_shard_cap);
+        }
+    } else {
+        if (grid_strokes != 0u)
+            hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
+                               f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines, f.arc_items, arc_shard_cap);
+        if (mid) (void)hipEventRecord(mid[1], s);
+        hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                           f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap);
+    }
 }
 
 }  // namespace vk

@@ -231,6 +231,7 @@ class Engine:
 
     def set_frames_in_flight(self, n):
         self._check(self._lib.vello_hip_set_frames_in_flight(self._h, n), "set_frames_in_flight")
+        self.KERNELS = dict(self.KERNELS, flatten=self.FLATTEN_KERNELS[0 if n == 1 else 1])
 
     def stream(self):
         """vello_hip_get_stream: the hipStream_t (as an int) of the lane that rendered the newest frame."""
@@ -288,7 +289,10 @@ class Engine:
         self._check(self._lib.vello_hip_get_stage_ms(self._h, ms, cnt), "get_stage_ms")
         return {STAGES[i]: (ms[i], cnt[i]) for i in range(len(STAGES))}
 
-    KERNELS = {"flatten": ("k_flatten_light", "k_flatten_strokes", "k_flatten_heavy"), "coarse": ("k_coarse_prep", "k_coarse")}
+    # flatten: with one frame in flight the stroked lines' workgroups ride in the heavy list's launch (k_flatten_main) and what
+    # they set aside follows (k_flatten_tail); with several, the stroked lines' kernel runs first and the heavy one takes it all
+    FLATTEN_KERNELS = (("k_flatten_light", "k_flatten_main", "k_flatten_tail"), ("k_flatten_light", "k_flatten_strokes", "k_flatten_heavy"))
+    KERNELS = {"flatten": FLATTEN_KERNELS[0], "coarse": ("k_coarse_prep", "k_coarse")}
 
     def kernel_ms(self):
         """vello_hip_get_kernel_ms for the stages that are several kernels: {kernel: (summed ms, profiled launches)}."""
