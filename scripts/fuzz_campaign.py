@@ -8,6 +8,7 @@ test suites carry.  Prints the failing seeds only.
     FUZZ_GPU=1 ...             the product library on the GPU instead of the emulator build
     FUZZ_STROKE_KERNEL=1 ...   with flatten's stroked-line kernel forced on (VELLO_HIP_DEBUG_STROKE_KERNEL)
     FUZZ_FINE_SLICES=1 ...   every tile through the sliced path of fine (VELLO_HIP_DEBUG_FINE_SLICES)
+    FUZZ_IN_FLIGHT=n ...     vello_hip_set_frames_in_flight(n): from 2 on flatten runs its stroke workgroups as a kernel of their own
 
 Round 1 ran api 0-43500, sizes 0-6000, pools 0-4000, extreme 0-358 (some extreme seeds emit tens of millions of lines and take
 minutes each on the emulator) (see DESIGN.md section 4 for what they found).
@@ -23,6 +24,7 @@ import vello_amd._lib as L  # noqa: E402
 
 ON_GPU = os.environ.get("FUZZ_GPU") == "1"              # the product library on a real MI355X instead of the emulator build
 STROKE_KERNEL = os.environ.get("FUZZ_STROKE_KERNEL") == "1"  # VELLO_HIP_DEBUG_STROKE_KERNEL: flatten's stroked-line kernel for every scene
+IN_FLIGHT = int(os.environ.get("FUZZ_IN_FLIGHT", "1"))
 FINE_SLICES = os.environ.get("FUZZ_FINE_SLICES") == "1"  # VELLO_HIP_DEBUG_FINE_SLICES: slices of 4 fills for every tile
 if not ON_GPU:
     L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
@@ -47,6 +49,7 @@ def one(mode, seed, eng):
     elif mode == "pools":
         eng = vello_amd.Engine(capacities=TINY)
         eng.set_auto_grow(True)
+        eng.set_frames_in_flight(IN_FLIGHT)
         eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES)
         w, h = [(128, 128), (300, 200), (64, 64)][seed % 3]
         scene = fuzz_scene(seed, size=max(w, h), n_ops=[40, 300][seed % 2])
@@ -69,6 +72,7 @@ def main():
     mode, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     eng = vello_amd.Engine()
     eng.set_auto_grow(True)
+    eng.set_frames_in_flight(IN_FLIGHT)
     eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES)
     bad, t0 = [], time.time()
     for seed in range(lo, hi):
