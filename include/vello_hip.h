@@ -95,7 +95,10 @@ enum {
 
 /* Stage ids (launch order; render.rs:250-502, :560-629).  Several reference dispatches are fused:
  * PATHTAG_SCAN = pathtag_reduce(+2)/scan(1)/scan + bbox_clear, DRAW_SCAN = draw_reduce + draw_leaf,
- * CLIP = clip_reduce + clip_leaf, PATH_COUNT/PATH_TILING include their *_setup dispatch. */
+ * CLIP = clip_reduce + clip_leaf, PATH_COUNT/PATH_TILING include their *_setup dispatch.
+ * A frame (and any vello_hip_run_stages range that holds both FLATTEN and DRAW_SCAN) runs DRAW_SCAN's workgroups in
+ * FLATTEN's first launch -- the stage needs the scene and the pathtag scan only -- and then has no launch of its own: its
+ * profiled time is an empty event pair; a range that starts at DRAW_SCAN launches it as a kernel. */
 enum {
     VELLO_HIP_STAGE_PATHTAG_SCAN = 0,
     VELLO_HIP_STAGE_FLATTEN,

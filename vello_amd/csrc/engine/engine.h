@@ -154,7 +154,8 @@ struct Frame {
 void launch_pathtag_scan(const Frame &f, hipStream_t s);
 // (mid: when not null, an event is recorded behind every kernel of the stage but the last: per-KERNEL times of a stage of
 // several kernels, vello_hip_get_kernel_ms)
-void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr);
+// with_draw_scan: the draw stage's workgroups ride in k_flatten_light's launch (the caller then leaves launch_draw_scan out)
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr, bool with_draw_scan = false);
 void launch_draw_scan(const Frame &f, hipStream_t s);
 void launch_clip(const Frame &f, hipStream_t s);             // clip.hip
 void launch_clip_sequential(const Frame &f, hipStream_t s);  // draw.hip

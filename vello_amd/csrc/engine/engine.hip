@@ -486,10 +486,13 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             launch_pathtag_scan(f, st);
             break;
         case VELLO_HIP_STAGE_FLATTEN:
-            launch_flatten(f, st, prof ? ev.mid : nullptr);
+            // (a range that goes on to DRAW_SCAN: that stage's workgroups ride in flatten's first launch)
+            launch_flatten(f, st, prof ? ev.mid : nullptr, last >= VELLO_HIP_STAGE_DRAW_SCAN);
             l.flatten_ran = true;
             break;
-        case VELLO_HIP_STAGE_DRAW_SCAN: launch_draw_scan(f, st); break;
+        case VELLO_HIP_STAGE_DRAW_SCAN:
+            if (first > VELLO_HIP_STAGE_FLATTEN) launch_draw_scan(f, st);  // (else: done beside k_flatten_light)
+            break;
         case VELLO_HIP_STAGE_CLIP: launch_clip(f, st); break;
         case VELLO_HIP_STAGE_BINNING: launch_binning(f, st); break;
         case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, st); break;

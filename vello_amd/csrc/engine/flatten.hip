@@ -11,6 +11,7 @@
 // Line order inside a workgroup follows LDS atomic order, across workgroups global atomic order, as
 // in the reference (the line soup is an unordered set, flatten.wgsl:775-798).
 #include "engine.h"
+#include "draw_scan.h"
 
 namespace vk {
 
@@ -697,20 +698,13 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
                                 PathBbox *path_bboxes, uint32_t ix) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
-    bool is_path = (tag.tag_byte & PATH_TAG_PATH) != 0u;
     uint32_t path_ix = tag.monoid.path_ix;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
-    if (!is_path && seg_type == 0u) return path_ix;
+    // (a PATH marker's draw flags / transform index, flatten.wgsl:813-817: stored by k_pathtag_scan, scan.hip)
+    if (seg_type == 0u) return path_ix;
     uint32_t style_ix = tag.monoid.style_ix;
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
-    {
-        if (is_path && path_ix < cfg.layout.n_paths) {  // a PATH marker per unclosed layer follows the last path (resolve.rs:127-129)
-            path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
-            path_bboxes[path_ix].trans_ix = trans_ix;
-        }
-    }
-    if (seg_type == 0u) return path_ix;
     const uint32_t *pd = scene + cfg.layout.path_data_base;
     bool is_stroke = (style_flags & STYLE_FLAGS_STYLE) != 0u;
     Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
@@ -806,19 +800,14 @@ __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config 
                                                   PathBbox *path_bboxes, uint32_t ix, uint32_t &path_ix_out) {
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
-    bool is_path = (tag.tag_byte & PATH_TAG_PATH) != 0u;
     uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
-    if (!is_path && seg_type == 0u) return 0u;
+    // (a PATH marker's draw flags / transform index, flatten.wgsl:813-817: stored by k_pathtag_scan, scan.hip)
+    if (seg_type == 0u) return 0u;
     uint32_t style_ix = tag.monoid.style_ix;
     uint32_t trans_ix = tag.monoid.trans_ix;
     uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
-    if (is_path && path_ix < cfg.layout.n_paths) {  // a PATH marker per unclosed layer follows the last path (resolve.rs:127-129)
-        path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
-        path_bboxes[path_ix].trans_ix = trans_ix;
-    }
-    if (seg_type == 0u) return 0u;
     // joins, caps, offset curves; stroked LINES (most of a map) are listed apart: they need no Euler spirals
     if ((style_flags & STYLE_FLAGS_STYLE) != 0u) return seg_type == PATH_TAG_LINETO ? HEAVY_STROKE_LINE : HEAVY_STROKE;
     const uint32_t *pd = scene + cfg.layout.path_data_base;
@@ -835,9 +824,20 @@ __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config 
     return 0u;
 }
 
+// The first n_draw_blocks workgroups are the draw stage's (draw_scan.h; first, so that their look-back chain is under way while
+// the flatten workgroups fill the chip): they need the scene and what
+// k_pathtag_scan stored at the PATH markers, nothing of flatten's, and the stage as a launch of its own is 6-10 us of launch
+// boundary and look-back latency on the frame's critical path.
 __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                          Control *control, LineSoup *lines, uint32_t *heavy_list) {
+                                                          Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t n_draw_blocks,
+                                                          unsigned long long *draw_state, DrawMonoid *__restrict__ draw_monoids,
+                                                          uint32_t *__restrict__ info, Clip *__restrict__ clip_inp) {
+    if (blockIdx.x < n_draw_blocks) {
+        draw_scan_workgroup(cfg, scene, control, draw_state, path_bboxes, draw_monoids, info, clip_inp);
+        return;
+    }
+    const uint32_t block = blockIdx.x - n_draw_blocks;
     __shared__ FlattenShared<FLATTEN_BLOCK_TAGS> sh;  // at most one line per tag: never overflows
     __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];  // curves from the front, strokes from the back
     __shared__ uint32_t sh_lines[FLATTEN_BLOCK_TAGS];  // stroked lines
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     const uint32_t lane = tid & 63u;
     // Lane t of a wave takes tag t of a 64-tag run (4 runs per thread, 256 tags apart): consecutive tags of
     // a path are of one kind, so waves stay convergent and segment reads coalesce.
-    const uint32_t tag0 = blockIdx.x * FLATTEN_BLOCK_TAGS + tid;
+    const uint32_t tag0 = block * FLATTEN_BLOCK_TAGS + tid;
     if ((control->bump.failed & FAILED_SCENE) != 0u) return;  // the tag stream overruns the scene: nothing may be indexed with it
     if (tid == 0u) {
         sh.count = 0u;
@@ -1248,12 +1248,16 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
                                                     stroke_kernel_min_lines, arc_items, arc_shard_cap);
 }
 
-void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid) {
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_draw_scan) {
     uint32_t n_tags = f.n_tag_words * 4u;
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
-    if (grid == 0) return;
-    hipLaunchKernelGGL(k_flatten_light, dim3(grid), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                       f.lines, f.heavy_list);
+    if (grid == 0) {
+        if (with_draw_scan) launch_draw_scan(f, s);
+        return;
+    }
+    const uint32_t grid_draw = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
+    hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                       f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp);
     if (mid) (void)hipEventRecord(mid[0], s);
     // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
     // (workgroups beyond the list exit at once)

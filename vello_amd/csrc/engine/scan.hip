@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
     __shared__ uint32_t sh_part;
     __shared__ uint32_t sh_wave[4][5];
     __shared__ uint32_t sh_excl[5];
+    __shared__ uint32_t sh_markers;  // last partition: PATH markers of the whole stream
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 
     // bbox_clear folded in: grid-stride over paths
@@ -38,10 +39,7 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
         path_bboxes[i].y0 = 0x7fffffff;
         path_bboxes[i].x1 = (int32_t)0x80000000;
         path_bboxes[i].y1 = (int32_t)0x80000000;
-        // flatten writes these at the path's PATH marker; defined values keep draw_leaf's transform read inside the
-        // scene when flatten is skipped (FAILED_SCENE)
-        path_bboxes[i].draw_flags = 0u;
-        path_bboxes[i].trans_ix = 0u;
+        // (draw_flags / trans_ix: written below by the thread that holds the path's PATH marker)
     }
 
     if (tid == 0) sh_part = atomicAdd(&control->ticket_pathtag, 1u);
@@ -96,6 +94,7 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
                                 pathseg_words <= L.draw_tag_base - L.path_data_base &&
                                 (uint64_t)L.style_base + style_words <= n_scene_words;
                 if (!ok) atomicOr(&control->bump.failed, FAILED_SCENE);
+                sh_markers = excl[4] + block_agg[4];
             }
         }
     }
@@ -113,6 +112,35 @@ __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag
             o.style_ix = base[3] + ex[k][3];
             o.path_ix = base[4] + ex[k][4];
             tag_monoids[word0 + k] = o;
+            // The reference's flatten stores a path's draw flags and transform index when it meets the PATH marker
+            // (flatten.wgsl:813-817); draw_leaf is their only reader.  Stored here, where the marker's monoid is at hand,
+            // the draw stage needs nothing of flatten's and its workgroups can share k_flatten_light's launch.
+            uint32_t marks = tw[k] & (PATH_TAG_PATH * 0x1010101u);
+            while (marks != 0u) {
+                const uint32_t shift = ((uint32_t)__ffs((int)marks) - 1u) & ~7u;  // bit offset of the marker's tag byte
+                marks &= ~(0xffu << shift);
+                const TagMonoid tm = reduce_tag(tw[k] & ((1u << shift) - 1u));  // flatten.wgsl:684-701
+                const uint32_t path_ix = o.path_ix + tm.path_ix;
+                if (path_ix < cfg.layout.n_paths) {  // a PATH marker per unclosed layer follows the last path (resolve.rs:127-129)
+                    const uint32_t style_at = cfg.layout.style_base + (o.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS);
+                    // (a stream that asks for more style words than the scene holds is refused by the last partition)
+                    const uint32_t style_flags = style_at < n_scene_words ? scene[style_at] : 0u;
+                    path_bboxes[path_ix].draw_flags = (style_flags & STYLE_FLAGS_FILL) == 0u ? 0u : DRAW_INFO_FLAGS_FILL_RULE_BIT;
+                    // (likewise for the transforms: an index whose six words -- at the reference's wrapping u32 address; a marker
+                    // ahead of the first transform has index -1 -- lie outside the scene buffer is not handed to draw_leaf)
+                    const uint32_t trans_ix = o.trans_ix + tm.trans_ix - 1u;
+                    const bool trans_ok = (uint64_t)(uint32_t)(cfg.layout.transform_base + trans_ix * 6u) + 6u <= (uint64_t)n_scene_words;
+                    path_bboxes[path_ix].trans_ix = trans_ok ? trans_ix : 0u;
+                }
+            }
+        }
+    }
+    // Paths beyond the stream's last marker (a layout that counts more paths than the tags close) have no writer above:
+    // defined values keep draw_leaf's transform read inside the scene.
+    if (part == gridDim.x - 1u) {
+        for (uint32_t i = sh_markers + (uint32_t)tid; i < cfg.layout.n_paths; i += 256u) {
+            path_bboxes[i].draw_flags = 0u;
+            path_bboxes[i].trans_ix = 0u;
         }
     }
 }
