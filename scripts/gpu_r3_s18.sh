@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 3 session 16: draw stage beside k_flatten_light (A) against the commit before (H)
+# round 3 session 18: tile pool zeroed ahead beside the pathtag scan (A) against the commit before (H)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-OUT=gpurun_out/r3s16
+OUT=gpurun_out/r3s18
 mkdir -p $OUT
 one() {
   python scripts/ab_bench.py $2 --steps 80 --warmup 10 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
