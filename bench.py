@@ -471,6 +471,9 @@ def main():
             tj = json.load(fh)
         traffic = tj.get("workloads", {}).get(head_key, tj).get("kernels", {}).get(head["dominant_kernel"], {}).get("traffic_bytes")
         traffic_commit = tj.get("commit")
+        if second is not None:  # (the other workload's dominant kernel, same passes)
+            second["roofline"]["traffic"] = (tj.get("workloads", {}).get("r1mix", {}).get("kernels", {})
+                                             .get(second["dominant_kernel"], {}).get("traffic_bytes"))
     except (OSError, ValueError):
         pass
 
