@@ -20,14 +20,18 @@ def report(key):
     cap = eng.capacities()["seg_counts"]
     n_lines = eng.bump()["lines"]
     n_chunks = (n_lines + 1023) // 1024
-    raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 2 * 8192) * 2:cap * 2].reshape(-1, 4).astype(np.int64)[:n_chunks]
+    raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 4 * 8192) * 2:cap * 2].reshape(-1, 8).astype(np.int64)[:n_chunks]
     t0, t1, t2, t3 = (raw[:, i] for i in range(4))
+    setup, rows, walk, rounds = (raw[:, i] for i in range(4, 8))
     base = t0.min()
     us = lambda t: (t - base) / 100.0
     print(f"{key}: {n_chunks} chunks; launch span {us(t3).max():.1f} us")
     for name, a, b in (("pass 1", t0, t1), ("reserve (atomic + barrier)", t1, t2), ("pass 2", t2, t3), ("whole chunk", t0, t3)):
         d = (b - a) / 100.0
         print(f"  {name:28s} mean {d.mean():7.2f} us  p50 {np.median(d):7.2f}  p90 {np.percentile(d, 90):7.2f}  max {d.max():7.2f}   sum {d.sum():9.0f}")
+    # inside pass 2, as thread 0 of the workgroup sees its four rounds of 256 lines
+    print(f"  pass 2, thread 0: setup (line + Path loads, walk parameters) mean {setup.mean() / 100:6.2f} us, row loops {rows.mean() / 100:6.2f}, "
+          f"lockstep rounds {walk.mean() / 100:6.2f} us over {rounds.mean():.1f} rounds of four steps ({walk.sum() / max(rounds.sum(), 1) / 100:.2f} us per round)")
     step = 5.0
     for a in np.arange(0.0, us(t3).max() + step, step):
         b = a + step

@@ -845,6 +845,31 @@ def _stroke_kernel_cases():
     return out
 
 
+def path_count_both_forms(eng, name):
+    """path_count sets its lines and Path records aside in LDS between its two passes while the size of the scene's line soup
+    is unknown, and from then on only for soups of more than a million lines (engine.h PATH_COUNT_KEEP_MIN_LINES): the first
+    frame of a small scene runs one form, the frames after a finished one the other -- all against the oracle."""
+    from oracle.oracle import Oracle
+
+    packed, layout = workloads.mmark_scene(n=1500).resolve()
+    eng.upload_scene(packed, layout)
+    o = Oracle()
+    o.set_scene(packed, layout, 1024, 1024, WHITE, int(AaConfig.Msaa16))
+    ref = o.render()
+    ob = o.bump()
+    for k in range(3):
+        eng.render_resident(1024, 1024, WHITE, AaConfig.Msaa16)
+        eng.sync_frame(0)
+        img = eng.read_buffer("output", np.uint8, 1024 * 1024 * 4).reshape(1024, 1024, 4)
+        bump = eng.bump()
+        assert np.array_equal(img, ref), f"{name}: frame {k} differs"
+        assert bump["failed"] == 0 and all(bump[key] == ob[key] for key in ("tile", "seg_counts", "lines", "binning")), (name, k, bump, ob)
+
+
+def test_emu_path_count_both_forms(emu_engine):
+    path_count_both_forms(emu_engine, "emu_path_count_forms")
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_emu_stroked_line_kernel(emu_engine, case):
     name, packed, layout, w, h = _stroke_kernel_cases()[case]

@@ -46,6 +46,8 @@ struct SceneSlot {
     // stroked-line tags of the scene as k_flatten_light counted them in an earlier frame (-1: not known yet).  A property of
     // the scene alone; lets the host leave out stroke workgroups that would exit at once.
     int64_t stroke_lines = -1;
+    // lines in the soup of a finished frame of this scene (-1 unknown): picks path_count's form (path.hip, k_path_count<KEEP>)
+    int64_t soup_lines = -1;
     int64_t slice_demand = -1;  // slice items coarse asked for in a finished MSAA frame of this scene (max seen), -1 unknown
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
 };
@@ -435,6 +437,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
+    f.path_count_keep = sc.soup_lines < 0 || sc.soup_lines > PATH_COUNT_KEEP_MIN_LINES;
     f.flatten_side_by_side = c->n_active == 1u;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;
@@ -769,6 +772,7 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
     sc.brushes = false;
     sc.stroke_lines = -1;
+    sc.soup_lines = -1;
     sc.slice_demand = -1;
     sc.generation += 1u;
     {
@@ -957,6 +961,7 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
         HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
         if (ctl.bump.failed == 0u) {
             sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            sc.soup_lines = (int64_t)ctl.bump.lines;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }
     }
@@ -976,6 +981,7 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
         SceneSlot &sc = slot_of(c, l);
         if (l.flatten_ran && l.frame_generation == sc.generation) {  // (flatten ran to its end)
             sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            sc.soup_lines = (int64_t)ctl.bump.lines;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }
         return VELLO_HIP_OK;

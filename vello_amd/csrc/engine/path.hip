@@ -46,7 +46,10 @@ __device__ __forceinline__ Path load_path(const Path *__restrict__ paths, uint32
     return r;
 }
 
-__device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict__ paths, uint32_t n_paths) {
+// `get_path`: the line's Path record, asked for only once the line is known to cross anything (pass 1 loads it and sets it
+// aside, pass 2 takes it from there: k_path_count below)
+template <class GetPath>
+__device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPath get_path, uint32_t n_paths) {
     LineWalk w = {};
     // A tag stream with more PATH markers than the layout counts (only a hand-made stream: resolve appends its extra
     // markers behind the last segment, resolve.rs:127-129) yields lines whose path has no Path record.  WebGPU reads
@@ -77,7 +80,7 @@ __device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict
     if (robust_err != 0.0f) a -= ROBUST_EPSILON * signf(robust_err);
     float x0 = xt0 * x_sign + (is_positive_slope ? 0.0f : -1.0f);
 
-    Path path = load_path(paths, line.path_ix);
+    Path path = get_path();
     int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2], bbox3 = (int32_t)path.bbox[3];
     float xmin = minf(s0.x, s1.x);
     int32_t stride = bbox2 - bbox0;
@@ -145,10 +148,17 @@ __device__ LineWalk setup_line_walk(const LineSoup &line, const Path *__restrict
 // (imax - imin), a shuffle scan + ONE atomicAdd(bump.seg_counts) reserves the chunk's slice, pass 2
 // re-derives the walk (cheap, line and path hit L2) and writes backdrops, per-tile counts and the
 // SegmentCount records.  The reference issues one bump atomic per line (path_count.wgsl:172).
+// KEEP: pass 1 sets the lines and Path records aside in LDS for pass 2 (36 KB: four workgroups per CU instead of six); the
+// host picks the form by the size of the soup (engine.h PATH_COUNT_KEEP_MIN_LINES).
+template <bool KEEP>
 __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
                                                     const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
     __shared__ uint32_t sh_scan[4];
     __shared__ uint32_t sh_base;
+    // A thread's four lines and their Path records, set aside by pass 1 for pass 2 (each thread reads back what it wrote: no
+    // barrier).  Reloading them cost pass 2 24 of its 57 us per chunk on the road map -- a dependent pair of loads per round
+    // at the 3 us a load takes while every workgroup's tile atomics are in flight (thread 0's stamps, scripts/pc_timeline.py).
+    __shared__ uint32_t sh_keep[9][KEEP ? PATH_COUNT_CHUNK : 1u];
     const uint32_t tid = threadIdx.x;
     if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
     const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
@@ -158,13 +168,31 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         // reserved / pass 2 done in the tail of the SegmentCount pool
         const uint32_t tl0 = (uint32_t)wall_clock64();
         uint32_t tl1 = 0u, tl2 = 0u;
+        // ... and inside pass 2, as thread 0 sees them: ticks in the rounds' setup (line + Path loads, the walk's parameters), in
+        // the row loops of lines left of the rectangle, in the lockstep rounds (atomics + records); rounds of four steps walked
+        uint32_t tl_setup = 0u, tl_rows = 0u, tl_walk = 0u, tl_rounds = 0u;
 #endif
         uint32_t my_total = 0u;
 #pragma unroll 1
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
             if (line_ix < n_lines) {
-                LineWalk w = setup_line_walk(load_line(lines, line_ix), paths, cfg.layout.n_paths);
+                const LineSoup line = load_line(lines, line_ix);
+                const uint32_t at = KEEP ? j * 256u + tid : 0u;
+                if (KEEP) {
+                    // (a line whose path has no record is set aside as a point: no crossings, and no Path asked for, in pass 2 as here)
+                    const bool known = line.path_ix < cfg.layout.n_paths;
+                    sh_keep[1][at] = known ? __float_as_uint(line.p0x) : 0u; sh_keep[2][at] = known ? __float_as_uint(line.p0y) : 0u;
+                    sh_keep[3][at] = known ? __float_as_uint(line.p1x) : 0u; sh_keep[4][at] = known ? __float_as_uint(line.p1y) : 0u;
+                }
+                LineWalk w = setup_line_walk(line, [&]() {
+                    const Path p = load_path(paths, line.path_ix);
+                    if (KEEP) {
+                        sh_keep[5][at] = p.bbox[0]; sh_keep[6][at] = p.bbox[1]; sh_keep[7][at] = p.bbox[2]; sh_keep[8][at] = p.bbox[3];
+                        sh_keep[0][at] = p.tiles;
+                    }
+                    return p;
+                }, cfg.layout.n_paths);
                 my_total += w.imax - w.imin;
             }
         }
@@ -183,10 +211,36 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
 #pragma unroll 1
         for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
             uint32_t line_ix = chunk + j * 256u + tid;
+#ifdef VELLO_PC_TIMELINE
+            const uint32_t tj0 = (uint32_t)wall_clock64();
+#endif
             LineWalk w = {};
-            if (line_ix < n_lines) w = setup_line_walk(load_line(lines, line_ix), paths, cfg.layout.n_paths);
-            const uint32_t count = w.valid ? w.imax - w.imin : 0u;
+            if (!KEEP) {
+                if (line_ix < n_lines) {
+                    const LineSoup line = load_line(lines, line_ix);
+                    w = setup_line_walk(line, [&]() { return load_path(paths, line.path_ix); }, cfg.layout.n_paths);
+                }
+            } else if (line_ix < n_lines) {
+                const uint32_t at = j * 256u + tid;
+                LineSoup line;
+                line.path_ix = 0u; line.pad = 0u;  // (checked against n_paths by pass 1)
+                line.p0x = __uint_as_float(sh_keep[1][at]); line.p0y = __uint_as_float(sh_keep[2][at]);
+                line.p1x = __uint_as_float(sh_keep[3][at]); line.p1y = __uint_as_float(sh_keep[4][at]);
+                w = setup_line_walk(line, [&]() {
+                    Path p;
+                    p.bbox[0] = sh_keep[5][at]; p.bbox[1] = sh_keep[6][at]; p.bbox[2] = sh_keep[7][at]; p.bbox[3] = sh_keep[8][at];
+                    p.tiles = sh_keep[0][at];
+                    p.pad[0] = p.pad[1] = p.pad[2] = 0u;
+                    return p;
+                }, 1u);
+            }
+            uint32_t count = w.valid ? w.imax - w.imin : 0u;
             const int32_t delta = w.is_down ? -1 : 1;
+#ifdef VELLO_PC_TIMELINE
+            count = opaque(count);  // (the stamp waits for the loads the count depends on)
+            const uint32_t tj1 = (uint32_t)wall_clock64();
+            tl_setup += tj1 - tj0;
+#endif
             // every tile index below is bounded by the buffer explicitly (WebGPU does that for the reference): with
             // crossing indices past f32's 24 bits the walk can leave the path's tile rectangle
             if (w.valid) {
@@ -196,6 +250,10 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                 }
             }
             float last_z = floorf(w.a * ((float)w.imin - 1.0f) + w.b);
+#ifdef VELLO_PC_TIMELINE
+            const uint32_t tj2 = (uint32_t)wall_clock64();
+            tl_rows += tj2 - tj1;
+#endif
             // The wave walks crossings in lockstep.  Consecutive lanes hold consecutive lines of the soup, which
             // (flatten writes in tag order) are consecutive short segments of one path and mostly fall into the
             // same tile: runs of adjacent lanes hitting the same tile reserve their slots with ONE returning
@@ -277,15 +335,23 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                 }
             }
             seg_base += count;
+#ifdef VELLO_PC_TIMELINE
+            seg_base = opaque(seg_base);
+            __builtin_amdgcn_s_waitcnt(0);  // (the round's atomics have answered, its records are on their way)
+            tl_walk += (uint32_t)wall_clock64() - tj2;
+            tl_rounds += (max_count + 3u) / 4u;
+#endif
         }
         __syncthreads();  // sh_base / sh_scan reuse in the next chunk
 #ifdef VELLO_PC_TIMELINE
         if (tid == 0u) {
             const uint32_t slot = chunk / PATH_COUNT_CHUNK;
-            if (cfg.seg_counts_size > 2u * 8192u && slot < 8192u) {
-                SegmentCount *dst = seg_counts + (cfg.seg_counts_size - 2u * 8192u) + 2u * slot;
+            if (cfg.seg_counts_size > 4u * 8192u && slot < 8192u) {
+                SegmentCount *dst = seg_counts + (cfg.seg_counts_size - 4u * 8192u) + 4u * slot;
                 dst[0].line_ix = tl0; dst[0].counts = tl1;
                 dst[1].line_ix = tl2; dst[1].counts = (uint32_t)wall_clock64();
+                dst[2].line_ix = tl_setup; dst[2].counts = tl_rows;
+                dst[3].line_ix = tl_walk; dst[3].counts = tl_rounds;
             }
         }
 #endif
@@ -483,7 +549,8 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 void launch_path_count(const Frame &f, hipStream_t s) {
     // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
     uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u);
-    hipLaunchKernelGGL(k_path_count, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    if (f.path_count_keep) hipLaunchKernelGGL(k_path_count<true>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    else hipLaunchKernelGGL(k_path_count<false>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
 }
 
 void launch_backdrop(const Frame &f, hipStream_t s) {
