@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Basic-block instruction census of one kernel in a hipcc -S dump.
+
+    hipcc --offload-arch=gfx950 ... -S --cuda-device-only -o fine.s engine/fine.hip
+    scripts/isa_blocks.py fine.s k_fineILi2ELb0E [--dump LABEL]
+
+Prints every basic block (label .. next label) with its VALU / SALU / LDS / VMEM / other counts and the labels it
+branches to, marking backward branches (loops).  What k_fine's "instructions per fill" are made of is read off the
+blocks of the fill loop; PMC counts say how many, this says which."""
+import re
+import sys
+
+
+def classify(op):
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        return "vmem"
+    if op.startswith("s_"):
+        if op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_sleep")):
+            return "wait"
+        if op.startswith(("s_load", "s_buffer_load")):
+            return "smem"
+        return "salu"
+    return "other"
+
+
+def main():
+    path, key = sys.argv[1], sys.argv[2]
+    dump = sys.argv[sys.argv.index("--dump") + 1] if "--dump" in sys.argv else None
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l and l.rstrip().endswith(":") is False and ":" in l)
+    end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+    # the function may have several s_endpgm; take the .Lfunc_end
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    blocks = []
+    cur = {"label": "entry", "line": start, "counts": {}, "targets": [], "text": []}
+    order = {}
+    for i in range(start + 1, end):
+        l = lines[i]
+        m = re.match(r"^(\.LBB[0-9_]+):", l)
+        if m:
+            blocks.append(cur)
+            cur = {"label": m.group(1), "line": i, "counts": {}, "targets": [], "text": []}
+            continue
+        s = l.strip()
+        if not s or s.startswith((";", ".", "//")):
+            continue
+        op = s.split()[0]
+        c = classify(op)
+        cur["counts"][c] = cur["counts"].get(c, 0) + 1
+        cur["text"].append(s)
+        if op.startswith(("s_cbranch", "s_branch")):
+            cur["targets"].append(s.split()[1])
+    blocks.append(cur)
+    for n, b in enumerate(blocks):
+        order[b["label"]] = n
+    tot = {}
+    for n, b in enumerate(blocks):
+        if dump is not None:
+            if b["label"] == dump:
+                print("\n".join(b["text"]))
+            continue
+        c = b["counts"]
+        for k, v in c.items():
+            tot[k] = tot.get(k, 0) + v
+        tg = ["%s%s" % (t, "^" if order.get(t, 1 << 30) <= n else "") for t in b["targets"]]
+        print("%-12s valu %4d salu %4d lds %3d vmem %3d smem %2d wait %3d  -> %s" % (
+            b["label"], c.get("valu", 0), c.get("salu", 0), c.get("lds", 0), c.get("vmem", 0), c.get("smem", 0), c.get("wait", 0), " ".join(tg)))
+    if dump is None:
+        print("total", tot)
+
+
+if __name__ == "__main__":
+    main()

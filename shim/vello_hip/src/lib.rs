@@ -10,14 +10,14 @@ pub mod ffi;
 
 use core::ffi::{c_int, c_void, CStr};
 use ffi::*;
-use vello::{AaConfig, RenderParams, RendererOptions, Scene};
+use vello::{AaConfig, AaSupport, RenderParams, Scene};
 use vello_encoding::{Layout, Resolver};
 
 #[derive(Debug)]
 pub enum Error {
     /// vello::Error::NoCompatibleDevice (vello/src/lib.rs:262): no gfx950 device; there is no CPU fallback.
     NoCompatibleDevice,
-    /// An AA mode that was not enabled in `RendererOptions::antialiasing_support` (render.rs:566-598 panics upstream),
+    /// An AA mode that was not enabled in the `AaSupport` given to `new` (render.rs:566-598 panics upstream),
     /// or a packed scene whose streams contradict each other.
     Invalid(String),
     /// A HIP runtime error.
@@ -52,9 +52,11 @@ fn to_hip_layout(l: &Layout) -> vello_hip_layout {
 }
 
 impl HipRenderer {
-    /// `Renderer::new` (vello/src/lib.rs:432-459).
-    pub fn new(device: i32, options: &RendererOptions) -> Result<Self, Error> {
-        let aa = options.antialiasing_support;
+    /// `Renderer::new` (vello/src/lib.rs:432-459).  Takes the one field of `RendererOptions` that means something here --
+    /// `antialiasing_support` -- as an `AaSupport`: `RendererOptions` itself is `#[cfg(feature = "wgpu")]`
+    /// (vello/src/lib.rs:371-373) and this crate depends on vello WITHOUT that feature (no wgpu in the build at all);
+    /// `use_cpu`, `num_init_threads` and `pipeline_cache` configure wgpu's shader compilation.
+    pub fn new(device: i32, aa: AaSupport) -> Result<Self, Error> {
         let mask = (aa.area as u32) * VELLO_HIP_AA_MASK_AREA
             | (aa.msaa8 as u32) * VELLO_HIP_AA_MASK_MSAA8
             | (aa.msaa16 as u32) * VELLO_HIP_AA_MASK_MSAA16;
@@ -68,8 +70,11 @@ impl HipRenderer {
         Ok(Self { ctx, resolver: Resolver::new(), packed: Vec::new(), atlas_size: (0, 0) })
     }
 
-    fn error(&self, rc: c_int, bump: vello_hip_bump) -> Error {
-        let msg = unsafe { CStr::from_ptr(vello_hip_last_error(self.ctx)) }.to_string_lossy().into_owned();
+    /// What a failed call left in the context.  A free function over the raw context pointer (not `&self`): it is called
+    /// while `render_to_buffer` still holds the `Ramps` / `Images` that `Resolver::resolve` lends out of `self.resolver`
+    /// (`resolve<'a>(&'a mut self, ..) -> (Layout, Ramps<'a>, Images<'a>)`, vello_encoding/src/resolve.rs:183-187).
+    fn error(ctx: *mut vello_hip_ctx, rc: c_int, bump: vello_hip_bump) -> Error {
+        let msg = unsafe { CStr::from_ptr(vello_hip_last_error(ctx)) }.to_string_lossy().into_owned();
         match rc {
             VELLO_HIP_E_NO_DEVICE => Error::NoCompatibleDevice,
             VELLO_HIP_E_INVALID => Error::Invalid(msg),
@@ -82,21 +87,27 @@ impl HipRenderer {
     /// device memory of the context's GPU): un-premultiplied, rows of `stride` bytes, origin top-left.
     pub fn render_to_buffer(&mut self, scene: &Scene, target: *mut c_void, stride: usize, on_device: bool,
                             params: &RenderParams) -> Result<(), Error> {
-        // identical to Render::render_encoding_coarse up to the uploads (vello/src/render.rs:135-232)
+        // identical to Render::render_encoding_coarse up to the uploads (vello/src/render.rs:135-232).
+        // Borrows: `resolve` borrows `self.resolver` mutably for as long as `ramps` / `images` live, and `self.packed`
+        // for the call only.  Everything below therefore touches `self` through DISJOINT fields (`self.ctx`, a `Copy`
+        // raw pointer read once up front; `self.atlas_size`; `self.packed`) and never through a `&self` / `&mut self`
+        // method, which would borrow all of `self` while the resolver is lent out (E0502).
+        let ctx = self.ctx;
         let (layout, ramps, images) = self.resolver.resolve(scene.encoding(), &mut self.packed);
         // vello/src/render.rs:160-203: the persistent image atlas follows the Resolver's image cache
         if (images.width, images.height) != self.atlas_size {
-            let rc = unsafe { vello_hip_resize_image_atlas(self.ctx, images.width, images.height) };
+            let rc = unsafe { vello_hip_resize_image_atlas(ctx, images.width, images.height) };
             if rc != VELLO_HIP_OK {
-                return Err(self.error(rc, Default::default()));
+                return Err(Self::error(ctx, rc, vello_hip_bump::default()));
             }
             self.atlas_size = (images.width, images.height);
         }
-        for (image, x, y) in images.images {
-            let bytes = image.data.data();
-            let rc = unsafe { vello_hip_write_image(self.ctx, *x, *y, image.width, image.height, bytes.as_ptr(), 0) };
+        // `images.images: &[(ImageData, u32, u32)]` (vello_encoding/src/image_cache.rs:24): iterate by reference
+        for (image, x, y) in images.images.iter() {
+            let bytes: &[u8] = image.data.data();
+            let rc = unsafe { vello_hip_write_image(ctx, *x, *y, image.width, image.height, bytes.as_ptr(), 0) };
             if rc != VELLO_HIP_OK {
-                return Err(self.error(rc, Default::default()));
+                return Err(Self::error(ctx, rc, vello_hip_bump::default()));
             }
         }
         let p = vello_hip_render_params {
@@ -111,11 +122,13 @@ impl HipRenderer {
         };
         let hl = to_hip_layout(&layout);
         let mut bump = vello_hip_bump::default();
+        // `Ramps { data: &[u32], width, height }` is `Copy` (ramp_cache.rs:16-21); an empty slice's pointer is dangling but
+        // non-null and is never read (n_ramps = 0)
         let rc = unsafe {
-            vello_hip_render(self.ctx, self.packed.as_ptr(), self.packed.len(), &hl, &p, ramps.data.as_ptr(), ramps.height,
+            vello_hip_render(ctx, self.packed.as_ptr(), self.packed.len(), &hl, &p, ramps.data.as_ptr(), ramps.height,
                              target, stride, on_device as c_int, &mut bump)
         };
-        if rc == VELLO_HIP_OK { Ok(()) } else { Err(self.error(rc, bump)) }
+        if rc == VELLO_HIP_OK { Ok(()) } else { Err(Self::error(ctx, rc, bump)) }
     }
 
     /// The vello_tests entry point (`render_then_debug_sync`, vello_tests/src/lib.rs:76): a frame into a fresh Vec.

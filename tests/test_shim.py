@@ -1,8 +1,15 @@
 """The Rust shim (shim/vello_hip) is source only -- no Rust toolchain in the image -- so the one thing a compiler could
 not check either is checked here: every item of its `extern "C"` block against include/vello_hip.h (function names,
-arity, argument and return types, struct fields, constants)."""
+arity, argument and return types, struct fields, constants).  Round 4 adds what can be checked of the rest without a
+compiler: the vello_tests patch applies to the reference tree (`git apply --check`), the crate names no item of `vello`
+that only exists under its "wgpu" feature (it is built with default-features = false), and `render_to_buffer` calls no
+`&self` method while `Resolver::resolve`'s loans are alive."""
 import os
 import re
+import shutil
+import subprocess
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "vello_hip.h")
@@ -129,3 +136,83 @@ def test_library_exports_every_function_of_the_shim(built):
     rf, _, _ = parse_rust()
     for name in rf:
         assert hasattr(lib, name), name
+
+
+REFERENCE = "/root/reference"
+LIB_RS = os.path.join(ROOT, "shim", "vello_hip", "src", "lib.rs")
+PATCH = os.path.join(ROOT, "shim", "vello_tests_patch", "render_then_debug.patch")
+
+
+def test_vello_tests_patch_is_a_unified_diff():
+    """Every hunk header carries ranges and the counts add up (what `git apply` checks first), reference or not."""
+    lines = open(PATCH).read().split("\n")
+    files = [l for l in lines if l.startswith("--- a/")]
+    assert files == ["--- a/vello_tests/Cargo.toml", "--- a/vello_tests/src/lib.rs"], files
+    i, hunks = 0, 0
+    while i < len(lines):
+        m = re.match(r"^@@ -(\d+),(\d+) \+(\d+),(\d+) @@", lines[i])
+        if lines[i].startswith("@@"):
+            assert m, f"hunk header without ranges: {lines[i]!r}"
+            old, new = int(m.group(2)), int(m.group(4))
+            i += 1
+            while old or new:
+                c = lines[i][:1]
+                assert c in (" ", "-", "+"), f"line {i + 1}: {lines[i]!r}"
+                old -= c in (" ", "-")
+                new -= c in (" ", "+")
+                i += 1
+            assert old == 0 and new == 0
+            hunks += 1
+        else:
+            i += 1
+    assert hunks >= 4
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "vello_tests")) or shutil.which("git") is None,
+                    reason="the reference tree is not on this machine")
+def test_vello_tests_patch_applies_to_the_reference():
+    r = subprocess.run(["git", "-C", REFERENCE, "apply", "--check", "--verbose", PATCH], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def _rust_code(path):
+    """The file without // comments and string literals' contents."""
+    src = re.sub(r"//[^\n]*", "", open(path).read())
+    return re.sub(r'"(?:[^"\\]|\\.)*"', '""', src)
+
+
+def test_shim_uses_only_ungated_vello_items():
+    code = _rust_code(LIB_RS)
+    cargo = open(os.path.join(ROOT, "shim", "vello_hip", "Cargo.toml")).read()
+    assert re.search(r'^vello = \{[^}]*default-features = false', cargo, flags=re.M)
+    # items behind #[cfg(feature = "wgpu")] in vello/src/lib.rs (:112-115, :141-143, :371-430): not nameable in this build
+    for gated in ("RendererOptions", "Renderer::", "vello::Renderer", "vello::util", "vello::wgpu", "wgpu::"):
+        assert gated not in code, gated
+    uses = re.search(r"use vello::\{([^}]*)\};", code).group(1)
+    assert {u.strip() for u in uses.split(",")} == {"AaConfig", "AaSupport", "RenderParams", "Scene"}
+    if os.path.isdir(os.path.join(REFERENCE, "vello", "src")):
+        lib = open(os.path.join(REFERENCE, "vello", "src", "lib.rs")).read()
+        for item in ("pub enum AaConfig", "pub struct AaSupport", "pub struct RenderParams", "pub use scene::{DrawGlyphs, Scene};"):
+            at = lib.index(item)
+            before = lib[:at].rstrip().split("\n")
+            # the attribute lines directly above the item (doc comments skipped) must not gate it
+            k = len(before) - 1
+            while k >= 0 and before[k].lstrip().startswith(("///", "#[derive", "#[doc")):
+                k -= 1
+            assert "cfg(feature" not in before[k], (item, before[k])
+
+
+def test_no_self_method_call_while_the_resolver_is_lent_out():
+    """`Resolver::resolve<'a>(&'a mut self, ..) -> (Layout, Ramps<'a>, Images<'a>)` (vello_encoding/src/resolve.rs:183-187)
+    keeps `self.resolver` mutably borrowed while `ramps` / `images` are used; a `self.method(..)` call in that region borrows
+    all of `self` and is E0502.  Field accesses (`self.packed`, `self.atlas_size`) are disjoint borrows and fine."""
+    code = _rust_code(LIB_RS)
+    body = code[code.index("pub fn render_to_buffer"):code.index("pub fn render_to_vec")]
+    after = body[body.index("self.resolver.resolve("):]
+    last_use = max(after.rfind("ramps."), after.rfind("images."))
+    region = after[len("self.resolver.resolve("):last_use]
+    calls = re.findall(r"\bself\.([a-z_]+)\s*\(", region)
+    assert calls == [], calls
+    fields = set(re.findall(r"\bself\.([a-z_]+)\b", region))
+    assert fields <= {"packed", "atlas_size"}, fields
+    assert "fn error(ctx: *mut vello_hip_ctx" in code  # the error path takes the raw pointer, not &self
