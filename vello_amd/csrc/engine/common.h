@@ -127,16 +127,34 @@ __device__ __forceinline__ float pow_cr(float x, float y) {
 }
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
+// WGSL's u32(f32) / i32(f32): truncation, saturating, NaN -> 0.  That is exactly what v_cvt_u32_f32 / v_cvt_i32_f32 do in
+// hardware (out-of-range values and infinities saturate, negative values give 0 unsigned, NaN gives 0), but a C cast of an
+// out-of-range value is undefined, so the portable form has to guard it -- which on the GPU was three compares, three
+// nested exec-mask branches and two constant moves around every conversion (k_fine's crossing-record loop: five
+// conversions, a third of its instructions).  The instruction goes in as inline asm (not volatile: it is a pure function of
+// its operand); scripts/calib/cvt_sat.hip checks it against the guarded form on the device for the values that matter.
 __device__ __forceinline__ uint32_t f2u(float f) {
+#ifdef VELLO_SIMT_EMU
     if (!(f > 0.0f)) return 0u;
     if (f >= 4294967296.0f) return 0xffffffffu;
     return (uint32_t)f;
+#else
+    uint32_t r;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#endif
 }
 __device__ __forceinline__ int32_t f2i(float f) {
+#ifdef VELLO_SIMT_EMU
     if (f != f) return 0;
     if (f <= -2147483648.0f) return (int32_t)0x80000000;
     if (f >= 2147483648.0f) return 0x7fffffff;
     return (int32_t)f;
+#else
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#endif
 }
 __device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
 __device__ __forceinline__ float minf(float a, float b) { return a < b ? a : b; }
@@ -207,6 +225,25 @@ __device__ __forceinline__ uint32_t row_shr(uint32_t v) {
     return (uint32_t)__shfl_up((int)v, K);
 #else
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, false);
+#endif
+}
+// the same with 0 for the lanes whose source lies outside their row (DPP bound_ctrl): an operand modifier of the add that
+// uses it, no register to preset
+template <int K>
+__device__ __forceinline__ uint32_t row_shr0(uint32_t v) {
+#ifdef VELLO_SIMT_EMU
+    const uint32_t o = (uint32_t)__shfl_up((int)v, K);
+    return (threadIdx.x & 15u) >= (uint32_t)K ? o : 0u;
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + K, 0xf, 0xf, true);
+#endif
+}
+// the top byte of v in all four bytes: v_perm_b32 (a shift and a 32-bit multiply otherwise)
+__device__ __forceinline__ uint32_t bcast_byte3(uint32_t v) {
+#ifdef VELLO_SIMT_EMU
+    return (v >> 24) * 0x1010101u;
+#else
+    return __builtin_amdgcn_perm(v, v, 0x03030303u);
 #endif
 }
 // v of a lane known at compile time (v_readlane on the GPU)

@@ -136,11 +136,14 @@ struct SegSetupLds {
     int32_t x0i[64], y0i[64];
     uint32_t flags[64];
 };
-// Per-pixel exchange of ms_fill_from_batch (live only while a staged fill is resolved): the byte a sample counter
-// holds where the winding number is zero, and the coverage, indexed by pixel.
+// Per-pixel exchange of ms_fill_from_batch (live while the fills of a staged batch are resolved; written after
+// ms_build_batch is done with SegSetupLds, whose storage it shares): `pw` = a lane's four packed x-winding prefixes,
+// `area` = the coverage, indexed by pixel, and `zero_at` = per staged fill and pixel row the byte an x-winding prefix
+// holds where the winding number is zero, replicated into the four bytes of a word (ms_build_batch, end).
 struct alignas(16) PixelLds {
-    uint32_t expected_zero[256];
+    uint32_t pw[64];
     float area[256];
+    uint32_t zero_at[12][16];
 };
 struct FineShared {
     union {
@@ -224,20 +227,22 @@ __device__ void fill_path_area(FineShared &sh, const Segment *__restrict__ segme
 // (ms_apply) and resolves.  Every integer operation on the counters is the reference's, so coverage is bit-identical.
 constexpr uint32_t MS_BATCH_FILLS = 12u;    // fills per batch (their segments must fit one 64-lane load)
 static_assert(MS_BATCH_FILLS <= 16u, "the slot search of ms_build_batch covers 16 slots");
+static_assert(MS_BATCH_FILLS == sizeof(PixelLds::zero_at) / sizeof(PixelLds::zero_at[0]), "a row of PixelLds::zero_at per staged fill");
+static_assert(sizeof(PixelLds) <= sizeof(SegSetupLds), "PixelLds lives in SegSetupLds's storage");
 constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
 constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
 
-struct FineBatch {
+struct alignas(16) FineBatch {
     uint32_t item[MS_ITEM_CAP];
     uint32_t seg_slot[64];                     // scratch of the slot-source scatter (lane numbers of the kept fills by rank)
     uint32_t winding_y[MS_BATCH_FILLS][4];     // per fill, as fine.wgsl's sh_winding_y
+    float color[MS_BATCH_FILLS][4];            // per fill of the regular prefix: the CMD_COLOR behind it, unpacked once
 };
 // What a staged fill's replay needs besides its records lives in two registers of lane `slot` (read with v_readlane, no
 // LDS round trip at the head of every fill): its record range [begin, end) and fill rule, packed, and its backdrop.
 struct SlotRegs {
     uint32_t pack;      // begin | end << 10 | even_odd << 20
     uint32_t backdrop;
-    uint32_t color;     // the CMD_COLOR word behind the slot's FILL (valid for the slots of the regular prefix)
 };
 constexpr uint32_t SLOT_END_SHIFT = 10u, SLOT_EO_SHIFT = 20u, SLOT_IX_MASK = 0x3ffu;
 static_assert(MS_ITEM_CAP <= SLOT_IX_MASK, "record indices are packed in 10 bits");
@@ -675,7 +680,12 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         if (lane == 0u) my_begin = 0u;
         slots.pack = (my_begin & SLOT_IX_MASK) | ((my_end & SLOT_IX_MASK) << SLOT_END_SHIFT) | ((my_rule_n & 1u) << SLOT_EO_SHIFT);
         slots.backdrop = my_backdrop;
-        slots.color = my_color;
+        // (unpacked by the slot's lane once, read back with one broadcast load per fill: every lane converting the four
+        // channels for itself was 10 VALU per fill)
+        if (lane < MS_BATCH_FILLS) {
+            const vec4 c = unpack4x8unorm(my_color);
+            *reinterpret_cast<float4 *>(&bt.color[lane][0]) = make_float4(c.x, c.y, c.z, c.w);
+        }
     }
     n_fast = minu(n_fit, pairs);
     if (n_fast != 0u) after_fast = win_base + wave_read(pos, 2u * n_fast - 1u) + 2u;
@@ -714,6 +724,31 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         }
         wave_lds_sync();
         if (i < total) bt.item[i] = rec;
+    }
+    wave_lds_sync();
+    // The row part of every staged fill's winding prefix, once per batch instead of once per fill.  fine.wgsl:365-398 gives
+    // pixel i of row r the byte ((x prefix byte) + wind_y(r)) & 0xff and compares it -- minus the backdrop -- with 0x80 where
+    // no crossing touched the pixel.  wind_y(r) depends on the fill alone: the scanned row counters (same 32-bit operations
+    // as ms_resolve, so a counter that leaves its byte carries on exactly as there), summed over the words before r's.  What
+    // a fill's replay needs of it is the byte an x prefix must hold for the winding number to be zero at row r:
+    // (0x80 + backdrop - wind_y(r)) & 0xff, kept replicated in a word so that one xor tests four pixels.  Lane 4 s + k
+    // takes word k of slot s (rows 4k .. 4k+3).  (The setup records are dead by now: their storage is PixelLds's.)
+    {
+        const uint32_t s_ix = lane >> 2, k = lane & 3u;
+        uint32_t y = bt.winding_y[minu(s_ix, MS_BATCH_FILLS - 1u)][k];
+        y += (y - 0x808080u) << 8;
+        y += (y - 0x8080u) << 16;
+        const uint32_t tot = (y >> 24) - 0x80u;  // wind_y of the word's last row: what the words after it add
+        const uint32_t t1 = wave_shfl(tot, (lane - 1u) & 63u), t2 = wave_shfl(tot, (lane - 2u) & 63u), t3 = wave_shfl(tot, (lane - 3u) & 63u);
+        const uint32_t base = (k >= 1u ? t1 : 0u) + (k >= 2u ? t2 : 0u) + (k >= 3u ? t3 : 0u);
+        const uint32_t bd = wave_shfl(my_backdrop, s_ix);
+        uint32_t z[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+            const uint32_t wind_y = (y >> (8u * j)) - 0x80u + base;
+            z[j] = ((0x80u + bd - wind_y) & 0xffu) * 0x1010101u;
+        }
+        if (s_ix < n_fit) *reinterpret_cast<uint4 *>(&sh.px.zero_at[s_ix][4u * k]) = make_uint4(z[0], z[1], z[2], z[3]);
     }
     wave_lds_sync();
     pf.mark(FP_BATCH_ITEMS);
@@ -809,40 +844,49 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
     }
     wave_lds_sync();
     pf.mark(FP_FILL_APPLY);
-    // winding prefix sums exactly as ms_resolve; the row counters go back to their cleared value as they are read
+    // x winding prefix sums exactly as ms_resolve (the counters go back to their cleared value as they are read); the row
+    // part comes ready-made from ms_build_batch: `zero_at` holds, for this fill and the lane's row, the byte an x prefix
+    // holds where the winding number is zero -- expected_zero == 0x80 in fine.wgsl's terms, the value an untouched pixel's
+    // sample counters all hold -- in all four bytes of a word: one xor tests the lane's four pixels
     const uint32_t lx = lane & 3u, ly = lane >> 2;
     uint32_t packed_w = sh.winding[lane];
     sh.winding[lane] = 0x80808080u;
     packed_w += (packed_w - 0x808080u) << 8;
     packed_w += (packed_w - 0x8080u) << 16;
-    uint32_t packed_y = bt.winding_y[slot][ly >> 2];
-    packed_y += (packed_y - 0x808080u) << 8;
-    packed_y += (packed_y - 0x8080u) << 16;
-    uint32_t wind_y = (packed_y >> ((ly & 3u) << 3)) - 0x80u;
-    const uint32_t prefix_x = ((packed_w >> 24) - 0x80u) * 0x1010101u;
-    const uint32_t px1 = row_shr<1>(prefix_x), px2 = row_shr<2>(prefix_x), px3 = row_shr<3>(prefix_x);
-    if (lx >= 1u) packed_w += px1;
-    if (lx >= 2u) packed_w += px2;
-    if (lx >= 3u) packed_w += px3;
-    const uint32_t wy3 = lane_value<12>(wind_y), wy7 = lane_value<28>(wind_y), wy11 = lane_value<44>(wind_y);
-    if (ly >= 4u) wind_y += wy3;
-    if (ly >= 8u) wind_y += wy7;
-    if (ly >= 12u) wind_y += wy11;
-    uint32_t ez[4];
+    // ((packed_w >> 24) - 0x80) * 0x1010101, mod 2^32: the lane's total, for the lanes to its right in the row of pixels.
+    // Masked at the SOURCE (a lane hands its total only as far as its own row of pixels reaches: 3, 2, 1 lanes to the
+    // right from columns 0, 1, 2), so that the three shifted adds need no select behind them
+    const uint32_t prefix_x = bcast_byte3(packed_w) - 0x80808080u;
+    packed_w += row_shr0<1>(lx <= 2u ? prefix_x : 0u);
+    packed_w += row_shr0<2>(lx <= 1u ? prefix_x : 0u);
+    packed_w += row_shr0<3>(lx == 0u ? prefix_x : 0u);
+    // expected_zero = ((x prefix + wind_y) & 0xff) - backdrop is 0x80 iff the x prefix byte equals zero_at -- provided
+    // 0x80 + backdrop is a byte at all (a scalar test: beyond it no pixel of the fill has winding number zero)
+    const bool zero_possible = (uint32_t)backdrop + 128u < 256u;
+    const uint32_t differs = packed_w ^ sh.px.zero_at[slot][ly];
+    // untouched counters are 0x80: every sample differs from expected_zero, or none does -- coverage 1 or 0.  Four pixels at
+    // once: bit 7 of a byte of `nz` says the byte of `differs` is not zero; shifted down the bytes are 1 or 0 and the
+    // byte-to-float conversion makes 1.0f or 0.0f of them
+    uint32_t nz = (((differs & 0x7f7f7f7fu) + 0x7f7f7f7fu) | differs) & 0x80808080u;
+    if (!zero_possible) nz = 0x80808080u;
+    const uint32_t ones = nz >> 7;
 #pragma unroll
-    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) {
-        ez[i] = (((packed_w >> (i * 8u)) + wind_y) & 0xffu) - (uint32_t)backdrop;
-        // untouched counters are 0x80: every sample differs from expected_zero, or none does
-        area[i] = ez[i] == 0x80u ? 0.0f : 1.0f;
-    }
+    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) area[i] = (float)((ones >> (i * 8u)) & 0xffu);
     if (begin == end) {
         pf.mark(FP_FILL_PREFIX);
         return;
     }
-    *reinterpret_cast<uint4 *>(&sh.px.expected_zero[lane * 4u]) = make_uint4(ez[0], ez[1], ez[2], ez[3]);
+    sh.px.pw[lane] = packed_w;
     *reinterpret_cast<float4 *>(&sh.px.area[lane * 4u]) = make_float4(area[0], area[1], area[2], area[3]);
     wave_lds_sync();
     pf.mark(FP_FILL_PREFIX);
+    // expected_zero of pixel p for the lane that holds one of its crossing records: the x prefix byte from the owner's word,
+    // the row part back out of zero_at (wind_y = 0x80 + backdrop - zero_at mod 256)
+    auto expected_zero_of = [&](uint32_t pix_ix) -> uint32_t {
+        const uint32_t xb = sh.px.pw[pix_ix >> 2] >> ((pix_ix & 3u) << 3);
+        const uint32_t b = (xb - sh.px.zero_at[slot][pix_ix >> 4] + 0x80u + (uint32_t)backdrop) & 0xffu;
+        return b - (uint32_t)backdrop;
+    };
     if (one_round) {
         // one record per lane: read the pixel's counters, put them back to the cleared value at once and evaluate.  A wave's
         // LDS instructions are performed in order, so every lane's reads precede any lane's writes (two records on one pixel
@@ -852,7 +896,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
         const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
         uint32_t e = 256u, s0 = 0u, s1 = 0u, s2 = 0u, s3 = 0u;
         if (valid) {
-            e = sh.px.expected_zero[pix_ix];
+            e = expected_zero_of(pix_ix);
             s0 = sh_samples[so]; s1 = sh_samples[so + 64u];
             if (AA == 2) { s2 = sh_samples[so + 128u]; s3 = sh_samples[so + 192u]; }
         }
@@ -870,7 +914,7 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
             const uint32_t rec = i < end ? bt.item[i] : 0u;
             if (rec & REC_PIX_VALID) {
                 const uint32_t pix_ix = rec & 0xffu;
-                const uint32_t e = sh.px.expected_zero[pix_ix];
+                const uint32_t e = expected_zero_of(pix_ix);
                 const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
                 const uint32_t s0 = sh_samples[so], s1 = sh_samples[so + 64u];
                 const uint32_t s2 = AA == 2 ? sh_samples[so + 128u] : 0u, s3 = AA == 2 ? sh_samples[so + 192u] : 0u;
@@ -1650,7 +1694,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     bool samples_clean = false;             // MSAA: the sample counters hold their cleared (non-zero rule) value
     uint32_t pf_win = 0u, pf_base = 0xffffffffu;  // MSAA: the command window requested ahead for the next batch
     uint32_t fast_left = 0u, fast_after = 0u;     // MSAA: fills left in the batch's regular prefix / where the list goes on behind it
-    SlotRegs slots{0u, 0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
+    SlotRegs slots{0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
     uint32_t rec_pre = 0u, rec_pre_begin = ~0u;   // MSAA: the records requested ahead for the next fill
     for (;;) {
         ensure(cmd_ix, 4u);
@@ -1723,10 +1767,13 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                         ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, samples_clean, rec_pre, rec_pre_begin, prof);
                         batch_pos += 1u;
                         if (!fast) break;
-                        if (mode == MODE_COV) {
-                            store_cov();
-                        } else {
-                            const vec4 fg = unpack4x8unorm(wave_read(slots.color, batch_pos - 1u));
+                        if (mode == MODE_COV) store_cov();
+                        // (a slice's wave blends as well: its pixels are never stored, and an unconditional update of rgba
+                        // is done in place -- behind a branch the compiler blends into fresh registers and copies all
+                        // sixteen back at the loop's join, eight v_mov_b64 per fill)
+                        {
+                            const float4 c = *reinterpret_cast<const float4 *>(&bt.color[batch_pos - 1u][0]);
+                            const vec4 fg{c.x, c.y, c.z, c.w};
 #pragma unroll
                             for (int i = 0; i < 4; i++) src_over(rgba[i], fg, area[i]);
                         }
