@@ -132,9 +132,10 @@ struct CmdFill {
 // Per-segment line setup of a batch (ms_setup), live only while ms_build_batch runs: shares its storage with the
 // staged Segment records of the one-fill-at-a-time paths (never both at once).
 struct SegSetupLds {
-    float a[64], b[64], xy0y[64], xy1y[64], mask_row[64];
+    float a[64], b[64], mask_row[64];
     int32_t x0i[64], y0i[64];
-    uint32_t flags[64];
+    uint32_t flags[64], edge_masks[64];
+    uint32_t unused[64];  // (PixelLds, which shares this storage later, is this long)
 };
 // Per-pixel exchange of ms_fill_from_batch (live while the fills of a staged batch are resolved; written after
 // ms_build_batch is done with SegSetupLds, whose storage it shares): `pw` = a lane's four packed x-winding prefixes,
@@ -251,9 +252,10 @@ static_assert(MS_ITEM_CAP <= SLOT_IX_MASK, "record indices are packed in 10 bits
 // The setup (one IEEE division, the robustness fix-up, the LUT row) depends on the segment alone: ms_setup runs once
 // per segment lane, ms_item_su once per crossing.  Same operations on the same values, only hoisted.
 struct MsSetup {
-    float a, b, xy0y, xy1y, mask_row;
+    float a, b, mask_row;
     int32_t x0i, y0i;
     uint32_t flags;
+    uint32_t edge_masks;  // the samples a segment's first crossing keeps (low half) and its last crossing keeps (high half)
 };
 constexpr uint32_t SU_IS_DOWN = 1u, SU_POS_SLOPE = 2u, SU_DELTA0 = 4u, SU_BUMP0 = 8u, SU_END_OK = 16u;
 
@@ -283,11 +285,26 @@ __device__ __forceinline__ MsSetup ms_setup(const Segment &sg, bool even_odd) {
     MsSetup su;
     su.a = a;
     su.b = b;
-    su.xy0y = xy0.y;
-    su.xy1y = xy1.y;
     su.mask_row = floorf(minf(a * half_height, half_height - 1.0f)) * (float)MASK_WIDTH;
     su.x0i = f2i(xt0 * x_sign + 0.5f * (x_sign - 1.0f));
     su.y0i = f2i(y0i);
+    // fine.wgsl:316-325 trims the sample mask of a segment's first crossing above its start point and of its last crossing
+    // below its end point; the row either crossing lies in follows from the segment alone (crossing 0 and crossing cnt - 1,
+    // the same expressions ms_item_su evaluates for them), so both trims are made here, once per segment
+    {
+        constexpr uint32_t NSAMP = AA == 2 ? 16u : 8u;
+        constexpr uint32_t FULL = AA == 2 ? 0xffffu : 0xffu;
+        const float z_first = floorf(a * (float)0u + b);
+        const int32_t y_first = su.y0i + (int32_t)0u - f2i(z_first);
+        const uint32_t shift0 = f2u(roundf_te((float)NSAMP * (xy0.y - (float)y_first)));
+        const uint32_t keep_first = (shift0 < 32u ? (FULL << shift0) : 0u) & FULL;
+        const uint32_t last_ix = cnt - 1u;
+        const float z_last = floorf(a * (float)last_ix + b);
+        const int32_t y_last = su.y0i + (int32_t)last_ix - f2i(z_last);
+        const uint32_t shift1 = f2u(roundf_te((float)NSAMP * (xy1.y - (float)y_last)));
+        const uint32_t keep_last = ~(shift1 < 32u ? (FULL << shift1) : 0u) & FULL;
+        su.edge_masks = keep_first | (keep_last << 16);
+    }
     const bool is_delta0 = y0i == xy0.y;
     const bool is_bump0 = even_odd ? (xy0.x == 0.0f) : (xy0.x == 0.0f && y0i != xy0.y);
     su.flags = (is_down ? SU_IS_DOWN : 0u) | (is_positive_slope ? SU_POS_SLOPE : 0u) | (is_delta0 ? SU_DELTA0 : 0u) |
@@ -300,7 +317,6 @@ template <int AA>
 __device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_ix, bool last_pixel, const uint32_t *__restrict__ mask_lut) {
     constexpr bool MSAA16 = AA == 2;
     constexpr uint32_t MASK_WIDTH = MSAA16 ? 64u : 32u, MASK_HEIGHT = MSAA16 ? 64u : 32u;
-    constexpr uint32_t NSAMP = MSAA16 ? 16u : 8u;
     constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
     const bool is_down = (su.flags & SU_IS_DOWN) != 0u, is_positive_slope = (su.flags & SU_POS_SLOPE) != 0u;
     const float a = su.a, b = su.b;
@@ -325,14 +341,8 @@ __device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_i
     uint32_t mask;
     if (MSAA16) mask = (mask_lut[mask_ix / 2u] >> ((mask_ix % 2u) * 16u)) & 0xffffu;
     else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
-    if (sub_ix == 0u && !is_bump) {
-        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy0y - (float)y)));
-        mask &= mask_shift < 32u ? (FULL << mask_shift) : 0u;
-    }
-    if (last_pixel && (su.flags & SU_END_OK) != 0u) {
-        uint32_t mask_shift = f2u(roundf_te((float)NSAMP * (su.xy1y - (float)y)));
-        mask &= ~(mask_shift < 32u ? (FULL << mask_shift) : 0u);
-    }
+    if (sub_ix == 0u && !is_bump) mask &= su.edge_masks & 0xffffu;
+    if (last_pixel && (su.flags & SU_END_OK) != 0u) mask &= su.edge_masks >> 16;
     // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
     return (pix_ix & 0xffu) | ((mask & FULL) << 8) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) |
            (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
@@ -370,23 +380,23 @@ __device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *
         atomicXor(&sh_samples[(pix_ix & 3u) * 64u + (pix_ix >> 2)], mask);
         return;
     }
-    const uint32_t bump_delta = is_down ? 0x1010101u : (uint32_t)(-0x1010101);
-    constexpr uint32_t NH = MSAA16 ? 2u : 1u;
+    // fine.wgsl adds, per word of four samples, e (the word's mask bits spread one to a byte) or -e by the crossing's
+    // direction, plus or minus 0x01010101 for a bump: +(e - bump) upward, -(e - bump) downward, mod 2^32.  The sign is in
+    // the LDS instruction (ds_sub / ds_add, each under its lanes' exec mask) instead of two VALU operations per word
+    // (four mask bits to four bytes: bit k of a nibble times 0x204081 lands on bits k, k + 7, k + 14, k + 21 -- no two
+    // terms on one bit, so the product is fine.wgsl's shift-and-xor spread, and bits 0, 8, 16, 24 of it are bits 0 .. 3)
+    constexpr uint32_t NW = MSAA16 ? 4u : 2u;
+    const uint32_t bump = is_bump ? 0x1010101u : 0u;
+    uint32_t v[NW];
 #pragma unroll
-    for (uint32_t h = 0; h < NH; h++) {
-        uint32_t m8 = (mask >> (8u * h)) & 0xffu;
-        uint32_t m_a = m8 ^ (m8 << 7);
-        uint32_t m_b = m_a ^ (m_a << 14);
-        uint32_t e0 = m_b & 0x1010101u;
-        uint32_t s0 = is_down ? (uint32_t)(-(int32_t)e0) : e0;
-        uint32_t e1 = (m_b >> 4) & 0x1010101u;
-        uint32_t s1 = is_down ? (uint32_t)(-(int32_t)e1) : e1;
-        if (is_bump) {
-            s0 += bump_delta;
-            s1 += bump_delta;
-        }
-        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h) * 64u + (pix_ix >> 2)], s0);
-        atomicAdd(&sh_samples[((pix_ix & 3u) * SWPP + 2u * h + 1u) * 64u + (pix_ix >> 2)], s1);
+    for (uint32_t w = 0; w < NW; w++) v[w] = ((((rec >> (8u + 4u * w)) & 0xfu) * 0x204081u) & 0x1010101u) - bump;
+    uint32_t *word = &sh_samples[(pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2)];
+    if (is_down) {
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) lds_atomic_sub(&word[w * 64u], v[w]);  // (hip's atomicSub is an add of -v)
+    } else {
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) atomicAdd(&word[w * 64u], v[w]);
     }
 }
 
@@ -659,7 +669,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
         Segment sg = segments[seg_data + (lane - seg_start)];
         count = ms_segment(sg, (rule & 1u) != 0u, bt.winding_y[slot]);
         const MsSetup su = ms_setup<AA>(sg, (rule & 1u) != 0u);
-        sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.xy0y[lane] = su.xy0y; sh.su.xy1y[lane] = su.xy1y;
+        sh.su.a[lane] = su.a; sh.su.b[lane] = su.b; sh.su.edge_masks[lane] = su.edge_masks;
         sh.su.mask_row[lane] = su.mask_row; sh.su.x0i[lane] = su.x0i; sh.su.y0i[lane] = su.y0i; sh.su.flags[lane] = su.flags;
     }
     uint32_t incl = wave_incl_scan_u32(count, (int)lane);
@@ -718,7 +728,7 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
             const uint32_t sub_ix = i - ((m >> 6) & 0xffffu);
             const bool last_pixel = raw_next != 0u;
             MsSetup su;
-            su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.xy0y = sh.su.xy0y[el_ix]; su.xy1y = sh.su.xy1y[el_ix];
+            su.a = sh.su.a[el_ix]; su.b = sh.su.b[el_ix]; su.edge_masks = sh.su.edge_masks[el_ix];
             su.mask_row = sh.su.mask_row[el_ix]; su.x0i = sh.su.x0i[el_ix]; su.y0i = sh.su.y0i[el_ix]; su.flags = sh.su.flags[el_ix];
             rec = ms_item_su<AA>(su, sub_ix, last_pixel, mask_lut);
         }
