@@ -769,7 +769,10 @@ int enable_coarse_lds() {
 
 void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     const uint32_t wb = (f.cfg.width_in_tiles + 15u) / 16u, hb = (f.cfg.height_in_tiles + 15u) / 16u;
-    if (wb * hb == 0) return;
+    if (wb * hb == 0) {
+        if (mid) (void)hipEventRecord(mid[0], s);  // (recorded on every way out: vello_hip_get_kernel_ms reads it)
+        return;
+    }
     const uint32_t n_el_blocks = (f.cfg.layout.n_draw_objects + 255u) / 256u;
     // bit planes: 4 waves x 64 tiles per block and step; sized for the pool (blocks beyond bump.tile exit at once)
     uint32_t n_bit_blocks = (uint32_t)(((uint64_t)f.cfg.tiles_size + 256u * 8u - 1u) / (256u * 8u));

@@ -1253,6 +1253,11 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
     if (grid == 0) {
         if (with_draw_scan) launch_draw_scan(f, s);
+        // (the stage's in-between events are recorded on every way out: vello_hip_get_kernel_ms reads all of them)
+        if (mid) {
+            (void)hipEventRecord(mid[0], s);
+            (void)hipEventRecord(mid[1], s);
+        }
         return;
     }
     const uint32_t grid_draw = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
