@@ -214,7 +214,7 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * VELLO_HIP_DEBUG_SEQ_CLIP matches clips with the one-wave stack machine that otherwise only takes scenes of more than
  * 524 288 clips (clip_reduce.wgsl / clip_leaf.wgsl run as partitioned kernels below that): same clip boxes.
  * VELLO_HIP_DEBUG_FINE_SLICES cuts EVERY tile's command list into slices of 4 fills for fine's MSAA modes (normally only
- * lists of >= 64 fills are cut, into slices of 32: the slices' coverage is computed by separate waves and the last one to
+ * lists of >= 96 fills are cut, into slices of 32: the slices' coverage is computed by separate waves and the last one to
  * finish composites the tile): same image -- so that small test scenes exercise the sliced path. */
 enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);

@@ -46,6 +46,8 @@ def gpu_engine(built):
     try:
         return vello_amd.Engine(device=0)
     except RuntimeError as e:  # vello_hip_create: VELLO_HIP_E_NO_DEVICE (-3): no MI355X here -- the -m gpu tests do not apply
-        if "no usable HIP device" in str(e) or "-3" in str(e):
+        # exactly VELLO_HIP_E_NO_DEVICE, as Engine words it ("vello_hip_create failed (-3): no usable HIP device (...)"): any
+        # other failure of create() is a real one and must fail the test, not skip it
+        if str(e).startswith("vello_hip_create failed (-3):") and "no usable HIP device" in str(e):
             pytest.skip("no HIP device: " + str(e))
         raise

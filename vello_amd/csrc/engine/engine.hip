@@ -213,8 +213,15 @@ int acquire_staging(vello_hip_ctx *c, size_t bytes, Staging *&out) {
 }
 
 // fine's coverage scratch (sliced tiles): 64 words per FILL of a sliced tile.  A FILL is >= 5 command words, so 2 x the
-// PTCL pool holds the fills of lists that add up to a sixth of the pool; tiles that do not fit are rendered unsliced.
-uint32_t cov_cap_words(const vello_hip_capacities &d) { return d.ptcl > 0x7fffffffu ? 0xfffffff0u : d.ptcl * 2u; }
+// PTCL pool holds the fills of lists that add up to a sixth of the pool; tiles that do not fit are rendered unsliced
+// (coarse only cuts what fits), so the scratch is an optimisation with a ceiling of its own -- 2^26 words, 256 MB per
+// lane: it does not follow a PTCL pool grown into the gigabytes -- and a context without an MSAA mode, which never
+// slices, holds none (it used to triple the PTCL footprint unconditionally).
+constexpr uint32_t COV_CAP_MAX_WORDS = 1u << 26;
+uint32_t cov_cap_words(const vello_hip_capacities &d, uint32_t aa_mask) {
+    if ((aa_mask & (VELLO_HIP_AA_MASK_MSAA8 | VELLO_HIP_AA_MASK_MSAA16)) == 0u) return 0u;
+    return d.ptcl >= COV_CAP_MAX_WORDS / 2u ? COV_CAP_MAX_WORDS : d.ptcl * 2u;
+}
 
 // words of one coarse bit plane: 2 per 64 tiles + 2 of slack for the 64-bit windows read at the last tiles
 uint32_t tile_bits_plane_words(uint32_t tiles) { return (tiles + 63u) / 64u * 2u + 2u; }
@@ -232,15 +239,15 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
     if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_plane_words(d.tiles) * 3u * 4u))) return r;
-    if ((r = ensure(c, l.cov, (size_t)cov_cap_words(d) * 4u))) return r;
+    if ((r = ensure(c, l.cov, (size_t)cov_cap_words(d, c->aa_mask) * 4u))) return r;
     return 0;
 }
 
 // bytes alloc_lane_pools asks for, per lane
-size_t pool_bytes(const vello_hip_capacities &d) {
+size_t pool_bytes(const vello_hip_capacities &d, uint32_t aa_mask) {
     return (size_t)d.lines * sizeof(LineSoup) + (size_t)d.bin_data * 4u + (size_t)d.tiles * sizeof(Tile) +
            (size_t)d.seg_counts * sizeof(SegmentCount) + (size_t)d.segments * sizeof(Segment) + (size_t)d.blend_spill * 4u +
-           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u + (size_t)cov_cap_words(d) * 4u;
+           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u + (size_t)cov_cap_words(d, aa_mask) * 4u;
 }
 
 // Makes `d` the context's capacities, or leaves the context as it was: ensure() frees a buffer before it allocates the
@@ -414,7 +421,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.slice_items = (SliceItem *)l.slice_items.ptr;
     f.slice_counters = (uint32_t *)l.slice_counters.ptr;
     f.cov = (uint32_t *)l.cov.ptr;
-    f.cov_cap = cov_cap_words(c->caps);
+    f.cov_cap = cov_cap_words(c->caps, c->aa_mask);
     f.slice_fills = f.slice_min_fills = 0u;
     l.slices_on = p->aa != 0u;
     if (p->aa != 0u) {
@@ -1161,7 +1168,7 @@ static int presize_pools(vello_hip_ctx *c, const uint8_t *scene, size_t scene_le
     // real demand, which is usually far below the estimator's bound.
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return VELLO_HIP_OK;
-    const size_t n_lanes = c->lanes.size(), held = pool_bytes(c->caps) * n_lanes, asked = pool_bytes(d) * n_lanes;
+    const size_t n_lanes = c->lanes.size(), held = pool_bytes(c->caps, c->aa_mask) * n_lanes, asked = pool_bytes(d, c->aa_mask) * n_lanes;
     if (asked > held && asked - held > free_b - free_b / 8u) return VELLO_HIP_OK;
     int r = sync_all(c);
     if (r) return r;

@@ -213,7 +213,7 @@ class Engine:
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
         runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
         stack machine instead of the partitioned kernels; fine_slices cuts every tile's command list into slices of
-        4 fills for fine's MSAA modes (normally only lists of >= 64 fills are cut).  Flags not named are cleared (update_debug_flags keeps them)."""
+        4 fills for fine's MSAA modes (normally only lists of >= 96 fills are cut, engine.h FINE_SLICE_MIN_FILLS).  Flags not named are cleared (update_debug_flags keeps them)."""
         self._debug = {"no_cull": bool(no_cull), "stroke_kernel": bool(stroke_kernel), "seq_clip": bool(seq_clip),
                        "fine_slices": bool(fine_slices)}
         d = self._debug
@@ -263,8 +263,9 @@ class Engine:
         return out.view(dtype) if n % np.dtype(dtype).itemsize == 0 else out
 
     def control_words(self):
-        """The last frame's 64-word control block (engine.h Control): bump allocators, tickets, flatten's list lengths, fine's
-        bucket counters [16:48], slice items [48] and coverage-scratch words [49] handed out by coarse."""
+        """The first 64 words of the last frame's 128-word control block (engine.h Control; the rest are flatten's arc
+        sub-list counters): bump allocators, tickets, flatten's list lengths, fine's bucket counters [16:48], slice items [48]
+        and coverage-scratch words [49] handed out by coarse."""
         return self.read_buffer("bump", np.uint32, 256)
 
     def fine_slice_stats(self):
