@@ -22,6 +22,9 @@ the frame's own bump counters / its launch duration measured with HIP events on 
 A TIME (isolated: `frac`), and with --in-flight frames sharing the CUs (`frac_overlapped`, context only).
 `frame_algorithmic_bytes` is d4's single formula.  `cpu_baseline` times the CPU oracle (a C port of the reference's
 CPU shaders + fine.wgsl) on a bounded sample of the same workload on rank 0 at N=1.
+`config.other_configs` carries BASELINE's other single-GPU configurations (C2 Tiger 1024^2 MSAA8, C4 mmark-50k 2048^2
+MSAA16; bounded, ~1 s each); `config.value_200_steps` is the headline once more over a fixed 200 steps (SURVEY 8d d1's
+"median of >= 200 frames" whatever --steps the caller passed).
 """
 import argparse
 import json
@@ -88,24 +91,19 @@ def pct(xs, q):
     return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
 
 
-def measure_copy_peak(device):
-    """Device-to-device float4 copy of 1 GiB on this GPU, this run: bytes read + written / time."""
-    n = 1 << 30
-    a = torch.empty(n, dtype=torch.uint8, device=device)
-    b = torch.empty(n, dtype=torch.uint8, device=device)
-    a.zero_()
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 0.0
-    for _ in range(5):
-        e0.record()
-        b.copy_(a)
-        e1.record()
-        e1.synchronize()
-        best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del a, b
-    return best
+def measure_copy_peak(local_rank):
+    """Device-to-device float4 copy of 1 GiB on this GPU, this run (scripts/calib/copy_bw.hip, the kernel shape
+    MI355X_MICROARCH.md quotes 6.29 TB/s for): bytes read + written / best of 5, GB/s.  None if the helper is not built."""
+    import ctypes
+
+    path = os.path.join(ROOT, "scripts", "calib", "libcopy_bw.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.copy_bw_gbps.restype = ctypes.c_double
+    lib.copy_bw_gbps.argtypes = [ctypes.c_int, ctypes.c_size_t, ctypes.c_int]
+    g = lib.copy_bw_gbps(local_rank, 1 << 30, 5)
+    return g if g > 0 else None
 
 
 def git_head():
@@ -121,18 +119,35 @@ def git_head():
 
 class Workload:
     def __init__(self, key, rank):
+        import vello_amd
         import workloads
 
         self.key = key
+        self.width = self.height = WIDTH
+        self.aa = vello_amd.AaConfig.Msaa16
+        self.caps = None
         if key == "d2":
             self.scene = workloads.paris_like_scene_d2(SEED0 + rank)
             self.caps = dict(D2_CAPS)
             self.mix = "70 % stroked open polylines (width 0.5-4 px, 8-60 vertices, step 4-40 px) / 25 % filled polygons / 5 % cubic blobs (SURVEY 8d d2)"
-        else:
+            self.packed, self.layout = self.scene.resolve()
+        elif key == "r1mix":
             self.scene = workloads.paris_like_scene(SEED0 + rank)
-            self.caps = None
             self.mix = "16 % stroked polylines (width 0.5-3 px, step 1.5-7 px) / 81 % filled polygons / 3 % cubic blobs (round 1's mix, fits config.rs:401-408)"
-        self.packed, self.layout = self.scene.resolve()
+            self.packed, self.layout = self.scene.resolve()
+        elif key == "tiger":  # BASELINE configs[1]
+            d = np.load(os.path.join(ROOT, "tests", "golden", "tiger_scene.npz"))
+            self.packed, self.layout = d["packed"], vello_amd.Layout(*[int(v) for v in d["layout"]])
+            self.width = self.height = 1024
+            self.aa = vello_amd.AaConfig.Msaa8
+            self.mix = "Ghostscript_Tiger.svg through the pico_svg-equivalent loader (tests/golden/tiger_scene.npz), fills + strokes"
+        elif key == "mmark":  # BASELINE configs[3]
+            self.scene = workloads.mmark_scene()
+            self.packed, self.layout = self.scene.resolve()
+            self.width = self.height = 2048
+            self.mix = "mmark-style 50 000 stroked line / quad / cubic elements (examples/scenes/src/mmark.rs:43-202, PCG seed 0x5EED0002, no text label)"
+        else:
+            raise ValueError(key)
         self.n_tag_words = self.layout.path_data_base - self.layout.path_tag_base
 
     def describe(self, engine):
@@ -140,6 +155,80 @@ class Workload:
         return (f"paris-30k-like SYNTHETIC scene '{self.key}' (real paris-30k.svg is not in the reference tree), seed 0x{SEED0:X}+rank, "
                 f"{self.layout.n_paths} paths: {self.mix}; {self.n_tag_words * 4} path tags, {self.packed.nbytes / 1e6:.2f} MB packed encoding, "
                 f"{WIDTH}x{HEIGHT}, MSAA16; pools (elements): " + ", ".join(f"{k} {v}" for k, v in caps.items()))
+
+
+def dominant_of(engine, stage_ms, kernel_ms):
+    """(kernel name, its stage, its mean isolated launch ms, the stage's ms) of the longest launch among per-stage / per-kernel
+    (ms, n) pairs measured one frame at a time."""
+    per_kernel = {f"k_{st}": (stage_ms[st][0] / max(stage_ms[st][1], 1), st) for st in stage_ms if st not in engine.KERNELS}
+    for st, names in engine.KERNELS.items():
+        for kn in names:
+            per_kernel[kn] = (kernel_ms[kn][0] / max(kernel_ms[kn][1], 1), st)
+    k = max(per_kernel, key=lambda n: per_kernel[n][0])
+    st = per_kernel[k][1]
+    return k, st, per_kernel[k][0], stage_ms[st][0] / max(stage_ms[st][1], 1)
+
+
+def measure_other_config(key, label, local_rank, budget_s=0.8):
+    """One of BASELINE's other single-GPU configurations, bounded (about a second of GPU time): frames/s with 4 frames in
+    flight, one-frame latency (median), the dominant kernel with its algorithmic bytes and HBM fraction.  Not the bench metric."""
+    import vello_amd
+
+    wl = Workload(key, 0)
+    dev = f"cuda:{local_rank}"
+    eng = vello_amd.Engine(device=local_rank, capacities=wl.caps)
+    eng.upload_scene(wl.packed, wl.layout)
+    w, h, aa = wl.width, wl.height, wl.aa
+    nif = 4
+    eng.set_frames_in_flight(nif)
+    ring = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(nif)]
+    torch.cuda.synchronize()
+    for i in range(12):
+        eng.render_resident(w, h, BASE_COLOR, aa, out=ring[i % nif])
+    if eng.sync() != 0:
+        return {"config": label, "error": f"frame failed: {eng.bump()}"}
+    t0 = time.perf_counter()
+    n = 0
+    while n < 40 or (time.perf_counter() - t0 < budget_s * 0.5 and n < 4000):
+        eng.render_resident(w, h, BASE_COLOR, aa, out=ring[n % nif])
+        n += 1
+    eng.sync()
+    fps = n / (time.perf_counter() - t0)
+    eng.set_frames_in_flight(1)
+    lat = []
+    for _ in range(5):
+        eng.render_resident(w, h, BASE_COLOR, aa, out=ring[0])
+        eng.sync_frame(0)
+    t0 = time.perf_counter()
+    while len(lat) < 30 or (time.perf_counter() - t0 < budget_s * 0.3 and len(lat) < 400):
+        t1 = time.perf_counter()
+        eng.render_resident(w, h, BASE_COLOR, aa, out=ring[0])
+        eng.sync_frame(0)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    eng.set_profiling(vello_amd.renderer.STAGES)
+    eng.stage_ms(); eng.kernel_ms()
+    for _ in range(20):
+        eng.render_resident(w, h, BASE_COLOR, aa, out=ring[0])
+        eng.sync_frame(0)
+    eng.sync()
+    st_ms, k_ms = eng.stage_ms(), eng.kernel_ms()
+    eng.set_profiling([])
+    bump = eng.bump()
+    kname, stage, k_iso, st_iso = dominant_of(eng, st_ms, k_ms)
+    ptcl_words = 64 * ((w + 15) // 16) * ((h + 15) // 16) + bump["ptcl"]
+    sb = stage_bytes(wl.layout, bump, wl.n_tag_words, w, h, ptcl_words)
+    multi = stage in eng.KERNELS
+    t_ms = st_iso if multi else k_iso
+    return {
+        "config": label, "scene": wl.mix, "size": [w, h], "aa": "msaa8" if int(aa) == 1 else ("msaa16" if int(aa) == 2 else "area"),
+        "value": round(fps, 1), "unit": "frames/s", "frames_in_flight": nif, "timed_frames": n,
+        "one_frame_latency_ms": round(pct(lat, 0.5), 4), "value_one_frame_at_a_time": round(1e3 / pct(lat, 0.5), 1),
+        "dominant_kernel": kname, "dominant_kernel_ms": round(k_iso, 5),
+        "algorithmic_bytes": int(sb[stage]), "bytes_and_time_of": "stage" if multi else "kernel",
+        "frac": round(sb[stage] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if t_ms > 0 else None,
+        "stage_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in st_ms.items() if v[0] / max(v[1], 1) >= 0.002},
+        "bump": bump,
+    }
 
 
 def run_workload(wl, args, rank, local_rank, world, timed_headline):
@@ -203,12 +292,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     iso_ms = engine.stage_ms()
     # ... kernel by kernel: flatten and coarse are stages of several kernels (vello_hip_get_kernel_ms times them apart)
     iso_k = engine.kernel_ms()
-    per_kernel = {f"k_{st}": (iso_ms[st][0] / max(iso_ms[st][1], 1), st) for st in iso_ms if st not in engine.KERNELS}
-    for st, names in engine.KERNELS.items():
-        for kn in names:
-            per_kernel[kn] = (iso_k[kn][0] / max(iso_k[kn][1], 1), st)
-    dominant_kernel = max(per_kernel, key=lambda k: per_kernel[k][0])
-    dominant = per_kernel[dominant_kernel][1]  # its stage: what the events of the timed region go around
+    dominant_kernel, dominant, _, _ = dominant_of(engine, iso_ms, iso_k)  # (its stage: what the timed region's events go around)
 
     # timed region: exactly K steps, events only around the dominant kernel (+ one completion event per frame)
     engine.set_profiling([dominant])
@@ -238,6 +322,22 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
         elapsed = float(t.item())
     own_fps = steps / elapsed
 
+    # the same pass once more over a FIXED 200 steps (">= 200 frames"): the driver's --steps is its own
+    fps_200 = None
+    if timed_headline and not distributed and not args.timed_only:
+        engine.set_profiling([])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(200):
+            pipe.step()
+        pipe.flush()
+        engine.sync()
+        fps_200 = 200 / (time.perf_counter() - t1)
+        step_done_200 = list(step_done[-200:])
+        intervals_200 = [(b - a) * 1e3 for a, b in zip(step_done_200[:-1], step_done_200[1:])]
+    else:
+        intervals_200 = []
+
     exchange_ms = None
     if distributed and timed_headline:
         # the exchange step on its own ("report the gather time separately"): nothing else on the GPUs
@@ -251,7 +351,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
         exchange_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     # one frame at a time: frame latency (host clock around render + wait) and the isolated per-kernel durations
-    n_serial = 0 if args.timed_only else min(max(steps, 20), 200)
+    n_serial = 0 if args.timed_only else (200 if timed_headline else 60)  # (d1: the median of >= 200 frames)
 
     def profiled_frames(n):
         """n frames one at a time with the enabled stages under HIP events, read in five batches: per stage and kernel the MEDIAN
@@ -325,28 +425,39 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     ptcl_words = 64 * ((WIDTH + 15) // 16) * ((HEIGHT + 15) // 16) + bump["ptcl"]
     sb = stage_bytes(wl.layout, bump, wl.n_tag_words, WIDTH, HEIGHT, ptcl_words)
     frame_bytes = d4_frame_bytes(wl.packed.nbytes, wl.layout, bump, wl.n_tag_words, WIDTH, HEIGHT, ptcl_words)
+    stage_iso_ms = all_ms[dominant][0] / max(all_ms[dominant][1], 1)
     if dominant in engine.KERNELS:
         iso_ms = all_k[dominant_kernel][0] / max(all_k[dominant_kernel][1], 1)
     else:
-        iso_ms = all_ms[dominant][0] / max(all_ms[dominant][1], 1)
+        iso_ms = stage_iso_ms
     ovl_ms = dom_ms / max(dom_n, 1)
+    #  algorithmic bytes exist per STAGE: when the dominant kernel is one of a stage's several, `achieved` / `frac`
+    # are the stage's bytes over the stage's time (all its kernels), not over the one kernel's
+    frac_ms = stage_iso_ms if dominant in engine.KERNELS else iso_ms
+    tile_area_bytes = 36 * bump["tile"]
     res = {
         "engine": engine, "frame": frame, "steps": steps, "elapsed": elapsed, "own_fps": own_fps, "bump": bump, "dominant": dominant, "dominant_kernel": dominant_kernel,
         "fine_slices": {"slice_work_items": slice_items, "coverage_scratch_bytes": cov_words * 4,
                         "rule": "MSAA: a tile of >= 96 FILLs is cut into slices of 32 fills (coverage by one wave per slice, composited by the last to finish)"},
         "exchange_ms": exchange_ms, "pcie_fps": pcie_fps, "pcie_pipelined_fps": pcie_pipelined_fps,
         "describe": wl.describe(engine),
-        "frame_ms": {"median": pct(intervals, 0.5), "p10": pct(intervals, 0.1), "p90": pct(intervals, 0.9), "n": len(intervals)},
+        "frame_ms": {"median": pct(intervals, 0.5), "p10": pct(intervals, 0.1), "p90": pct(intervals, 0.9), "mean": (sum(intervals) / len(intervals)) if intervals else None,
+                     "n": len(intervals)},
+        "fps_200": fps_200,
+        "frame_ms_200": {"median": pct(intervals_200, 0.5), "p10": pct(intervals_200, 0.1), "p90": pct(intervals_200, 0.9),
+                         "mean": (sum(intervals_200) / len(intervals_200)) if intervals_200 else None, "n": len(intervals_200)},
         "serial_ms": {"median": pct(serial, 0.5), "p10": pct(serial, 0.1), "p90": pct(serial, 0.9), "n": len(serial)},
         "roofline": {
             "bound": "hbm",
             "kernel": dominant_kernel,
             "kernel_how": "the kernel with the longest isolated launch (HIP events around every kernel, one frame at a time; flatten and coarse "
-                          "are stages of three / two kernels, timed apart)" + ("; algorithmic bytes are its whole stage's" if dominant in engine.KERNELS else ""),
-            "achieved": round(sb[dominant] / (iso_ms * 1e-3) / 1e9, 2) if iso_ms > 0 else None,
+                          "are stages of three / two kernels, timed apart)",
+            "achieved_and_frac_of": ("the kernel's STAGE: its algorithmic bytes over the isolated time of all its kernels (bytes exist per stage only)"
+                                     if dominant in engine.KERNELS else "the kernel: its algorithmic bytes over its isolated launch time"),
+            "achieved": round(sb[dominant] / (frac_ms * 1e-3) / 1e9, 2) if frac_ms > 0 else None,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(sb[dominant] / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso_ms > 0 else None,
+            "frac": round(sb[dominant] / (frac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if frac_ms > 0 else None,
             "algorithmic_bytes_per_launch": int(sb[dominant]),
             "avg_launch_ms": round(iso_ms, 5),
             "avg_launch_ms_how": "HIP events around the kernel, one frame at a time in the timed region's configuration: median of five batches' mean launch times",
@@ -357,6 +468,8 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
             "frame_algorithmic_formula": "SURVEY 8d d4: S + 48Tw + 96P + 168D + 8Bd + 48L + 36A + 48C + 48G + 8Wp + 4Npx",
             "frame_achieved_GBps": round(frame_bytes / (elapsed / steps) / 1e9, 2),
             "frame_frac": round(frame_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "frame_frac_without_tile_area": round((frame_bytes - tile_area_bytes) / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 5),
+            "frame_frac_without_tile_area_how": "d4 minus its 36 A term: the passes over every path's bounding-box tiles (zero fill, backdrop, bit planes), whose size has nothing to do with what is drawn",
             "frame_achieved_GBps_one_frame_at_a_time": round(frame_bytes / (pct(serial, 0.5) * 1e-3) / 1e9, 2) if serial else None,
             "stage_ms": {k: round(v[0] / max(v[1], 1), 5) for k, v in all_ms.items()},
             "kernel_ms_of_multi_kernel_stages": {k: round(v[0] / max(v[1], 1), 5) for k, v in all_k.items()},
@@ -422,6 +535,7 @@ def main():
     ap.add_argument("--workload", choices=["both", "d2", "r1mix"], default="both",
                     help="d2 = SURVEY 8d d2's C3 scene (the workload of `value`); r1mix = round 1's mix; both = d2 + r1mix beside it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip config.other_configs (BASELINE's C2 / C4, ~1 s each)")
     ap.add_argument("--timed-only", action="store_true",
                     help="skip the serial / PCIe / CPU passes (for rocprofv3 runs: every launch it sees is then a "
                          "warm-up or timed-region launch)")
@@ -444,7 +558,7 @@ def main():
 
     head_key = "r1mix" if args.workload == "r1mix" else "d2"
     head_wl = Workload(head_key, rank)
-    peak_measured = measure_copy_peak(f"cuda:{local_rank}") if rank == 0 else None
+    peak_measured = measure_copy_peak(local_rank) if rank == 0 else None
     head = run_workload(head_wl, args, rank, local_rank, world, timed_headline=True)
     second = None
     if args.workload == "both" and not distributed and not args.timed_only:
@@ -490,7 +604,7 @@ def main():
 
     roof = head["roofline"]
     roof["peak_measured"] = round(peak_measured, 1) if peak_measured else None
-    roof["peak_measured_how"] = "torch device-to-device copy of 1 GiB on this GPU in this run, read + written bytes / best of 5"
+    roof["peak_measured_how"] = "float4 device-to-device copy kernel (scripts/calib/copy_bw.hip) of 1 GiB on this GPU in this run, read + written bytes / best of 5"
     roof["traffic"] = traffic
     roof["traffic_source"] = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, "
                               f"collected at commit {traffic_commit})")
@@ -521,10 +635,16 @@ def main():
             "bump": head["bump"],
             "frames_in_flight": max(1, min(args.in_flight, 8)),
             "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-            "frame_ms_pipelined": head["frame_ms"],
+            "frame_completion_interval_ms_pipelined": head["frame_ms"],
+            "frame_completion_interval_how": "host clock between consecutive frames' completions with --in-flight frames queued; completions come in bursts "
+                                             "(the frames in flight finish close together), so the MEDIAN interval is well below ms_per_step -- the mean is ms_per_step",
+            "value_200_steps": None if head["fps_200"] is None else round(head["fps_200"], 2),
+            "frame_completion_interval_ms_200_steps": head["frame_ms_200"],
             "frame_ms_one_at_a_time": head["serial_ms"],
             "value_one_frame_at_a_time": round(1e3 / serial_med, 2) if serial_med else None,
-            "one_frame_at_a_time_how": "vello_hip_set_frames_in_flight(1), then render + wait per frame on the host clock",
+            "one_frame_at_a_time_how": "vello_hip_set_frames_in_flight(1), then render + wait per frame on the host clock, median of 200 frames (SURVEY 8d d1 / b5: "
+                                       "one frame in flight per renderer); NOTE a different kernel configuration than `value`'s: with one frame in flight flatten "
+                                       "runs k_flatten_main / k_flatten_tail instead of k_flatten_strokes / k_flatten_heavy",
             "pcie_inclusive_frames_per_s": None if head["pcie_fps"] is None else round(head["pcie_fps"], 2),
             "pcie_inclusive_pipelined_frames_per_s": None if head["pcie_pipelined_fps"] is None else round(head["pcie_pipelined_fps"], 2),
         },
@@ -538,12 +658,20 @@ def main():
             "steps": second["steps"],
             "ms_per_step": round(second["elapsed"] / second["steps"] * 1e3, 4),
             "value_one_frame_at_a_time": round(1e3 / smed, 2) if smed else None,
-            "frame_ms_pipelined": second["frame_ms"],
+            "frame_completion_interval_ms_pipelined": second["frame_ms"],
             "frame_ms_one_at_a_time": second["serial_ms"],
             "bump": second["bump"],
             "fine_slices": second["fine_slices"],
             "roofline": second["roofline"],
         }
+    if world == 1 and not args.timed_only and not args.no_other_configs:
+        others = []
+        for key, label in (("tiger", "configs[1]: Ghostscript_Tiger.svg, 1024x1024, MSAA8"), ("mmark", "configs[3]: mmark-style 50k stroked quads, 2048x2048, MSAA16")):
+            try:
+                others.append(measure_other_config(key, label, local_rank))
+            except Exception as e:  # (never lose the headline line to a side measurement)
+                others.append({"config": label, "error": repr(e)})
+        result["config"]["other_configs"] = others
     if world == 1 and not args.no_cpu_baseline and not args.timed_only:
         result["cpu_baseline"] = cpu_baseline(head_wl, frame_head)
     print(json.dumps(result))
