@@ -48,6 +48,9 @@ def _lib():
         lib.vo_make_mask_lut.argtypes = [vp]
         lib.vo_make_mask_lut_16.argtypes = [vp]
         lib.vo_set_threads.argtypes = [vp, i32]
+        lib.vo_set_capacity_scale.argtypes = [vp, u32]
+        lib.vo_get_capacity_scale.restype = u32
+        lib.vo_get_capacity_scale.argtypes = [vp]
         _LIB = lib
     return _LIB
 
@@ -65,10 +68,20 @@ def make_mask_lut_16():
 
 
 class Oracle:
-    def __init__(self, capacity_scale=1):
+    """capacity_scale: pools = scale x the reference's fixed sizes (config.rs:398-408).  auto_grow: a frame that overflows a pool
+    (bump.failed's stage bits) doubles the scale -- up to max_capacity_scale -- and runs again from the first stage, so that
+    scenes beyond any fixed pool (the fuzzer's extreme-value mode) are still checked against something."""
+
+    CAPACITY_FAILURES = 0x1F  # STAGE_BINNING | TILE_ALLOC | FLATTEN | PATH_COUNT | COARSE (config.rs:39-44)
+
+    def __init__(self, capacity_scale=1, auto_grow=False, max_capacity_scale=64):
         self._lib = _lib()
         self._h = self._lib.vo_create(capacity_scale)
         self.width = self.height = 0
+        self.auto_grow = auto_grow
+        self.max_capacity_scale = max_capacity_scale
+        self.grown = 0  # times the pools were doubled
+        self._scene_args = None
 
     def __del__(self):
         try:
@@ -88,6 +101,24 @@ class Oracle:
         if r != 0:
             raise RuntimeError("vo_set_scene failed")
         self.width, self.height = width, height
+        self._scene_args = (packed, tuple(layout), width, height, int(base_color_rgba8), int(aa))
+
+    def capacity_scale(self):
+        return int(self._lib.vo_get_capacity_scale(self._h))
+
+    def _grow_if_overflowed(self):
+        """True if the last run overflowed a pool and the pools were doubled (the caller runs again from the first stage)."""
+        if not self.auto_grow or self._scene_args is None:
+            return False
+        if (self.bump()["failed"] & self.CAPACITY_FAILURES) == 0:
+            return False
+        scale = self.capacity_scale()
+        if scale * 2 > self.max_capacity_scale:
+            return False
+        self._lib.vo_set_capacity_scale(self._h, scale * 2)
+        self.set_scene(*self._scene_args)
+        self.grown += 1
+        return True
 
     def set_ramps(self, ramps):
         """Gradient ramp texture: n_ramps x 512 RGBA8 texels as uint32 (ramp_cache.rs), or None."""
@@ -112,14 +143,20 @@ class Oracle:
     def run(self, first, last):
         first = STAGES.index(first) if isinstance(first, str) else first
         last = STAGES.index(last) if isinstance(last, str) else last
-        if self._lib.vo_run(self._h, first, last) != 0:
-            raise RuntimeError("vo_run failed")
+        while True:
+            if self._lib.vo_run(self._h, first, last) != 0:
+                raise RuntimeError("vo_run failed")
+            if first != 0 or not self._grow_if_overflowed():  # (a range from the first stage can simply be run again)
+                break
 
     def render(self):
         out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
-        r = self._lib.vo_render(self._h, out.ctypes.data)
-        if r < 0:
-            raise RuntimeError("vo_render failed")
+        while True:
+            r = self._lib.vo_render(self._h, out.ctypes.data)
+            if r < 0:
+                raise RuntimeError("vo_render failed")
+            if not self._grow_if_overflowed():
+                break
         return out
 
     def buffer(self, name, dtype=np.uint8):

@@ -130,6 +130,9 @@ void vo_make_mask_lut_16(uint8_t out[8192]);
  * shaders' own atomics; outputs then differ from the serial run by what the order of atomics decides.  0/1 = serial,
  * the mode every parity test uses. */
 void vo_set_threads(vo_ctx *, int n_threads);
+/* pools = capacity_scale x config.rs:398-408's sizes from the next vo_set_scene on (growable pools: oracle.py auto_grow) */
+void vo_set_capacity_scale(vo_ctx *c, uint32_t capacity_scale);
+uint32_t vo_get_capacity_scale(const vo_ctx *c);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,11 @@ void vo_destroy(vo_ctx *c) {
 
 void vo_set_threads(vo_ctx *c, int n) { c->n_threads = n; }
 
+/* Pool sizes = capacity_scale x the reference's fixed ones (config.rs:398-408); takes effect at the next vo_set_scene.
+ * The Python wrapper's auto_grow doubles it and renders again while a frame overflows a pool. */
+void vo_set_capacity_scale(vo_ctx *c, uint32_t capacity_scale) { c->cap_scale = capacity_scale ? capacity_scale : 1u; }
+uint32_t vo_get_capacity_scale(const vo_ctx *c) { return c->cap_scale; }
+
 static int ensure(vo_ctx *c, int id, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (c->buf_size[id] >= bytes) return 0;

@@ -58,7 +58,7 @@ def one(mode, seed, eng):
         w = h = 128
         scene, aa, base = fuzz_scene(seed, n_ops=14, extreme=True), AAS[seed % 3], 0xFF000000
         # (scenes that emit > 8 M lines overflow this oracle; crossing indices beyond 16 bits collide in the slot diff of the back half)
-        kw = {"min_agree": None, "oracle": Oracle(capacity_scale=4), "back_half": False}
+        kw = {"min_agree": None, "oracle": Oracle(capacity_scale=4, auto_grow=True), "back_half": False}
     else:
         raise SystemExit(__doc__)
     r = vello_amd.Resolver().resolve(scene)

@@ -501,7 +501,7 @@ def test_emu_extreme_coordinates(emu_engine, v):
             packed, layout = scene(kind).resolve()
             for aa in (AaConfig.Area, AaConfig.Msaa16):
                 compare_frame(emu_engine, packed, layout, 64, 64, BLACK, aa, f"emu_extreme_{kind}_{v}_{int(aa)}",
-                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4))
+                              tol=1 if aa == AaConfig.Area else 0, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4, auto_grow=True))
     finally:
         emu_engine.set_auto_grow(False)
 
@@ -518,7 +518,7 @@ def test_emu_fuzz_extreme_values(emu_engine):
             r = vello_amd.Resolver().resolve(fuzz_scene(seed, n_ops=14, extreme=True))
             aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
             compare_frame(emu_engine, r.packed, r.layout, 128, 128, BLACK, aa, f"emu_fuzzx_{seed}", tol=1 if aa == AaConfig.Area else 0,
-                          resolved=r, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4))
+                          resolved=r, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4, auto_grow=True))
     finally:
         emu_engine.set_auto_grow(False)
 

@@ -138,3 +138,26 @@ def test_smoke_data_image_roundtrip_golden(built, extend):
     h, w = rgba.shape[:2]
     img = _render_resolved(workloads.smoke_data_image_scene(rgba, getattr(Extend, extend)), w, h, 0)
     assert np.array_equal(img[:, :, :3], rgb), f"max diff {np.abs(img[:, :, :3].astype(int) - rgb.astype(int)).max()}"
+
+
+def test_oracle_pools_grow_on_overflow():
+    """a frame that overflows a pool doubles the oracle's pools and runs again (auto_grow), so scenes beyond
+    any fixed pool are still checked by something; without auto_grow the overflow is reported as before."""
+    import workloads
+    from oracle.oracle import Oracle
+
+    scene = workloads.random_test_scene(3, n_paths=400, size=512.0, strokes=True, clips=False)
+    packed, layout = scene.resolve()
+    # an 8192^2 target is 512 x 512 tiles x 64 words = 2^24 words of fixed PTCL blocks: beyond config.rs:408's 2^23
+    fixed = Oracle(capacity_scale=1)
+    fixed.set_scene(packed, layout, 8192, 8192, 0xFF000000, 0)
+    fixed.render()
+    assert fixed.bump()["failed"] != 0 and fixed.grown == 0
+    o = Oracle(capacity_scale=1, auto_grow=True, max_capacity_scale=64)
+    o.set_scene(packed, layout, 8192, 8192, 0xFF000000, 0)
+    img = o.render()
+    assert o.grown >= 1 and o.capacity_scale() >= 2 and o.bump()["failed"] == 0
+    # the same frame from pools that were large enough from the start
+    big = Oracle(capacity_scale=4)
+    big.set_scene(packed, layout, 8192, 8192, 0xFF000000, 0)
+    assert (big.render() == img).all() and big.bump()["failed"] == 0
