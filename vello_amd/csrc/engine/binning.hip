@@ -174,8 +174,16 @@ __global__ void __launch_bounds__(256) k_tile_alloc(Config cfg, const uint32_t *
         p.pad[0] = 0u; p.pad[1] = 0u; p.pad[2] = 0u;
         paths[drawobj_ix] = p;
     }
-    unsigned long long *t64 = reinterpret_cast<unsigned long long *>(tiles + tile_offset);
-    for (uint32_t i = tid; i < fill; i += 256u) t64[i] = 0ull;
+    // 16-byte stores over the 16-byte aligned middle of the range, single tiles at its ends
+    {
+        const uint32_t head = minu(fill, tile_offset & 1u);  // (a Tile is 8 bytes: the pool is 16-byte aligned at even tiles)
+        unsigned long long *t64 = reinterpret_cast<unsigned long long *>(tiles + tile_offset);
+        if (tid < head) t64[tid] = 0ull;
+        const uint32_t pairs = (fill - head) / 2u;
+        uint4 *t128 = reinterpret_cast<uint4 *>(tiles + tile_offset + head);
+        for (uint32_t i = tid; i < pairs; i += 256u) t128[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid == 0u && head + 2u * pairs < fill) t64[fill - 1u] = 0ull;
+    }
 }
 
 void launch_binning(const Frame &f, hipStream_t s) {

@@ -390,26 +390,48 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
             const uint32_t first = path.tiles + row0 * width;
             const uint32_t n = minu(block_rows, height - row0) * width;
             int32_t carry = 0;
-            // the tiles of the NEXT step are requested before this step is scanned: a block is a chain of steps
-            int32_t next = 0;
-            if (lane < n && first + lane < cfg.tiles_size) next = tiles[first + lane].backdrop;
-            for (uint32_t base = 0; base < n; base += 64u) {
-                const uint32_t i = base + lane;
-                const uint32_t tile_ix = first + i;
-                const bool valid = i < n && tile_ix < cfg.tiles_size;
-                const uint32_t col = i % width;
-                int32_t v = next;
-                next = 0;
-                if (i + 64u < n && tile_ix + 64u < cfg.tiles_size) next = tiles[tile_ix + 64u].backdrop;
-                const int32_t own = v;
+            // The tiles of the NEXT GROUP of four steps are requested before this group is scanned: a block is a chain of
+            // steps, and since most steps are their load alone (below) what a wave has in flight is what it streams at --
+            // one 512-byte request per wave was 2 TB/s over the pool (round 4: four).
+            constexpr uint32_t G = 4u;
+            int32_t next[G];
+            // (every lane loads, from a clamped address, and what lies outside the block is zeroed afterwards: a load under a
+            // branch makes the wait for THIS group's tiles a wait for everything in flight, the next group's request included
+            // -- vmcnt counts in order and the compiler cannot count what a branch may have skipped)
+            const uint32_t last_tile = cfg.tiles_size - 1u;
+            auto request = [&](uint32_t base) {
 #pragma unroll
-                for (uint32_t d = 1; d < 64u; d <<= 1) {
-                    const int32_t up = __shfl_up(v, (int)d);
-                    if (lane >= d && col >= d) v += up;
+                for (uint32_t k = 0; k < G; k++) next[k] = tiles[minu(first + base + k * 64u + lane, last_tile)].backdrop;
+            };
+            request(0u);
+            for (uint32_t base = 0; base < n; base += 64u * G) {
+                int32_t cur[G];
+#pragma unroll
+                for (uint32_t k = 0; k < G; k++) cur[k] = next[k];
+                request(base + 64u * G);  // (beyond the block: clamped loads nobody reads)
+#pragma unroll
+                for (uint32_t k = 0; k < G; k++) {
+                    const uint32_t i = base + k * 64u + lane;
+                    if (base + k * 64u >= n) break;
+                    const uint32_t tile_ix = first + i;
+                    const bool valid = i < n && tile_ix < cfg.tiles_size;
+                    int32_t v = valid ? cur[k] : 0;
+                    // Nothing to add up where nothing was bumped: 64 zero backdrops behind a zero carry are their own prefix
+                    // sums.  On a road map that is nearly every step (the two outlines of a stroke cancel within a tile or
+                    // two, and path_count never writes the cancelled pairs), and the step is then its load alone -- no column
+                    // arithmetic (an integer division), no six shuffle rounds.
+                    if (__ballot(v != 0) == 0ull && carry == 0) continue;
+                    const uint32_t col = i % width;
+                    const int32_t own = v;
+#pragma unroll
+                    for (uint32_t d = 1; d < 64u; d <<= 1) {
+                        const int32_t up = __shfl_up(v, (int)d);
+                        if (lane >= d && col >= d) v += up;
+                    }
+                    if (col > lane) v += carry;  // the row began before this step's first lane
+                    carry = __shfl(v, 63);
+                    if (valid && v != own) tiles[tile_ix].backdrop = v;
                 }
-                if (col > lane) v += carry;  // the row began before this step's first lane
-                carry = __shfl(v, 63);
-                if (valid && v != own) tiles[tile_ix].backdrop = v;
             }
         }
       }
