@@ -15,13 +15,16 @@ constexpr uint32_t PATHTAG_PART_WORDS = 1024;  // 256 threads x 4 tag words (= 4
 constexpr uint32_t DRAW_PART = 256;            // draw objects per partition
 constexpr uint32_t FLATTEN_TAGS_PER_THREAD = 4;
 constexpr uint32_t FLATTEN_BLOCK_TAGS = 256 * FLATTEN_TAGS_PER_THREAD;
-constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = 4;
+#ifndef VK_PC_LPT
+#define VK_PC_LPT 4
+#endif
+constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = VK_PC_LPT;
 constexpr uint32_t PATH_COUNT_CHUNK = 256 * PATH_COUNT_LINES_PER_THREAD;
 // path_count sets its lines and Path records aside in LDS between its two passes (k_path_count<true>, four workgroups per
 // CU) when the soup has more chunks than the chip holds workgroups of that kind at once -- that is when every load of pass
 // 2 queues behind the tile atomics of a full chip (3 us each on the road map); below, the plain form is as fast or faster
 // (mmark-50k, 788 chunks: 89 us plain, 100 us with the lines kept).  Decided from a finished frame's bump.lines; kept when unknown.
-constexpr int64_t PATH_COUNT_KEEP_MIN_LINES = 1024 * (int64_t)PATH_COUNT_CHUNK;
+constexpr int64_t PATH_COUNT_KEEP_MIN_LINES = 1024 * 1024;
 // Spin bound for look-back waits: a predecessor always holds a smaller ticket, so it is resident
 // or finished; the bound only turns a driver-level hang into a reported failure.
 constexpr uint32_t SPIN_LIMIT = 1u << 24;

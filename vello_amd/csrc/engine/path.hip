@@ -570,7 +570,7 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 
 void launch_path_count(const Frame &f, hipStream_t s) {
     // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
-    uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u);
+    uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u * 4u / PATH_COUNT_LINES_PER_THREAD);
     if (f.path_count_keep) hipLaunchKernelGGL(k_path_count<true>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
     else hipLaunchKernelGGL(k_path_count<false>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
 }
