@@ -246,14 +246,6 @@ __device__ __forceinline__ uint32_t bcast_byte3(uint32_t v) {
     return __builtin_amdgcn_perm(v, v, 0x03030303u);
 #endif
 }
-// *p -= v on a workgroup-memory word: ds_sub_u32 (hip's atomicSub negates v and adds)
-__device__ __forceinline__ void lds_atomic_sub(uint32_t *p, uint32_t v) {
-#ifdef VELLO_SIMT_EMU
-    *p -= v;
-#else
-    __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
 // v of a lane known at compile time (v_readlane on the GPU)
 template <int L>
 __device__ __forceinline__ uint32_t lane_value(uint32_t v) {

@@ -381,22 +381,18 @@ __device__ __forceinline__ void ms_apply(uint32_t rec, bool even_odd, uint32_t *
         return;
     }
     // fine.wgsl adds, per word of four samples, e (the word's mask bits spread one to a byte) or -e by the crossing's
-    // direction, plus or minus 0x01010101 for a bump: +(e - bump) upward, -(e - bump) downward, mod 2^32.  The sign is in
-    // the LDS instruction (ds_sub / ds_add, each under its lanes' exec mask) instead of two VALU operations per word
-    // (four mask bits to four bytes: bit k of a nibble times 0x204081 lands on bits k, k + 7, k + 14, k + 21 -- no two
-    // terms on one bit, so the product is fine.wgsl's shift-and-xor spread, and bits 0, 8, 16, 24 of it are bits 0 .. 3)
+    // direction, plus or minus 0x01010101 for a bump: +(e - bump) upward, -(e - bump) downward, mod 2^32.
+    // (Four mask bits to four bytes: bit k of a nibble times 0x204081 lands on bits k, k + 7, k + 14, k + 21 -- no two
+    // terms on one bit, so the product is fine.wgsl's shift-and-xor spread, and bits 0, 8, 16, 24 of it are bits 0 .. 3.)
+    // (Round 4 measured the sign in the LDS instruction instead -- ds_sub for the downward lanes, ds_add for the others,
+    // each under its exec mask: 8 VALU fewer per fill, twice the LDS instructions, no faster; profiles/r04_ab_s12_*.)
     constexpr uint32_t NW = MSAA16 ? 4u : 2u;
     const uint32_t bump = is_bump ? 0x1010101u : 0u;
-    uint32_t v[NW];
-#pragma unroll
-    for (uint32_t w = 0; w < NW; w++) v[w] = ((((rec >> (8u + 4u * w)) & 0xfu) * 0x204081u) & 0x1010101u) - bump;
     uint32_t *word = &sh_samples[(pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2)];
-    if (is_down) {
 #pragma unroll
-        for (uint32_t w = 0; w < NW; w++) lds_atomic_sub(&word[w * 64u], v[w]);  // (hip's atomicSub is an add of -v)
-    } else {
-#pragma unroll
-        for (uint32_t w = 0; w < NW; w++) atomicAdd(&word[w * 64u], v[w]);
+    for (uint32_t w = 0; w < NW; w++) {
+        const uint32_t v = ((((rec >> (8u + 4u * w)) & 0xfu) * 0x204081u) & 0x1010101u) - bump;
+        atomicAdd(&word[w * 64u], is_down ? 0u - v : v);
     }
 }
 
