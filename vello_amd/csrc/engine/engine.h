@@ -44,7 +44,13 @@ constexpr uint32_t FINE_HEAVY_WORDS = 384;
 // slice is a work item of its own (one wave computes the coverage of its fills into the coverage scratch), and the wave that
 // finishes a tile's last slice composites the tile from the scratch (fine.hip).  k_fine's launch is as long as its longest
 // tile's chain of fills otherwise (d2: 137 fills, 258 us against 117 us of balanced work).
-constexpr uint32_t FINE_SLICE_FILLS = 32, FINE_SLICE_MIN_FILLS = 96;
+#ifndef VK_SLICE_FILLS
+#define VK_SLICE_FILLS 32
+#endif
+#ifndef VK_SLICE_MIN_FILLS
+#define VK_SLICE_MIN_FILLS 96
+#endif
+constexpr uint32_t FINE_SLICE_FILLS = VK_SLICE_FILLS, FINE_SLICE_MIN_FILLS = VK_SLICE_MIN_FILLS;
 constexpr uint32_t FINE_SLICE_FILLS_FORCED = 4, FINE_SLICE_MIN_FILLS_FORCED = 5;  // VELLO_HIP_DEBUG_FINE_SLICES
 struct SliceItem {
     uint32_t tile_ix;     // ~0: a hole left by a tile whose slices did not fit the capacity
