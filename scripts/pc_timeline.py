@@ -21,6 +21,8 @@ def report(key):
     n_lines = eng.bump()["lines"]
     n_chunks = (n_lines + 1023) // 1024
     raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 4 * 8192) * 2:cap * 2].reshape(-1, 8).astype(np.int64)[:n_chunks]
+    if os.environ.get("PC_OLD") != "1":
+        return report_agg(key, raw, n_chunks)
     t0, t1, t2, t3 = (raw[:, i] for i in range(4))
     setup, rows, walk, rounds = (raw[:, i] for i in range(4, 8))
     base = t0.min()
@@ -40,6 +42,26 @@ def report(key):
         rs = np.clip(np.minimum(us(t2), b) - np.maximum(us(t1), a), 0, None).sum() / step
         print(f"  {a:6.0f} us: resident chunks {res:6.0f}  (pass 1 {p1:6.0f}, reserving {rs:6.0f}, pass 2 {res - p1 - rs:6.0f}) started {int(((us(t0) >= a) & (us(t0) < b)).sum())}")
     del eng
+
+
+def report_agg(key, raw, n_chunks):
+    """k_path_count_agg: start / walks + scan done / counted (pass A) / end, flush answered / records written (pass B), table entries
+    used, crossings that went to memory directly."""
+    t0, t1, t2, t3, t4, t5, n_occ, direct = (raw[:, i] for i in range(8))
+    base = t0.min()
+    us = lambda t: (t - base) / 100.0
+    print(f"{key}: {n_chunks} chunks; launch span {us(t3).max():.1f} us; table entries used per chunk mean {n_occ.mean():.0f} p90 {np.percentile(n_occ, 90):.0f} "
+          f"max {n_occ.max()}; crossings sent to memory directly {direct.sum()} ({direct.sum() / max(n_chunks, 1):.1f} per chunk)")
+    for name, a, b in (("pass 1 (loads, walks, scan)", t0, t1), ("pass A (count in LDS)", t1, t2), ("flush (atomics answered)", t2, t4),
+                       ("pass B (records)", t4, t5), ("clear", t5, t3), ("whole chunk", t0, t3)):
+        d = (b - a) / 100.0
+        print(f"  {name:28s} mean {d.mean():7.2f} us  p50 {np.median(d):7.2f}  p90 {np.percentile(d, 90):7.2f}  max {d.max():7.2f}   sum {d.sum():9.0f}")
+    step = 5.0
+    for a in np.arange(0.0, us(t3).max() + step, step):
+        b = a + step
+        ov = lambda x, y: np.clip(np.minimum(us(y), b) - np.maximum(us(x), a), 0, None).sum() / step
+        print(f"  {a:6.0f} us: resident chunks {ov(t0, t3):6.0f}  (pass 1 {ov(t0, t1):6.0f}, A {ov(t1, t2):6.0f}, flush {ov(t2, t4):6.0f}, B {ov(t4, t5):6.0f}) "
+              f"started {int(((us(t0) >= a) & (us(t0) < b)).sum())}")
 
 
 if __name__ == "__main__":

@@ -7,6 +7,10 @@
 // count the previous stage left in `bump` (the *_setup dispatches disappear).
 #include "engine.h"
 
+#ifndef VK_PC_AGG
+#define VK_PC_AGG 0
+#endif
+
 namespace vk {
 
 namespace {
@@ -358,6 +362,262 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
     }
 }
 
+// ---- k_path_count_agg: the tile atomics of a whole workgroup chunk added up in LDS first -------------------------------
+//
+// What a scattered atomic costs is one request per (instruction, distinct cache line), 2.7e10 per second chip-wide, whether
+// the lines come from one XCD or from all (scripts/calib/atomic_rate.hip, atomic_scope.hip); k_path_count above issues 2.0-2.3
+// M of them on the road map (scripts/pc_requests.py) and runs at that rate.  The 1 024 lines of a chunk are consecutive lines
+// of a few paths and cross the same tiles over and over: per chunk 1 430 crossings fall into 475 tiles on 207 cache lines of
+// the tile pool.  So the workgroup counts in LDS -- a small hash table keyed by the cache line (16 tiles), a word per tile:
+// crossings in the low half, the sum of the top-edge backdrop bumps in the high half -- and then asks memory ONCE per touched
+// tile, 16 lanes on the 16 tiles of a line: 0.7-0.9 M requests.  The returned old value of a tile becomes the cursor its
+// crossings draw their slot index from (a returning LDS add) when the walk is repeated to write the SegmentCount records.
+// Which crossing of a tile gets which slot is as arbitrary as in the reference (path_count.wgsl:189 is an atomicAdd in
+// dispatch order).  A line whose cache line finds no place in the table (PC_PROBES slots taken by other lines: the table
+// only grows within a chunk, so both walks see the same answer) goes to memory directly, as every crossing used to.
+// The walks of a thread's lines live in registers between the passes (13 words each).
+#ifndef VK_PC_TABLE_LOG2
+#define VK_PC_TABLE_LOG2 9
+#endif
+constexpr uint32_t PC_TABLE_LOG2 = VK_PC_TABLE_LOG2, PC_TABLE = 1u << PC_TABLE_LOG2, PC_PROBES = 4u;
+constexpr uint32_t PC_EMPTY = 0xffffffffu, PC_NONE = 0xffffffffu;
+
+struct PcTable {
+    uint32_t keys[PC_TABLE];     // tile index >> 4 of the entry, PC_EMPTY
+    uint32_t cnt[PC_TABLE][16];  // pass A: crossings | backdrop sum << 16; after the flush: the tile's slot cursor
+    uint16_t occupied[PC_TABLE];
+    uint32_t n_occ;
+};
+
+struct PcWalk {
+    float a, b, x0, y0;
+    uint32_t imin, count;
+    int32_t ymin, ymax;          // rows bumped in column 0 by a line left of the rectangle
+    uint32_t base;               // tile index of (x, y) = base + y * stride + x
+    int32_t stride, bbox0, bbox2;
+    uint32_t flags;              // 1: is_down, 2: negative slope, 4: y0 == s0.y
+};
+
+__device__ __forceinline__ PcWalk pc_pack(const LineWalk &w) {
+    PcWalk p;
+    p.a = w.a; p.b = w.b; p.x0 = w.x0; p.y0 = w.y0;
+    p.imin = w.imin;
+    p.count = w.valid ? w.imax - w.imin : 0u;
+    p.ymin = w.valid ? w.ymin : 0; p.ymax = w.valid ? w.ymax : 0;
+    p.base = w.tiles_base - (uint32_t)w.bbox1 * (uint32_t)w.stride - (uint32_t)w.bbox0;
+    p.stride = w.stride; p.bbox0 = w.bbox0; p.bbox2 = w.bbox2;
+    p.flags = (w.is_down ? 1u : 0u) | (w.is_positive_slope ? 0u : 2u) | (w.y0 == w.s0y ? 4u : 0u);
+    return p;
+}
+
+// crossing s of a walk: its tile and the tile its top edge bumps (PC_NONE: none, or outside the pool)
+__device__ __forceinline__ void pc_crossing(const PcWalk &w, uint32_t s, float &last_z, uint32_t tiles_size, uint32_t &key, uint32_t &bkey, uint32_t &i_out) {
+    const uint32_t i = w.imin + s;
+    const float z = floorf(w.a * (float)i + w.b);
+    const int32_t y = f2i(w.y0 + (float)i - z);
+    const int32_t x = f2i(w.x0 + ((w.flags & 2u) ? -1.0f : 1.0f) * z);
+    const uint32_t row = w.base + (uint32_t)y * (uint32_t)w.stride;
+    const bool top_edge = (i == 0u) ? ((w.flags & 4u) != 0u) : (last_z == z);
+    bkey = PC_NONE;
+    if (top_edge && x + 1 < w.bbox2) {
+        const uint32_t t = row + (uint32_t)maxi(x + 1, w.bbox0);
+        if (t < tiles_size) bkey = t;
+    }
+    key = row + (uint32_t)x;
+    last_z = z;
+    i_out = i;
+}
+
+__device__ __forceinline__ uint32_t pc_hash(uint32_t line) { return (line * 0x9E3779B1u) >> (32u - PC_TABLE_LOG2); }
+
+template <bool INSERT>
+__device__ __forceinline__ uint32_t pc_slot(PcTable &t, uint32_t line) {
+    uint32_t s = pc_hash(line);
+#pragma unroll 1
+    for (uint32_t p = 0; p < PC_PROBES; p++) {
+        uint32_t k = __atomic_load_n(&t.keys[s], __ATOMIC_RELAXED);
+        if (k == line) return s;
+        if (k == PC_EMPTY) {
+            if (!INSERT) return PC_NONE;
+            k = atomicCAS(&t.keys[s], PC_EMPTY, line);
+            if (k == PC_EMPTY) {
+                t.occupied[atomicAdd(&t.n_occ, 1u)] = (uint16_t)s;
+                return s;
+            }
+            if (k == line) return s;
+        }
+        s = (s + 1u) & (PC_TABLE - 1u);
+    }
+    return PC_NONE;
+}
+
+// the slot of a tile's cache line, remembering the last answer (a walk stays on a line for several steps)
+template <bool INSERT>
+__device__ __forceinline__ uint32_t pc_slot_of(PcTable &t, uint32_t tile_ix, uint32_t &last_line, uint32_t &last_slot) {
+    const uint32_t line = tile_ix >> 4;
+    if (line != last_line) {
+        last_line = line;
+        last_slot = pc_slot<INSERT>(t, line);
+    }
+    return last_slot;
+}
+
+template <uint32_t LPT>
+__global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
+                                                        const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
+    __shared__ uint32_t sh_scan[4];
+    __shared__ uint32_t sh_base;
+    __shared__ PcTable tb;
+#ifdef VELLO_PC_TIMELINE
+    __shared__ uint32_t sh_direct;  // measurement build: crossings and bumps that found no place in the table
+    if (threadIdx.x == 0u) sh_direct = 0u;
+#endif
+    const uint32_t tid = threadIdx.x;
+    if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
+    const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
+    const uint32_t n_paths = cfg.layout.n_paths;
+    for (uint32_t k = tid; k < PC_TABLE; k += 256u) tb.keys[k] = PC_EMPTY;
+    for (uint32_t k = tid; k < PC_TABLE * 16u; k += 256u) (&tb.cnt[0][0])[k] = 0u;
+    if (tid == 0u) tb.n_occ = 0u;
+    __syncthreads();
+    constexpr uint32_t CHUNK = 256u * LPT;
+    for (uint32_t chunk = blockIdx.x * CHUNK; chunk < n_lines; chunk += gridDim.x * CHUNK) {
+#ifdef VELLO_PC_TIMELINE
+        // measurement build (scripts/pc_timeline.py): wall-clock stamps (100 MHz) of the chunk's phases in the tail of the pool
+        const uint32_t tl0 = (uint32_t)wall_clock64();
+#endif
+        // ---- pass 1: the walks; the chunk's slice of the SegmentCount pool ----
+        LineSoup ln[LPT];
+        Path pa[LPT];
+#pragma unroll
+        for (uint32_t j = 0; j < LPT; j++) ln[j] = load_line(lines, minu(chunk + j * 256u + tid, n_lines - 1u));
+#pragma unroll
+        for (uint32_t j = 0; j < LPT; j++) pa[j] = load_path(paths, ln[j].path_ix < n_paths ? ln[j].path_ix : 0u);  // (the pool holds >= 256 records)
+        PcWalk w[LPT];
+        uint32_t my_total = 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < LPT; j++) {
+            LineWalk lw = {};
+            if (chunk + j * 256u + tid < n_lines) lw = setup_line_walk(ln[j], [&]() { return pa[j]; }, n_paths);
+            w[j] = pc_pack(lw);
+            my_total += w[j].count;
+        }
+        uint32_t total;
+        const uint32_t incl = block256_incl_scan_u32(my_total, sh_scan, &total);
+#ifdef VELLO_PC_TIMELINE
+        const uint32_t tl1 = (uint32_t)wall_clock64();
+#endif
+        uint32_t reserved = 0u;
+        if (tid == 0u && total) reserved = atomicAdd(&bump->seg_counts, total);  // (answers while pass A runs)
+        // ---- pass A: count into the table ----
+        uint32_t last_line = PC_NONE, last_slot = PC_NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < LPT; j++) {
+            const uint32_t dword = (w[j].flags & 1u) ? 0xffff0000u : 0x00010000u;  // -1 or +1 in the high half
+            for (int32_t y = w[j].ymin; y < w[j].ymax; y++) {
+                const uint32_t t = w[j].base + (uint32_t)w[j].bbox0 + (uint32_t)y * (uint32_t)w[j].stride;
+                if (t < cfg.tiles_size) {
+                    const uint32_t slot = pc_slot_of<true>(tb, t, last_line, last_slot);
+                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][t & 15u], dword);
+                }
+            }
+            float last_z = floorf(w[j].a * ((float)w[j].imin - 1.0f) + w[j].b);
+            for (uint32_t s = 0; s < w[j].count; s++) {
+                uint32_t key, bkey, i;
+                pc_crossing(w[j], s, last_z, cfg.tiles_size, key, bkey, i);
+                if (key < cfg.tiles_size) {
+                    const uint32_t slot = pc_slot_of<true>(tb, key, last_line, last_slot);
+                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][key & 15u], 1u);
+                }
+                if (bkey != PC_NONE) {
+                    const uint32_t slot = pc_slot_of<true>(tb, bkey, last_line, last_slot);
+                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][bkey & 15u], dword);
+                }
+            }
+        }
+        if (tid == 0u) sh_base = reserved;
+        __syncthreads();
+#ifdef VELLO_PC_TIMELINE
+        const uint32_t tl2 = (uint32_t)wall_clock64();
+#endif
+        // ---- flush: one returning add per touched tile, 16 lanes on the 16 tiles of a cache line ----
+        const uint32_t n_occ = tb.n_occ;
+        for (uint32_t k = tid; k < n_occ * 16u; k += 256u) {
+            const uint32_t e = tb.occupied[k >> 4], t = k & 15u;
+            const uint32_t word = tb.cnt[e][t];
+            const uint32_t n = word & 0xffffu;
+            const int32_t d = (int32_t)word >> 16;
+            const uint32_t ix = tb.keys[e] * 16u + t;
+            if (n != 0u) tb.cnt[e][t] = atomicAdd(&tile[ix].segment_count_or_ix, n);
+            if (d != 0) atomicAdd(&tile[ix].backdrop, d);
+        }
+        __syncthreads();
+#ifdef VELLO_PC_TIMELINE
+        __builtin_amdgcn_s_waitcnt(0);
+        const uint32_t tl4 = (uint32_t)wall_clock64();
+#endif
+        // ---- pass B: the records ----
+        uint32_t seg_base = sh_base + (incl - my_total);
+        last_line = PC_NONE; last_slot = PC_NONE;
+#pragma unroll
+        for (uint32_t j = 0; j < LPT; j++) {
+            const uint32_t line_ix = chunk + j * 256u + tid;
+            const int32_t delta = (w[j].flags & 1u) ? -1 : 1;
+            for (int32_t y = w[j].ymin; y < w[j].ymax; y++) {
+                const uint32_t t = w[j].base + (uint32_t)w[j].bbox0 + (uint32_t)y * (uint32_t)w[j].stride;
+                if (t < cfg.tiles_size && pc_slot_of<false>(tb, t, last_line, last_slot) == PC_NONE) atomicAdd(&tile[t].backdrop, delta);
+            }
+            float last_z = floorf(w[j].a * ((float)w[j].imin - 1.0f) + w[j].b);
+            for (uint32_t s = 0; s < w[j].count; s++) {
+                uint32_t key, bkey, i;
+                pc_crossing(w[j], s, last_z, cfg.tiles_size, key, bkey, i);
+                uint32_t seg_within_slice = 0u;
+                if (key < cfg.tiles_size) {
+                    const uint32_t slot = pc_slot_of<false>(tb, key, last_line, last_slot);
+                    if (slot != PC_NONE) seg_within_slice = atomicAdd(&tb.cnt[slot][key & 15u], 1u);
+                    else {
+                        seg_within_slice = atomicAdd(&tile[key].segment_count_or_ix, 1u);
+#ifdef VELLO_PC_TIMELINE
+                        atomicAdd(&sh_direct, 1u);
+#endif
+                    }
+                }
+                if (bkey != PC_NONE && pc_slot_of<false>(tb, bkey, last_line, last_slot) == PC_NONE) atomicAdd(&tile[bkey].backdrop, delta);
+                const uint32_t seg_ix = seg_base + s;
+                if (seg_ix < cfg.seg_counts_size) {
+                    SegmentCount sc;
+                    sc.line_ix = line_ix;
+                    sc.counts = (seg_within_slice << 16) | i;
+                    seg_counts[seg_ix] = sc;
+                }
+            }
+            seg_base += w[j].count;
+        }
+        __syncthreads();
+#ifdef VELLO_PC_TIMELINE
+        const uint32_t tl5 = (uint32_t)wall_clock64();
+#endif
+        // ---- the table back to empty: only what the chunk touched ----
+        for (uint32_t k = tid; k < n_occ * 16u; k += 256u) tb.cnt[tb.occupied[k >> 4]][k & 15u] = 0u;
+        for (uint32_t k = tid; k < n_occ; k += 256u) tb.keys[tb.occupied[k]] = PC_EMPTY;
+        if (tid == 0u) tb.n_occ = 0u;
+        __syncthreads();
+#ifdef VELLO_PC_TIMELINE
+        if (tid == 0u) {
+            const uint32_t slot = chunk / CHUNK;
+            if (cfg.seg_counts_size > 4u * 8192u && slot < 8192u) {
+                SegmentCount *dst = seg_counts + (cfg.seg_counts_size - 4u * 8192u) + 4u * slot;
+                dst[0].line_ix = tl0; dst[0].counts = tl1;
+                dst[1].line_ix = tl2; dst[1].counts = (uint32_t)wall_clock64();
+                dst[2].line_ix = tl4; dst[2].counts = tl5;
+                dst[3].line_ix = n_occ; dst[3].counts = sh_direct;
+                sh_direct = 0u;
+            }
+        }
+#endif
+    }
+}
+
 // backdrop_dyn.wgsl:28-86: row-wise inclusive prefix of tile backdrops.
 // The reference gives a row to a thread that walks it tile by tile (load -> add -> store, one memory latency per tile,
 // lanes striding rows: nothing coalesces).  Here a WAVE owns a path and its lanes take 64 CONSECUTIVE tiles of the
@@ -571,6 +831,10 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 void launch_path_count(const Frame &f, hipStream_t s) {
     // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
     uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u * 4u / PATH_COUNT_LINES_PER_THREAD);
+#if VK_PC_AGG
+    hipLaunchKernelGGL(k_path_count_agg<PATH_COUNT_LINES_PER_THREAD>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    return;
+#endif
     if (f.path_count_keep) hipLaunchKernelGGL(k_path_count<true>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
     else hipLaunchKernelGGL(k_path_count<false>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
 }
