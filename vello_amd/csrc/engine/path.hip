@@ -8,7 +8,7 @@
 #include "engine.h"
 
 #ifndef VK_PC_AGG
-#define VK_PC_AGG 0
+#define VK_PC_AGG 1
 #endif
 
 namespace vk {
@@ -52,13 +52,16 @@ __device__ __forceinline__ Path load_path(const Path *__restrict__ paths, uint32
 
 // `get_path`: the line's Path record, asked for only once the line is known to cross anything (pass 1 loads it and sets it
 // aside, pass 2 takes it from there: k_path_count below)
+// Written without early exits: a line that crosses nothing carries `valid == false` through the same arithmetic (its
+// values are never used), so that the compiler keeps one copy of the twenty results instead of moving them between the
+// copies of four exit paths (100 of the 212 VALU instructions per line were v_mov).  `get_path` is asked for every line.
 template <class GetPath>
 __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPath get_path, uint32_t n_paths) {
-    LineWalk w = {};
+    LineWalk w;
     // A tag stream with more PATH markers than the layout counts (only a hand-made stream: resolve appends its extra
     // markers behind the last segment, resolve.rs:127-129) yields lines whose path has no Path record.  WebGPU reads
-    // zeros there (stride 0 -> no crossings, path_count.wgsl:112); HIP would read past paths[].
-    if (line.path_ix >= n_paths) return w;
+    // zeros there (stride 0 -> no crossings, path_count.wgsl:112); HIP would read past paths[]: get_path clamps.
+    bool valid = line.path_ix < n_paths;
     const float TILE_SCALE = 0.0625f;
     bool is_down = line.p1y >= line.p0y;
     vec2 xy0 = is_down ? v2(line.p0x, line.p0y) : v2(line.p1x, line.p1y);
@@ -69,8 +72,7 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
     uint32_t count = count_x + span(s0.y, s1.y);
     float dx = fabsf(s1.x - s0.x);
     float dy = s1.y - s0.y;
-    if (dx + dy == 0.0f) return w;
-    if (dy == 0.0f && floorf(s0.y) == s0.y) return w;
+    valid = valid && !(dx + dy == 0.0f) && !(dy == 0.0f && floorf(s0.y) == s0.y);
     float idxdy = 1.0f / (dx + dy);
     float a = dx * idxdy;
     bool is_positive_slope = s1.x >= s0.x;
@@ -88,7 +90,7 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
     int32_t bbox0 = (int32_t)path.bbox[0], bbox1 = (int32_t)path.bbox[1], bbox2 = (int32_t)path.bbox[2], bbox3 = (int32_t)path.bbox[3];
     float xmin = minf(s0.x, s1.x);
     int32_t stride = bbox2 - bbox0;
-    if (s0.y >= (float)bbox3 || s1.y <= (float)bbox1 || xmin >= (float)bbox2 || stride == 0) return w;
+    valid = valid && !(s0.y >= (float)bbox3 || s1.y <= (float)bbox1 || xmin >= (float)bbox2 || stride == 0);
     uint32_t imin = 0u;
     if (s0.y < (float)bbox1) {
         float iminf = roundf_te(((float)bbox1 - y0 + b - a) / (1.0f - a)) - 1.0f;
@@ -134,13 +136,13 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
         }
     }
     imax = maxu(imin, imax);
-    w.valid = true;
+    w.valid = valid;
     w.is_down = is_down;
     w.is_positive_slope = is_positive_slope;
     w.a = a; w.b = b; w.x0 = x0; w.y0 = y0; w.x_sign = x_sign; w.s0x = s0.x; w.s0y = s0.y;
-    w.imin = imin; w.imax = imax;
-    w.ymin = maxi(ymin, bbox1);
-    w.ymax = mini(ymax, bbox3);
+    w.imin = valid ? imin : 0u; w.imax = valid ? imax : 0u;
+    w.ymin = valid ? maxi(ymin, bbox1) : 0;
+    w.ymax = valid ? mini(ymax, bbox3) : 0;
     w.bbox0 = bbox0; w.bbox1 = bbox1; w.bbox2 = bbox2; w.bbox3 = bbox3; w.stride = stride;
     w.tiles_base = path.tiles;
     return w;
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                     sh_keep[3][at] = known ? __float_as_uint(line.p1x) : 0u; sh_keep[4][at] = known ? __float_as_uint(line.p1y) : 0u;
                 }
                 LineWalk w = setup_line_walk(line, [&]() {
-                    const Path p = load_path(paths, line.path_ix);
+                    const Path p = load_path(paths, line.path_ix < cfg.layout.n_paths ? line.path_ix : 0u);  // (the pool holds >= 256 records)
                     if (KEEP) {
                         sh_keep[5][at] = p.bbox[0]; sh_keep[6][at] = p.bbox[1]; sh_keep[7][at] = p.bbox[2]; sh_keep[8][at] = p.bbox[3];
                         sh_keep[0][at] = p.tiles;
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
             if (!KEEP) {
                 if (line_ix < n_lines) {
                     const LineSoup line = load_line(lines, line_ix);
-                    w = setup_line_walk(line, [&]() { return load_path(paths, line.path_ix); }, cfg.layout.n_paths);
+                    w = setup_line_walk(line, [&]() { return load_path(paths, line.path_ix < cfg.layout.n_paths ? line.path_ix : 0u); }, cfg.layout.n_paths);
                 }
             } else if (line_ix < n_lines) {
                 const uint32_t at = j * 256u + tid;
@@ -371,114 +373,158 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
 // the tile pool.  So the workgroup counts in LDS -- a small hash table keyed by the cache line (16 tiles), a word per tile:
 // crossings in the low half, the sum of the top-edge backdrop bumps in the high half -- and then asks memory ONCE per touched
 // tile, 16 lanes on the 16 tiles of a line: 0.7-0.9 M requests.  The returned old value of a tile becomes the cursor its
-// crossings draw their slot index from (a returning LDS add) when the walk is repeated to write the SegmentCount records.
-// Which crossing of a tile gets which slot is as arbitrary as in the reference (path_count.wgsl:189 is an atomicAdd in
-// dispatch order).  A line whose cache line finds no place in the table (PC_PROBES slots taken by other lines: the table
-// only grows within a chunk, so both walks see the same answer) goes to memory directly, as every crossing used to.
-// The walks of a thread's lines live in registers between the passes (13 words each).
+// crossings draw their slot index from (a returning LDS add).  Which crossing of a tile gets which slot is as arbitrary as in
+// the reference (path_count.wgsl:189 is an atomicAdd in dispatch order).  A tile whose cache line finds no place in the table
+// (PC_PROBES slots taken by other lines) goes to memory directly, as every crossing used to.
+//
+// The walks stay in the registers of the threads that set them up (11 words a line).  The counting pass is a thread per
+// line; what a crossing learns there -- the address of its cursor, or the slot index itself when it went to memory directly
+// -- waits in a per-wave stash (PC_STASH crossings; the ones beyond it take the direct route afterwards), so that the
+// SegmentCount records are written by a pass with a crossing per lane that repeats none of the arithmetic.
 #ifndef VK_PC_TABLE_LOG2
 #define VK_PC_TABLE_LOG2 9
 #endif
-constexpr uint32_t PC_TABLE_LOG2 = VK_PC_TABLE_LOG2, PC_TABLE = 1u << PC_TABLE_LOG2, PC_PROBES = 4u;
+#ifndef VK_PC_STASH
+#define VK_PC_STASH 768
+#endif
+constexpr uint32_t PC_TABLE_LOG2 = VK_PC_TABLE_LOG2, PC_TABLE = 1u << PC_TABLE_LOG2, PC_PROBES = 3u;
 constexpr uint32_t PC_EMPTY = 0xffffffffu, PC_NONE = 0xffffffffu;
+constexpr uint32_t PC_STASH = VK_PC_STASH;  // crossings per wave and chunk that wait in LDS for their cursors
+constexpr uint32_t PC_DONE = 0x80000000u;   // stash word: bits 0-15 are the slot index already (else: the cursor's word index)
 
-struct PcTable {
-    uint32_t keys[PC_TABLE];     // tile index >> 4 of the entry, PC_EMPTY
-    uint32_t cnt[PC_TABLE][16];  // pass A: crossings | backdrop sum << 16; after the flush: the tile's slot cursor
+// `c` for some lane of the wave, as a scalar branch condition: the seldom-taken arms below are a handful of instructions, which
+// the compiler would run with an empty exec mask rather than branch over.  (The emulator runs lanes as fibers: the lane's own c.)
+#ifdef VELLO_SIMT_EMU
+#define PC_WAVE_ANY(c) (c)
+#else
+#define PC_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#endif
+
+constexpr uint32_t PC_CNT_WORDS = PC_TABLE * 16u;
+struct PcShared {
+    // (the 64 words behind keys[] and cnt[]: a place of its own for every lane whose LDS operation is not wanted -- the walk
+    // loop selects ADDRESSES instead of branching around the operations: a branch costs five scalar instructions, a select one)
+    uint32_t keys[PC_TABLE + 64u];     // tile index >> 4 of the entry, PC_EMPTY; the spare words hold PC_NOBODY
+    // counting, a word per tile: its crossings | << 16 the sum of the backdrop bumps of the tile to its RIGHT (where a crossing
+    // with a top edge puts its bump, path_count.wgsl:181-186: one add does both); after the flush: the tile's slot cursor
+    uint32_t cnt[PC_CNT_WORDS + 64u];
     uint16_t occupied[PC_TABLE];
     uint32_t n_occ;
+    uint32_t stash[4][PC_STASH]; // cursor word index or PC_DONE | slot index; | lane of the line << 16
+    uint32_t wave_total[4];
+    uint32_t base;
 };
+constexpr uint32_t PC_NOBODY = 0xfffffffeu;
 
 struct PcWalk {
     float a, b, x0, y0;
-    uint32_t imin, count;
-    int32_t ymin, ymax;          // rows bumped in column 0 by a line left of the rectangle
+    uint32_t ioff, count;        // crossing index of the line's item q (counted over the wave's 64 lines): ioff + q
     uint32_t base;               // tile index of (x, y) = base + y * stride + x
-    int32_t stride, bbox0, bbox2;
+    uint32_t bbox02;             // bbox0 | bbox2 << 16 (tile coordinates of a target of at most 65 535 tiles, engine.hip)
     uint32_t flags;              // 1: is_down, 2: negative slope, 4: y0 == s0.y
 };
 
-__device__ __forceinline__ PcWalk pc_pack(const LineWalk &w) {
-    PcWalk p;
-    p.a = w.a; p.b = w.b; p.x0 = w.x0; p.y0 = w.y0;
-    p.imin = w.imin;
-    p.count = w.valid ? w.imax - w.imin : 0u;
-    p.ymin = w.valid ? w.ymin : 0; p.ymax = w.valid ? w.ymax : 0;
-    p.base = w.tiles_base - (uint32_t)w.bbox1 * (uint32_t)w.stride - (uint32_t)w.bbox0;
-    p.stride = w.stride; p.bbox0 = w.bbox0; p.bbox2 = w.bbox2;
-    p.flags = (w.is_down ? 1u : 0u) | (w.is_positive_slope ? 0u : 2u) | (w.y0 == w.s0y ? 4u : 0u);
-    return p;
-}
-
-// crossing s of a walk: its tile and the tile its top edge bumps (PC_NONE: none, or outside the pool)
-__device__ __forceinline__ void pc_crossing(const PcWalk &w, uint32_t s, float &last_z, uint32_t tiles_size, uint32_t &key, uint32_t &bkey, uint32_t &i_out) {
-    const uint32_t i = w.imin + s;
-    const float z = floorf(w.a * (float)i + w.b);
-    const int32_t y = f2i(w.y0 + (float)i - z);
-    const int32_t x = f2i(w.x0 + ((w.flags & 2u) ? -1.0f : 1.0f) * z);
-    const uint32_t row = w.base + (uint32_t)y * (uint32_t)w.stride;
-    const bool top_edge = (i == 0u) ? ((w.flags & 4u) != 0u) : (last_z == z);
-    bkey = PC_NONE;
-    if (top_edge && x + 1 < w.bbox2) {
-        const uint32_t t = row + (uint32_t)maxi(x + 1, w.bbox0);
-        if (t < tiles_size) bkey = t;
-    }
-    key = row + (uint32_t)x;
-    last_z = z;
-    i_out = i;
-}
-
 __device__ __forceinline__ uint32_t pc_hash(uint32_t line) { return (line * 0x9E3779B1u) >> (32u - PC_TABLE_LOG2); }
-
-template <bool INSERT>
-__device__ __forceinline__ uint32_t pc_slot(PcTable &t, uint32_t line) {
-    uint32_t s = pc_hash(line);
+// the places a cache line of tiles may take when its first one (pc_hash) is somebody else's; PC_NONE if they all are (the table
+// only grows within a chunk: whoever asks for the same line later gets the same answer)
+__device__ __forceinline__ uint32_t pc_slot_more(PcShared &sh, uint32_t line) {
+    uint32_t h = pc_hash(line);
+    const uint32_t step = (line >> 2) | 1u;
 #pragma unroll 1
-    for (uint32_t p = 0; p < PC_PROBES; p++) {
-        uint32_t k = __atomic_load_n(&t.keys[s], __ATOMIC_RELAXED);
-        if (k == line) return s;
-        if (k == PC_EMPTY) {
-            if (!INSERT) return PC_NONE;
-            k = atomicCAS(&t.keys[s], PC_EMPTY, line);
-            if (k == PC_EMPTY) {
-                t.occupied[atomicAdd(&t.n_occ, 1u)] = (uint16_t)s;
-                return s;
-            }
-            if (k == line) return s;
-        }
-        s = (s + 1u) & (PC_TABLE - 1u);
+    for (uint32_t p = 1; p < PC_PROBES; p++) {
+        h = (h + step) & (PC_TABLE - 1u);
+        const uint32_t o = atomicCAS(&sh.keys[h], PC_EMPTY, line);
+        if (o == PC_EMPTY || o == line) return h;
     }
     return PC_NONE;
 }
 
-// the slot of a tile's cache line, remembering the last answer (a walk stays on a line for several steps)
-template <bool INSERT>
-__device__ __forceinline__ uint32_t pc_slot_of(PcTable &t, uint32_t tile_ix, uint32_t &last_line, uint32_t &last_slot) {
-    const uint32_t line = tile_ix >> 4;
-    if (line != last_line) {
-        last_line = line;
-        last_slot = pc_slot<INSERT>(t, line);
+// The crossings of one line (path_count.wgsl:172-199), a thread per line; its crossing s is item `item0 + s` of the wave.
+// COUNT: the items below PC_STASH, into the table and the stash.  Otherwise: the items from PC_STASH on, straight to memory
+// and to the SegmentCount pool (the wave's records start at `seg_wave`).
+template <bool COUNT>
+__device__ __forceinline__ void pc_walk_line(PcShared &sh, const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, uint32_t lane, uint32_t wave,
+                                             const Config &cfg, Tile *tile, uint32_t seg_wave, uint32_t line_ix,
+                                             SegmentCount *__restrict__ seg_counts) {
+    const int32_t bbox0 = (int32_t)(w.bbox02 & 0xffffu), bbox2 = (int32_t)(w.bbox02 >> 16);
+    const uint32_t stride = (uint32_t)(bbox2 - bbox0);
+    const float x_sign = (w.flags & 2u) ? -1.0f : 1.0f;
+    const int32_t delta = (w.flags & 1u) ? -1 : 1;
+    // the line's first n_stash crossings have places in the stash (COUNT) / the rest
+    const uint32_t s_begin = COUNT ? 0u : n_stash, s_end = COUNT ? n_stash : w.count;
+    // last_z: the z of the crossing before (path_count.wgsl:172-186 carries it through its loop)
+    const uint32_t i_begin = imin + s_begin;
+    float last_z = floorf(w.a * (s_begin == 0u ? (float)imin - 1.0f : (float)(i_begin - 1u)) + w.b);
+    const bool top_edge_0 = (w.flags & 4u) != 0u;
+    for (uint32_t s = s_begin; s < s_end; s++) {
+        const uint32_t i = imin + s;
+        const float z = floorf(w.a * (float)i + w.b);
+        const int32_t y = f2i(w.y0 + (float)i - z);
+        const int32_t x = f2i(w.x0 + x_sign * z);
+        const uint32_t row = w.base + (uint32_t)y * stride;
+        const bool top_edge = i == 0u ? top_edge_0 : last_z == z;  // (not folded into last_z: z is a NaN when a is not finite)
+        last_z = z;
+        const uint32_t key = row + (uint32_t)x;
+        const int32_t x1 = (int32_t)((uint32_t)x + 1u);  // (x saturates at the ends of i32 for coordinates like 3e38: WGSL's i32 wraps)
+        const uint32_t bkey = row + (uint32_t)maxi(x1, bbox0);
+        const bool counted = key < cfg.tiles_size;
+        const bool bump = top_edge && x1 < bbox2 && bkey < cfg.tiles_size;
+        if (COUNT) {
+            // the usual crossing: in the pool, its cache line in the first place the table gives it, its bump (if any) on the tile to
+            // its right -- a compare-and-swap, an add and the stash, no branch
+            const uint32_t line = key >> 4, h = pc_hash(line);
+            const uint32_t o = atomicCAS(&sh.keys[counted ? h : PC_TABLE + lane], PC_EMPTY, line);
+            const bool hit = o == PC_EMPTY || o == line;  // (a lane outside the pool reads PC_NOBODY)
+            const bool bump_right = bump && bkey == key + 1u;
+            const uint32_t at = h * 16u + (key & 15u);
+            const uint32_t one = 1u + (bump_right ? (uint32_t)delta << 16 : 0u);
+            atomicAdd(&sh.cnt[hit ? at : PC_CNT_WORDS + lane], one);
+            uint32_t word = hit ? at : PC_DONE;  // (a crossing outside the pool gets slot 0, as a robust access would give it)
+            // everything else, seldom: another place in the table, or none and straight to memory; a bump that is not on the right
+            const bool rest = (counted && !hit) || (bump && !(hit && bump_right));
+            if (PC_WAVE_ANY(rest)) {
+                if (rest) {
+                    bool bumped = hit && bump_right;
+                    if (counted && !hit) {
+                        const uint32_t slot = pc_slot_more(sh, line);
+                        if (slot != PC_NONE) {
+                            word = slot * 16u + (key & 15u);
+                            atomicAdd(&sh.cnt[word], one);
+                            bumped = bump_right;
+                        } else {
+                            word = PC_DONE | (atomicAdd(&tile[key].segment_count_or_ix, 1u) & 0xffffu);
+                        }
+                    }
+                    if (bump && !bumped) atomicAdd(&tile[bkey].backdrop, delta);
+                }
+            }
+            sh.stash[wave][item0 + s] = word | (lane << 16);
+        } else {
+            uint32_t seg_within_slice = 0u;
+            if (counted) seg_within_slice = atomicAdd(&tile[key].segment_count_or_ix, 1u);
+            if (bump) atomicAdd(&tile[bkey].backdrop, delta);
+            const uint32_t seg_ix = seg_wave + item0 + s;
+            if (seg_ix < cfg.seg_counts_size) {
+                SegmentCount sc;
+                sc.line_ix = line_ix;
+                sc.counts = (seg_within_slice << 16) | i;
+                seg_counts[seg_ix] = sc;
+            }
+        }
     }
-    return last_slot;
 }
 
 template <uint32_t LPT>
 __global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
                                                         const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
-    __shared__ uint32_t sh_scan[4];
-    __shared__ uint32_t sh_base;
-    __shared__ PcTable tb;
-#ifdef VELLO_PC_TIMELINE
-    __shared__ uint32_t sh_direct;  // measurement build: crossings and bumps that found no place in the table
-    if (threadIdx.x == 0u) sh_direct = 0u;
-#endif
-    const uint32_t tid = threadIdx.x;
+    __shared__ PcShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
     const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
     const uint32_t n_paths = cfg.layout.n_paths;
-    for (uint32_t k = tid; k < PC_TABLE; k += 256u) tb.keys[k] = PC_EMPTY;
-    for (uint32_t k = tid; k < PC_TABLE * 16u; k += 256u) (&tb.cnt[0][0])[k] = 0u;
-    if (tid == 0u) tb.n_occ = 0u;
+    for (uint32_t k = tid; k < PC_TABLE + 64u; k += 256u) sh.keys[k] = k < PC_TABLE ? PC_EMPTY : PC_NOBODY;
+    for (uint32_t k = tid; k < PC_CNT_WORDS + 64u; k += 256u) sh.cnt[k] = 0u;
+    if (tid == 0u) sh.n_occ = 0u;
     __syncthreads();
     constexpr uint32_t CHUNK = 256u * LPT;
     for (uint32_t chunk = blockIdx.x * CHUNK; chunk < n_lines; chunk += gridDim.x * CHUNK) {
@@ -486,7 +532,7 @@ __global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, 
         // measurement build (scripts/pc_timeline.py): wall-clock stamps (100 MHz) of the chunk's phases in the tail of the pool
         const uint32_t tl0 = (uint32_t)wall_clock64();
 #endif
-        // ---- pass 1: the walks; the chunk's slice of the SegmentCount pool ----
+        // ---- the walks; the wave's and the chunk's slices of the SegmentCount pool ----
         LineSoup ln[LPT];
         Path pa[LPT];
 #pragma unroll
@@ -494,113 +540,119 @@ __global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, 
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) pa[j] = load_path(paths, ln[j].path_ix < n_paths ? ln[j].path_ix : 0u);  // (the pool holds >= 256 records)
         PcWalk w[LPT];
-        uint32_t my_total = 0u;
+        uint32_t p[LPT], T[LPT], wave_total = 0u;
+        // Places in the stash: item `wave_total + p` onwards while they last.  The sums are u32 like the reference's bump counter
+        // and wrap with lines of billions of crossings (coordinates like 3e38): from the first line of the wave with more
+        // crossings than the stash holds, nobody's item number is trusted for a place (V[j]: the stashed items of line group j).
+        uint32_t n_stash[LPT], V[LPT];
+        bool trusted = true;  // (wave-uniform)
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) {
-            LineWalk lw = {};
-            if (chunk + j * 256u + tid < n_lines) lw = setup_line_walk(ln[j], [&]() { return pa[j]; }, n_paths);
-            w[j] = pc_pack(lw);
-            my_total += w[j].count;
+            LineWalk lw = setup_line_walk(ln[j], [&]() { return pa[j]; }, chunk + j * 256u + tid < n_lines ? n_paths : 0u);
+            w[j].a = lw.a; w[j].b = lw.b; w[j].x0 = lw.x0; w[j].y0 = lw.y0;
+            w[j].count = lw.imax - lw.imin;  // (0 for a line that crosses nothing)
+            w[j].base = lw.tiles_base - (uint32_t)lw.bbox1 * (uint32_t)lw.stride - (uint32_t)lw.bbox0;
+            w[j].bbox02 = ((uint32_t)lw.bbox0 & 0xffffu) | ((uint32_t)lw.bbox2 << 16);
+            w[j].flags = (lw.is_down ? 1u : 0u) | (lw.is_positive_slope ? 0u : 2u) | (lw.y0 == lw.s0y ? 4u : 0u);
+            const uint32_t incl = wave_incl_scan_u32(w[j].count, (int)lane);
+            p[j] = incl - w[j].count;
+            T[j] = wave_read(incl, 63u);
+            w[j].ioff = lw.imin - p[j];
+            {
+                const unsigned long long big = __ballot(w[j].count > PC_STASH);
+                const uint32_t first_big = big ? (uint32_t)__ffsll((long long)big) - 1u : 64u;
+                const uint32_t item0 = wave_total + p[j];
+                const bool mine = trusted && lane <= first_big && item0 < PC_STASH;
+                n_stash[j] = mine ? minu(w[j].count, PC_STASH - item0) : 0u;
+                const uint32_t upto = first_big < 64u ? wave_read(p[j] + n_stash[j], first_big) : T[j];  // (items of the group before the doubt)
+                V[j] = trusted && wave_total < PC_STASH ? minu(upto, PC_STASH - wave_total) : 0u;
+                trusted = trusted && first_big == 64u;
+            }
+            wave_total += T[j];
+            // (a line left of its path's rectangle: a bump in column 0 of every row it spans -- rare, straight to memory)
+            if (PC_WAVE_ANY(lw.ymin < lw.ymax)) {
+                for (int32_t y = lw.ymin; y < lw.ymax; y++) {
+                    const uint32_t t = lw.tiles_base + (uint32_t)(y - lw.bbox1) * (uint32_t)lw.stride;
+                    if (t < cfg.tiles_size) atomicAdd(&tile[t].backdrop, lw.is_down ? -1 : 1);
+                }
+            }
         }
-        uint32_t total;
-        const uint32_t incl = block256_incl_scan_u32(my_total, sh_scan, &total);
+        if (lane == 0u) sh.wave_total[wave] = wave_total;
+        __syncthreads();
+        const uint32_t t0 = sh.wave_total[0], t1 = sh.wave_total[1], t2 = sh.wave_total[2], t3 = sh.wave_total[3];
+        const uint32_t wave_off = (wave > 0u ? t0 : 0u) + (wave > 1u ? t1 : 0u) + (wave > 2u ? t2 : 0u);
+        const uint32_t total = t0 + t1 + t2 + t3;
 #ifdef VELLO_PC_TIMELINE
         const uint32_t tl1 = (uint32_t)wall_clock64();
 #endif
         uint32_t reserved = 0u;
-        if (tid == 0u && total) reserved = atomicAdd(&bump->seg_counts, total);  // (answers while pass A runs)
-        // ---- pass A: count into the table ----
-        uint32_t last_line = PC_NONE, last_slot = PC_NONE;
+        if (tid == 0u && total) reserved = atomicAdd(&bump->seg_counts, total);  // (answers while the counting pass runs)
+        // ---- counting pass ----
+        uint32_t done = 0u;  // items of this wave before line group j (wave-uniform)
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) {
-            const uint32_t dword = (w[j].flags & 1u) ? 0xffff0000u : 0x00010000u;  // -1 or +1 in the high half
-            for (int32_t y = w[j].ymin; y < w[j].ymax; y++) {
-                const uint32_t t = w[j].base + (uint32_t)w[j].bbox0 + (uint32_t)y * (uint32_t)w[j].stride;
-                if (t < cfg.tiles_size) {
-                    const uint32_t slot = pc_slot_of<true>(tb, t, last_line, last_slot);
-                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][t & 15u], dword);
-                }
-            }
-            float last_z = floorf(w[j].a * ((float)w[j].imin - 1.0f) + w[j].b);
-            for (uint32_t s = 0; s < w[j].count; s++) {
-                uint32_t key, bkey, i;
-                pc_crossing(w[j], s, last_z, cfg.tiles_size, key, bkey, i);
-                if (key < cfg.tiles_size) {
-                    const uint32_t slot = pc_slot_of<true>(tb, key, last_line, last_slot);
-                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][key & 15u], 1u);
-                }
-                if (bkey != PC_NONE) {
-                    const uint32_t slot = pc_slot_of<true>(tb, bkey, last_line, last_slot);
-                    if (slot != PC_NONE) atomicAdd(&tb.cnt[slot][bkey & 15u], dword);
-                }
-            }
+            pc_walk_line<true>(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile, 0u, 0u, seg_counts);
+            done += T[j];
         }
-        if (tid == 0u) sh_base = reserved;
+        if (tid == 0u) sh.base = reserved;
         __syncthreads();
 #ifdef VELLO_PC_TIMELINE
         const uint32_t tl2 = (uint32_t)wall_clock64();
 #endif
         // ---- flush: one returning add per touched tile, 16 lanes on the 16 tiles of a cache line ----
-        const uint32_t n_occ = tb.n_occ;
+        for (uint32_t k = tid; k < PC_TABLE; k += 256u)
+            if (sh.keys[k] != PC_EMPTY) sh.occupied[atomicAdd(&sh.n_occ, 1u)] = (uint16_t)k;
+        __syncthreads();
+        const uint32_t n_occ = sh.n_occ;
         for (uint32_t k = tid; k < n_occ * 16u; k += 256u) {
-            const uint32_t e = tb.occupied[k >> 4], t = k & 15u;
-            const uint32_t word = tb.cnt[e][t];
+            const uint32_t e = sh.occupied[k >> 4], t = k & 15u;
+            const uint32_t word = sh.cnt[e * 16u + t];
             const uint32_t n = word & 0xffffu;
             const int32_t d = (int32_t)word >> 16;
-            const uint32_t ix = tb.keys[e] * 16u + t;
-            if (n != 0u) tb.cnt[e][t] = atomicAdd(&tile[ix].segment_count_or_ix, n);
-            if (d != 0) atomicAdd(&tile[ix].backdrop, d);
+            const uint32_t ix = sh.keys[e] * 16u + t;
+            if (n != 0u) sh.cnt[e * 16u + t] = atomicAdd(&tile[ix].segment_count_or_ix, n);
+            if (d != 0) atomicAdd(&tile[ix + 1u].backdrop, d);  // (inside the pool: checked when the bump was added)
         }
         __syncthreads();
 #ifdef VELLO_PC_TIMELINE
         __builtin_amdgcn_s_waitcnt(0);
         const uint32_t tl4 = (uint32_t)wall_clock64();
 #endif
-        // ---- pass B: the records ----
-        uint32_t seg_base = sh_base + (incl - my_total);
-        last_line = PC_NONE; last_slot = PC_NONE;
+        // ---- the records: a crossing per lane out of the stash ----
+        const uint32_t seg_wave = sh.base + wave_off;
+        done = 0u;
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) {
-            const uint32_t line_ix = chunk + j * 256u + tid;
-            const int32_t delta = (w[j].flags & 1u) ? -1 : 1;
-            for (int32_t y = w[j].ymin; y < w[j].ymax; y++) {
-                const uint32_t t = w[j].base + (uint32_t)w[j].bbox0 + (uint32_t)y * (uint32_t)w[j].stride;
-                if (t < cfg.tiles_size && pc_slot_of<false>(tb, t, last_line, last_slot) == PC_NONE) atomicAdd(&tile[t].backdrop, delta);
-            }
-            float last_z = floorf(w[j].a * ((float)w[j].imin - 1.0f) + w[j].b);
-            for (uint32_t s = 0; s < w[j].count; s++) {
-                uint32_t key, bkey, i;
-                pc_crossing(w[j], s, last_z, cfg.tiles_size, key, bkey, i);
-                uint32_t seg_within_slice = 0u;
-                if (key < cfg.tiles_size) {
-                    const uint32_t slot = pc_slot_of<false>(tb, key, last_line, last_slot);
-                    if (slot != PC_NONE) seg_within_slice = atomicAdd(&tb.cnt[slot][key & 15u], 1u);
-                    else {
-                        seg_within_slice = atomicAdd(&tile[key].segment_count_or_ix, 1u);
-#ifdef VELLO_PC_TIMELINE
-                        atomicAdd(&sh_direct, 1u);
-#endif
+            for (uint32_t R = 0; R < V[j]; R += 64u) {
+                const uint32_t q = R + lane;
+                const bool act = q < V[j];
+                const uint32_t word = act ? sh.stash[wave][done + q] : PC_DONE;
+                const uint32_t owner = (word >> 16) & 63u;
+                const uint32_t i = wave_shfl(w[j].ioff, owner) + q;
+                if (act) {
+                    uint32_t seg_within_slice = word & 0xffffu;
+                    if (!(word & PC_DONE)) seg_within_slice = atomicAdd(&sh.cnt[word & 0xffffu], 1u);
+                    const uint32_t seg_ix = seg_wave + done + q;
+                    if (seg_ix < cfg.seg_counts_size) {
+                        SegmentCount sc;
+                        sc.line_ix = chunk + j * 256u + wave * 64u + owner;
+                        sc.counts = (seg_within_slice << 16) | i;
+                        seg_counts[seg_ix] = sc;
                     }
                 }
-                if (bkey != PC_NONE && pc_slot_of<false>(tb, bkey, last_line, last_slot) == PC_NONE) atomicAdd(&tile[bkey].backdrop, delta);
-                const uint32_t seg_ix = seg_base + s;
-                if (seg_ix < cfg.seg_counts_size) {
-                    SegmentCount sc;
-                    sc.line_ix = line_ix;
-                    sc.counts = (seg_within_slice << 16) | i;
-                    seg_counts[seg_ix] = sc;
-                }
             }
-            seg_base += w[j].count;
+            if (PC_WAVE_ANY(n_stash[j] < w[j].count))  // crossings without a place in the stash: straight to memory
+                pc_walk_line<false>(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile, seg_wave, chunk + j * 256u + tid, seg_counts);
+            done += T[j];
         }
         __syncthreads();
 #ifdef VELLO_PC_TIMELINE
         const uint32_t tl5 = (uint32_t)wall_clock64();
 #endif
         // ---- the table back to empty: only what the chunk touched ----
-        for (uint32_t k = tid; k < n_occ * 16u; k += 256u) tb.cnt[tb.occupied[k >> 4]][k & 15u] = 0u;
-        for (uint32_t k = tid; k < n_occ; k += 256u) tb.keys[tb.occupied[k]] = PC_EMPTY;
-        if (tid == 0u) tb.n_occ = 0u;
+        for (uint32_t k = tid; k < n_occ * 16u; k += 256u) sh.cnt[sh.occupied[k >> 4] * 16u + (k & 15u)] = 0u;
+        for (uint32_t k = tid; k < n_occ; k += 256u) sh.keys[sh.occupied[k]] = PC_EMPTY;
+        if (tid == 0u) sh.n_occ = 0u;
         __syncthreads();
 #ifdef VELLO_PC_TIMELINE
         if (tid == 0u) {
@@ -610,8 +662,7 @@ __global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, 
                 dst[0].line_ix = tl0; dst[0].counts = tl1;
                 dst[1].line_ix = tl2; dst[1].counts = (uint32_t)wall_clock64();
                 dst[2].line_ix = tl4; dst[2].counts = tl5;
-                dst[3].line_ix = n_occ; dst[3].counts = sh_direct;
-                sh_direct = 0u;
+                dst[3].line_ix = n_occ; dst[3].counts = 0u;
             }
         }
 #endif
