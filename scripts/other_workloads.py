@@ -4,6 +4,9 @@ import json, os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("VELLO_AB_LIB"):  # same-box A/B: ab_tmp/libvello_hip_<X>.so instead of the in-tree build
+    import vello_amd._lib as _L
+    _L._use_library(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ab_tmp", "libvello_hip_%s.so" % os.environ["VELLO_AB_LIB"]))
 import vello_amd, workloads
 from vello_amd import AaConfig
 

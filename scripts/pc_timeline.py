@@ -1,5 +1,5 @@
 """Where k_path_count's workgroups spend their time (measurement build: PROF_FLAGS=-DVELLO_PC_TIMELINE scripts/build_prof.sh):
-per chunk of 1024 lines the wall-clock stamps of start / pass 1 done / slots reserved / pass 2 done.
+per chunk of 1024 lines the wall-clock stamps of its phases.
     python scripts/pc_timeline.py [d2] [r1mix]"""
 import os, sys
 import numpy as np
@@ -21,31 +21,12 @@ def report(key):
     n_lines = eng.bump()["lines"]
     n_chunks = (n_lines + 1023) // 1024
     raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 4 * 8192) * 2:cap * 2].reshape(-1, 8).astype(np.int64)[:n_chunks]
-    if os.environ.get("PC_OLD") != "1":
-        return report_agg(key, raw, n_chunks)
-    t0, t1, t2, t3 = (raw[:, i] for i in range(4))
-    setup, rows, walk, rounds = (raw[:, i] for i in range(4, 8))
-    base = t0.min()
-    us = lambda t: (t - base) / 100.0
-    print(f"{key}: {n_chunks} chunks; launch span {us(t3).max():.1f} us")
-    for name, a, b in (("pass 1", t0, t1), ("reserve (atomic + barrier)", t1, t2), ("pass 2", t2, t3), ("whole chunk", t0, t3)):
-        d = (b - a) / 100.0
-        print(f"  {name:28s} mean {d.mean():7.2f} us  p50 {np.median(d):7.2f}  p90 {np.percentile(d, 90):7.2f}  max {d.max():7.2f}   sum {d.sum():9.0f}")
-    # inside pass 2, as thread 0 of the workgroup sees its four rounds of 256 lines
-    print(f"  pass 2, thread 0: setup (line + Path loads, walk parameters) mean {setup.mean() / 100:6.2f} us, row loops {rows.mean() / 100:6.2f}, "
-          f"lockstep rounds {walk.mean() / 100:6.2f} us over {rounds.mean():.1f} rounds of four steps ({walk.sum() / max(rounds.sum(), 1) / 100:.2f} us per round)")
-    step = 5.0
-    for a in np.arange(0.0, us(t3).max() + step, step):
-        b = a + step
-        res = np.clip(np.minimum(us(t3), b) - np.maximum(us(t0), a), 0, None).sum() / step
-        p1 = np.clip(np.minimum(us(t1), b) - np.maximum(us(t0), a), 0, None).sum() / step
-        rs = np.clip(np.minimum(us(t2), b) - np.maximum(us(t1), a), 0, None).sum() / step
-        print(f"  {a:6.0f} us: resident chunks {res:6.0f}  (pass 1 {p1:6.0f}, reserving {rs:6.0f}, pass 2 {res - p1 - rs:6.0f}) started {int(((us(t0) >= a) & (us(t0) < b)).sum())}")
+    report_chunks(key, raw, n_chunks)
     del eng
 
 
-def report_agg(key, raw, n_chunks):
-    """k_path_count_agg: start / walks + scan done / counted (pass A) / end, flush answered / records written (pass B), table entries
+def report_chunks(key, raw, n_chunks):
+    """start / walks + scan done / counted (pass A) / end, flush answered / records written (pass B), table entries
     used, crossings that went to memory directly."""
     t0, t1, t2, t3, t4, t5, n_occ, direct = (raw[:, i] for i in range(8))
     base = t0.min()

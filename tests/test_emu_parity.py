@@ -846,9 +846,9 @@ def _stroke_kernel_cases():
 
 
 def path_count_both_forms(eng, name):
-    """path_count sets its lines and Path records aside in LDS between its two passes while the size of the scene's line soup
-    is unknown, and from then on only for soups of more than a million lines (engine.h PATH_COUNT_KEEP_MIN_LINES): the first
-    frame of a small scene runs one form, the frames after a finished one the other -- all against the oracle."""
+    """path_count cuts the line soup into chunks of 1 024 lines while the size of the scene's soup is unknown, and from then on
+    into chunks of 256 when the soup is small (engine.h PATH_COUNT_SMALL_MAX_LINES): the first frame of a small scene runs one
+    form, the frames after a finished one the other -- all against the oracle."""
     from oracle.oracle import Oracle
 
     packed, layout = workloads.mmark_scene(n=1500).resolve()

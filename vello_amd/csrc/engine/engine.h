@@ -20,11 +20,10 @@ constexpr uint32_t FLATTEN_BLOCK_TAGS = 256 * FLATTEN_TAGS_PER_THREAD;
 #endif
 constexpr uint32_t PATH_COUNT_LINES_PER_THREAD = VK_PC_LPT;
 constexpr uint32_t PATH_COUNT_CHUNK = 256 * PATH_COUNT_LINES_PER_THREAD;
-// path_count sets its lines and Path records aside in LDS between its two passes (k_path_count<true>, four workgroups per
-// CU) when the soup has more chunks than the chip holds workgroups of that kind at once -- that is when every load of pass
-// 2 queues behind the tile atomics of a full chip (3 us each on the road map); below, the plain form is as fast or faster
-// (mmark-50k, 788 chunks: 89 us plain, 100 us with the lines kept).  Decided from a finished frame's bump.lines; kept when unknown.
-constexpr int64_t PATH_COUNT_KEEP_MIN_LINES = 1024 * 1024;
+// A soup of fewer lines than this (known from a finished frame of the scene) is cut into chunks of 256 lines instead of 1 024:
+// a chunk is 15-20 us of dependent phases whatever its size, and the tiger's 15 000 lines are 15 workgroups of the large kind
+// on 256 CUs.  (768 workgroups of k_path_count are resident at once.)
+constexpr int64_t PATH_COUNT_SMALL_MAX_LINES = 768 * 256;
 // Spin bound for look-back waits: a predecessor always holds a smaller ticket, so it is resident
 // or finished; the bound only turns a driver-level hang into a reported failure.
 constexpr uint32_t SPIN_LIMIT = 1u << 24;
@@ -155,7 +154,7 @@ struct Frame {
     const uint32_t *atlas;  // RGBA8 image atlas (render.rs:160-203), atlas_w x atlas_h texels
     uint32_t atlas_w, atlas_h;
     uint32_t stroke_kernel_min_lines;  // flatten: stroked lines from which stroke workgroups take them (FLATTEN_STROKE_KERNEL_MIN_LINES; 0 with VELLO_HIP_DEBUG_STROKE_KERNEL)
-    bool path_count_keep;  // path_count: lines and Path records set aside in LDS between its two passes (PATH_COUNT_KEEP_MIN_LINES)
+    bool path_count_small;  // path_count: chunks of 256 lines (PATH_COUNT_SMALL_MAX_LINES)
     bool flatten_side_by_side;  // flatten: stroke workgroups in the heavy list's launch (one frame in flight) instead of a kernel before it
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that stroke workgroups would exit at once
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count

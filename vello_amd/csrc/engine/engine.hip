@@ -46,7 +46,7 @@ struct SceneSlot {
     // stroked-line tags of the scene as k_flatten_light counted them in an earlier frame (-1: not known yet).  A property of
     // the scene alone; lets the host leave out stroke workgroups that would exit at once.
     int64_t stroke_lines = -1;
-    // lines in the soup of a finished frame of this scene (-1 unknown): picks path_count's form (path.hip, k_path_count<KEEP>)
+    // lines in the soup of a finished frame of this scene (-1 unknown): picks path_count's chunk size (path.hip, k_path_count<LPT>)
     int64_t soup_lines = -1;
     int64_t slice_demand = -1;  // slice items coarse asked for in a finished MSAA frame of this scene (max seen), -1 unknown
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
@@ -444,7 +444,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
-    f.path_count_keep = sc.soup_lines < 0 || sc.soup_lines > PATH_COUNT_KEEP_MIN_LINES;
+    f.path_count_small = sc.soup_lines >= 0 && sc.soup_lines < PATH_COUNT_SMALL_MAX_LINES;
     f.flatten_side_by_side = c->n_active == 1u;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
     l.frame_generation = sc.generation;

@@ -7,10 +7,6 @@
 // count the previous stage left in `bump` (the *_setup dispatches disappear).
 #include "engine.h"
 
-#ifndef VK_PC_AGG
-#define VK_PC_AGG 1
-#endif
-
 namespace vk {
 
 namespace {
@@ -150,225 +146,13 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 
 }  // namespace
 
-// One workgroup handles chunks of 256 x 8 lines.  Pass 1 derives every line's crossing count
-// (imax - imin), a shuffle scan + ONE atomicAdd(bump.seg_counts) reserves the chunk's slice, pass 2
-// re-derives the walk (cheap, line and path hit L2) and writes backdrops, per-tile counts and the
-// SegmentCount records.  The reference issues one bump atomic per line (path_count.wgsl:172).
-// KEEP: pass 1 sets the lines and Path records aside in LDS for pass 2 (36 KB: four workgroups per CU instead of six); the
-// host picks the form by the size of the soup (engine.h PATH_COUNT_KEEP_MIN_LINES).
-template <bool KEEP>
-__global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
-                                                    const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
-    __shared__ uint32_t sh_scan[4];
-    __shared__ uint32_t sh_base;
-    // A thread's four lines and their Path records, set aside by pass 1 for pass 2 (each thread reads back what it wrote: no
-    // barrier).  Reloading them cost pass 2 24 of its 57 us per chunk on the road map -- a dependent pair of loads per round
-    // at the 3 us a load takes while every workgroup's tile atomics are in flight (thread 0's stamps, scripts/pc_timeline.py).
-    __shared__ uint32_t sh_keep[9][KEEP ? PATH_COUNT_CHUNK : 1u];
-    const uint32_t tid = threadIdx.x;
-    if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
-    const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
-    for (uint32_t chunk = blockIdx.x * PATH_COUNT_CHUNK; chunk < n_lines; chunk += gridDim.x * PATH_COUNT_CHUNK) {
-#ifdef VELLO_PC_TIMELINE
-        // measurement build (scripts/pc_timeline.py): per chunk, wall-clock stamps (100 MHz) of start / pass 1 done / slots
-        // reserved / pass 2 done in the tail of the SegmentCount pool
-        const uint32_t tl0 = (uint32_t)wall_clock64();
-        uint32_t tl1 = 0u, tl2 = 0u;
-        // ... and inside pass 2, as thread 0 sees them: ticks in the rounds' setup (line + Path loads, the walk's parameters), in
-        // the row loops of lines left of the rectangle, in the lockstep rounds (atomics + records); rounds of four steps walked
-        uint32_t tl_setup = 0u, tl_rows = 0u, tl_walk = 0u, tl_rounds = 0u;
-#endif
-        uint32_t my_total = 0u;
-#pragma unroll 1
-        for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
-            uint32_t line_ix = chunk + j * 256u + tid;
-            if (line_ix < n_lines) {
-                const LineSoup line = load_line(lines, line_ix);
-                const uint32_t at = KEEP ? j * 256u + tid : 0u;
-                if (KEEP) {
-                    // (a line whose path has no record is set aside as a point: no crossings, and no Path asked for, in pass 2 as here)
-                    const bool known = line.path_ix < cfg.layout.n_paths;
-                    sh_keep[1][at] = known ? __float_as_uint(line.p0x) : 0u; sh_keep[2][at] = known ? __float_as_uint(line.p0y) : 0u;
-                    sh_keep[3][at] = known ? __float_as_uint(line.p1x) : 0u; sh_keep[4][at] = known ? __float_as_uint(line.p1y) : 0u;
-                }
-                LineWalk w = setup_line_walk(line, [&]() {
-                    const Path p = load_path(paths, line.path_ix < cfg.layout.n_paths ? line.path_ix : 0u);  // (the pool holds >= 256 records)
-                    if (KEEP) {
-                        sh_keep[5][at] = p.bbox[0]; sh_keep[6][at] = p.bbox[1]; sh_keep[7][at] = p.bbox[2]; sh_keep[8][at] = p.bbox[3];
-                        sh_keep[0][at] = p.tiles;
-                    }
-                    return p;
-                }, cfg.layout.n_paths);
-                my_total += w.imax - w.imin;
-            }
-        }
-        uint32_t total;
-        uint32_t incl = block256_incl_scan_u32(my_total, sh_scan, &total);
-#ifdef VELLO_PC_TIMELINE
-        tl1 = (uint32_t)wall_clock64();
-#endif
-        if (tid == 0u) sh_base = total ? atomicAdd(&bump->seg_counts, total) : 0u;
-        __syncthreads();
-#ifdef VELLO_PC_TIMELINE
-        tl2 = (uint32_t)wall_clock64();
-#endif
-        uint32_t seg_base = sh_base + (incl - my_total);
-        const int lane = (int)(tid & 63u);
-#pragma unroll 1
-        for (uint32_t j = 0; j < PATH_COUNT_LINES_PER_THREAD; j++) {
-            uint32_t line_ix = chunk + j * 256u + tid;
-#ifdef VELLO_PC_TIMELINE
-            const uint32_t tj0 = (uint32_t)wall_clock64();
-#endif
-            LineWalk w = {};
-            if (!KEEP) {
-                if (line_ix < n_lines) {
-                    const LineSoup line = load_line(lines, line_ix);
-                    w = setup_line_walk(line, [&]() { return load_path(paths, line.path_ix < cfg.layout.n_paths ? line.path_ix : 0u); }, cfg.layout.n_paths);
-                }
-            } else if (line_ix < n_lines) {
-                const uint32_t at = j * 256u + tid;
-                LineSoup line;
-                line.path_ix = 0u; line.pad = 0u;  // (checked against n_paths by pass 1)
-                line.p0x = __uint_as_float(sh_keep[1][at]); line.p0y = __uint_as_float(sh_keep[2][at]);
-                line.p1x = __uint_as_float(sh_keep[3][at]); line.p1y = __uint_as_float(sh_keep[4][at]);
-                w = setup_line_walk(line, [&]() {
-                    Path p;
-                    p.bbox[0] = sh_keep[5][at]; p.bbox[1] = sh_keep[6][at]; p.bbox[2] = sh_keep[7][at]; p.bbox[3] = sh_keep[8][at];
-                    p.tiles = sh_keep[0][at];
-                    p.pad[0] = p.pad[1] = p.pad[2] = 0u;
-                    return p;
-                }, 1u);
-            }
-            uint32_t count = w.valid ? w.imax - w.imin : 0u;
-            const int32_t delta = w.is_down ? -1 : 1;
-#ifdef VELLO_PC_TIMELINE
-            count = opaque(count);  // (the stamp waits for the loads the count depends on)
-            const uint32_t tj1 = (uint32_t)wall_clock64();
-            tl_setup += tj1 - tj0;
-#endif
-            // every tile index below is bounded by the buffer explicitly (WebGPU does that for the reference): with
-            // crossing indices past f32's 24 bits the walk can leave the path's tile rectangle
-            if (w.valid) {
-                for (int32_t y = w.ymin; y < w.ymax; y++) {
-                    int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride;
-                    if ((uint32_t)base < cfg.tiles_size) atomicAdd(&tile[base].backdrop, delta);
-                }
-            }
-            float last_z = floorf(w.a * ((float)w.imin - 1.0f) + w.b);
-#ifdef VELLO_PC_TIMELINE
-            const uint32_t tj2 = (uint32_t)wall_clock64();
-            tl_rows += tj2 - tj1;
-#endif
-            // The wave walks crossings in lockstep.  Consecutive lanes hold consecutive lines of the soup, which
-            // (flatten writes in tag order) are consecutive short segments of one path and mostly fall into the
-            // same tile: runs of adjacent lanes hitting the same tile reserve their slots with ONE returning
-            // atomic issued by the run head (the reference does one per crossing, path_count.wgsl:189).
-            uint32_t max_count = count;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) max_count = maxu(max_count, __shfl_xor(max_count, d));
-            // Four crossing steps per round: their four returning atomics are in flight together, the records are
-            // written once all have answered (one atomic round trip per step made long lines -- tiger, mmark --
-            // pay ~1.5 us per crossed tile).
-            for (uint32_t s0 = 0; s0 < max_count; s0 += 4u) {
-                bool k_act[4];
-                uint32_t k_i[4], k_r[4];
-                int k_head[4];
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; k++) {
-                    const uint32_t s = s0 + k;
-                    const bool act = s < count;
-                    uint32_t key = 0xffffffffu, bkey = 0xffffffffu;
-                    uint32_t i = w.imin + s;
-                    if (act) {
-                        float zf = w.a * (float)i + w.b;
-                        float z = floorf(zf);
-                        int32_t y = f2i(w.y0 + (float)i - z);
-                        int32_t x = f2i(w.x0 + w.x_sign * z);
-                        int32_t base = (int32_t)w.tiles_base + (y - w.bbox1) * w.stride - w.bbox0;
-                        bool top_edge = (i == 0u) ? (w.y0 == w.s0y) : (last_z == z);
-                        if (top_edge && x + 1 < w.bbox2) {
-                            int32_t x_bump = maxi(x + 1, w.bbox0);
-                            if ((uint32_t)(base + x_bump) < cfg.tiles_size) bkey = (uint32_t)(base + x_bump);
-                        }
-                        key = (uint32_t)(base + x);
-                        last_z = z;
-                    }
-                    // Backdrop bumps of ADJACENT lanes on the same tile are added up before they touch memory, in pairs
-                    // (even offsets of a run of equal targets absorb their right neighbour).  The two outlines of a stroked
-                    // segment are neighbours in the soup (flatten allocates them together), run a few pixels apart in
-                    // opposite directions and cross a tile row in the same tile: their +1 and -1 cancel and no atomic is
-                    // issued at all.  What a scattered atomic costs is one request per distinct cache line and
-                    // instruction, 2.7e10 per second chip-wide (scripts/calib/atomic_rate.hip) -- that rate, not
-                    // arithmetic or bandwidth, is what bounds this kernel.  Integer adds: any grouping gives the same sum.
-                    if (__ballot(bkey != 0xffffffffu) != 0ull) {
-                        const uint32_t bprev = __shfl_up(bkey, 1), bnext = __shfl_down(bkey, 1);
-                        const int32_t dnext = __shfl_down(delta, 1);
-                        const unsigned long long bheads = __ballot(lane == 0 || bprev != bkey);
-                        const int bhead_lane = 63 - __clzll((long long)(bheads & (~0ull >> (63 - lane))));
-                        if (bkey != 0xffffffffu && (((lane - bhead_lane) & 1) == 0)) {
-                            const int32_t d = delta + ((lane < 63 && bnext == bkey) ? dnext : 0);
-                            if (d != 0) atomicAdd(&tile[bkey].backdrop, d);
-                        }
-                    }
-                    uint32_t prev_key = __shfl_up(key, 1);
-                    bool head = !act || lane == 0 || prev_key != key;
-                    unsigned long long heads = __ballot(head);
-                    unsigned long long le = heads & (~0ull >> (63 - lane));       // heads at lanes <= mine
-                    int head_lane = 63 - __clzll((long long)le);
-                    unsigned long long gt = lane == 63 ? 0ull : (heads & (~0ull << (lane + 1)));  // heads after me
-                    int run_end = gt ? (__ffsll((long long)gt) - 1) : 64;
-                    uint32_t r = 0u;
-                    if (act && head && key < cfg.tiles_size) r = atomicAdd(&tile[key].segment_count_or_ix, (uint32_t)(run_end - lane));
-                    k_act[k] = act;
-                    k_i[k] = i;
-                    k_r[k] = r;
-                    k_head[k] = head_lane;
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; k++) {
-                    uint32_t base_slot = __shfl(k_r[k], k_head[k]);
-                    if (k_act[k]) {
-                        uint32_t seg_within_slice = base_slot + (uint32_t)(lane - k_head[k]);
-                        uint32_t seg_ix = seg_base + s0 + k;
-                        if (seg_ix < cfg.seg_counts_size) {
-                            SegmentCount sc;
-                            sc.line_ix = line_ix;
-                            sc.counts = (seg_within_slice << 16) | k_i[k];
-                            seg_counts[seg_ix] = sc;
-                        }
-                    }
-                }
-            }
-            seg_base += count;
-#ifdef VELLO_PC_TIMELINE
-            seg_base = opaque(seg_base);
-            __builtin_amdgcn_s_waitcnt(0);  // (the round's atomics have answered, its records are on their way)
-            tl_walk += (uint32_t)wall_clock64() - tj2;
-            tl_rounds += (max_count + 3u) / 4u;
-#endif
-        }
-        __syncthreads();  // sh_base / sh_scan reuse in the next chunk
-#ifdef VELLO_PC_TIMELINE
-        if (tid == 0u) {
-            const uint32_t slot = chunk / PATH_COUNT_CHUNK;
-            if (cfg.seg_counts_size > 4u * 8192u && slot < 8192u) {
-                SegmentCount *dst = seg_counts + (cfg.seg_counts_size - 4u * 8192u) + 4u * slot;
-                dst[0].line_ix = tl0; dst[0].counts = tl1;
-                dst[1].line_ix = tl2; dst[1].counts = (uint32_t)wall_clock64();
-                dst[2].line_ix = tl_setup; dst[2].counts = tl_rows;
-                dst[3].line_ix = tl_walk; dst[3].counts = tl_rounds;
-            }
-        }
-#endif
-    }
-}
-
-// ---- k_path_count_agg: the tile atomics of a whole workgroup chunk added up in LDS first -------------------------------
+// ---- k_path_count: path_count.wgsl:51-202, the tile atomics of a whole workgroup chunk added up in LDS first ------------------
 //
+// A workgroup takes chunks of 256 x LPT lines (the reference: a thread per line, an atomicAdd(bump.seg_counts) per line and one
+// on the tile per crossing).  Here: one bump atomic per chunk, and --
 // What a scattered atomic costs is one request per (instruction, distinct cache line), 2.7e10 per second chip-wide, whether
-// the lines come from one XCD or from all (scripts/calib/atomic_rate.hip, atomic_scope.hip); k_path_count above issues 2.0-2.3
-// M of them on the road map (scripts/pc_requests.py) and runs at that rate.  The 1 024 lines of a chunk are consecutive lines
+// the lines come from one XCD or from all (scripts/calib/atomic_rate.hip, atomic_scope.hip); a returning add per run of crossings
+// on one tile (rounds 1-3) was 2.0-2.3 M of them on the road map (scripts/pc_requests.py) and ran at that rate.  The 1 024 lines of a chunk are consecutive lines
 // of a few paths and cross the same tiles over and over: per chunk 1 430 crossings fall into 475 tiles on 207 cache lines of
 // the tile pool.  So the workgroup counts in LDS -- a small hash table keyed by the cache line (16 tiles), a word per tile:
 // crossings in the low half, the sum of the top-edge backdrop bumps in the high half -- and then asks memory ONCE per touched
@@ -515,18 +299,19 @@ __device__ __forceinline__ void pc_walk_line(PcShared &sh, const PcWalk &w, uint
 }
 
 template <uint32_t LPT>
-__global__ void __launch_bounds__(256) k_path_count_agg(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
+__global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
                                                         const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
     __shared__ PcShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
     const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
     const uint32_t n_paths = cfg.layout.n_paths;
+    constexpr uint32_t CHUNK = 256u * LPT;
+    if (blockIdx.x * CHUNK >= n_lines) return;  // (the grid is sized for the pool: most workgroups of a small scene)
     for (uint32_t k = tid; k < PC_TABLE + 64u; k += 256u) sh.keys[k] = k < PC_TABLE ? PC_EMPTY : PC_NOBODY;
     for (uint32_t k = tid; k < PC_CNT_WORDS + 64u; k += 256u) sh.cnt[k] = 0u;
     if (tid == 0u) sh.n_occ = 0u;
     __syncthreads();
-    constexpr uint32_t CHUNK = 256u * LPT;
     for (uint32_t chunk = blockIdx.x * CHUNK; chunk < n_lines; chunk += gridDim.x * CHUNK) {
 #ifdef VELLO_PC_TIMELINE
         // measurement build (scripts/pc_timeline.py): wall-clock stamps (100 MHz) of the chunk's phases in the tail of the pool
@@ -881,13 +666,13 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 
 void launch_path_count(const Frame &f, hipStream_t s) {
     // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
-    uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u * 4u / PATH_COUNT_LINES_PER_THREAD);
-#if VK_PC_AGG
-    hipLaunchKernelGGL(k_path_count_agg<PATH_COUNT_LINES_PER_THREAD>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
-    return;
-#endif
-    if (f.path_count_keep) hipLaunchKernelGGL(k_path_count<true>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
-    else hipLaunchKernelGGL(k_path_count<false>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    if (f.path_count_small) {
+        const uint32_t grid = clamp_grid(f.cfg.lines_size, 256u, 4096u * 4u);
+        hipLaunchKernelGGL(k_path_count<1u>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    } else {
+        const uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u * 4u / PATH_COUNT_LINES_PER_THREAD);
+        hipLaunchKernelGGL(k_path_count<PATH_COUNT_LINES_PER_THREAD>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    }
 }
 
 void launch_backdrop(const Frame &f, hipStream_t s) {
