@@ -481,7 +481,9 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
         const Path path = group_paths[p];
         const uint32_t width = path.bbox[2] - path.bbox[0], height = path.bbox[3] - path.bbox[1];
         if (width <= 1u) continue;  // (a row of one tile is its own prefix)
-        const uint32_t block_rows = maxu(1u, BACKDROP_BLOCK_TILES / width);
+        // (rows per block: any number >= 1 gives the same backdrops, and a scalar division is 35 instructions for each of the
+        // four waves that look at the path -- the largest power of two with block_rows * width <= BACKDROP_BLOCK_TILES instead)
+        const uint32_t block_rows = width >= BACKDROP_BLOCK_TILES ? 1u : BACKDROP_BLOCK_TILES >> (32u - (uint32_t)__builtin_clz(width - 1u));
         for (uint32_t row0 = ((slice - p) & 3u) * block_rows; row0 < height; row0 += 4u * block_rows) {
             const uint32_t first = path.tiles + row0 * width;
             const uint32_t n = minu(block_rows, height - row0) * width;
@@ -499,34 +501,40 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
 #pragma unroll
                 for (uint32_t k = 0; k < G; k++) next[k] = tiles[minu(first + base + k * 64u + lane, last_tile)].backdrop;
             };
+            // one step: 64 tiles from tile i0 of the block on, their backdrops in `loaded`
+            auto step = [&](uint32_t i0, int32_t loaded) {
+                const uint32_t i = i0 + lane;
+                const uint32_t tile_ix = first + i;
+                const bool valid = i < n && tile_ix < cfg.tiles_size;
+                int32_t v = valid ? loaded : 0;
+                // Nothing to add up where nothing was bumped: 64 zero backdrops behind a zero carry are their own prefix
+                // sums.  On a road map that is nearly every step (the two outlines of a stroke cancel within a tile or
+                // two, and path_count never writes the cancelled pairs), and the step is then its load alone -- no column
+                // arithmetic (an integer division), no six shuffle rounds.
+                if (__ballot(v != 0) == 0ull && carry == 0) return;
+                const uint32_t col = i % width;
+                const int32_t own = v;
+#pragma unroll
+                for (uint32_t d = 1; d < 64u; d <<= 1) {
+                    const int32_t up = __shfl_up(v, (int)d);
+                    if (lane >= d && col >= d) v += up;
+                }
+                if (col > lane) v += carry;  // the row began before this step's first lane
+                carry = __shfl(v, 63);
+                if (valid && v != own) tiles[tile_ix].backdrop = v;
+            };
             request(0u);
             for (uint32_t base = 0; base < n; base += 64u * G) {
                 int32_t cur[G];
 #pragma unroll
                 for (uint32_t k = 0; k < G; k++) cur[k] = next[k];
-                request(base + 64u * G);  // (beyond the block: clamped loads nobody reads)
+                // (beyond the block: clamped loads nobody reads -- but not useless: what lies behind a path's tiles are the next path's,
+                // and a small block without this request was 3 us slower over the road map, profiles/r04_ab_s17_backdrop.txt)
+                request(base + 64u * G);
 #pragma unroll
                 for (uint32_t k = 0; k < G; k++) {
-                    const uint32_t i = base + k * 64u + lane;
                     if (base + k * 64u >= n) break;
-                    const uint32_t tile_ix = first + i;
-                    const bool valid = i < n && tile_ix < cfg.tiles_size;
-                    int32_t v = valid ? cur[k] : 0;
-                    // Nothing to add up where nothing was bumped: 64 zero backdrops behind a zero carry are their own prefix
-                    // sums.  On a road map that is nearly every step (the two outlines of a stroke cancel within a tile or
-                    // two, and path_count never writes the cancelled pairs), and the step is then its load alone -- no column
-                    // arithmetic (an integer division), no six shuffle rounds.
-                    if (__ballot(v != 0) == 0ull && carry == 0) continue;
-                    const uint32_t col = i % width;
-                    const int32_t own = v;
-#pragma unroll
-                    for (uint32_t d = 1; d < 64u; d <<= 1) {
-                        const int32_t up = __shfl_up(v, (int)d);
-                        if (lane >= d && col >= d) v += up;
-                    }
-                    if (col > lane) v += carry;  // the row began before this step's first lane
-                    carry = __shfl(v, 63);
-                    if (valid && v != own) tiles[tile_ix].backdrop = v;
+                    step(base + k * 64u, cur[k]);
                 }
             }
         }
