@@ -870,6 +870,35 @@ def test_emu_path_count_both_forms(emu_engine):
     path_count_both_forms(emu_engine, "emu_path_count_forms")
 
 
+def path_count_long_lines(eng, name):
+    """k_path_count's seldom-walked arms with the product's own constants: long lines give a wave far more crossings than its stash
+    holds (768: the rest go straight to memory after the flush) and a chunk far more cache lines of tiles than its table has
+    entries (512: those crossings take the returning global add in the counting pass); fills and strokes, both fill rules, a line
+    that leaves the target on every side.  Everything against the oracle, the back half included."""
+    from vello_amd import Affine, BezPath, Color, Fill, Scene, Stroke
+
+    rng = np.random.default_rng(77)
+    s = Scene()
+    for k in range(40):
+        p = BezPath()
+        p.move_to((float(rng.uniform(-200, 1800)), float(rng.uniform(-200, 1800))))
+        for _ in range(int(rng.integers(3, 9))):
+            p.line_to((float(rng.uniform(-200, 1800)), float(rng.uniform(-200, 1800))))
+        col = Color(float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0, 1)), float(rng.uniform(0.3, 1)))
+        if k % 3 == 0:
+            s.stroke(Stroke(float(rng.uniform(1, 9))), Affine.IDENTITY, col, None, p)
+        else:
+            p.close_path()
+            s.fill(Fill.EvenOdd if k % 2 else Fill.NonZero, Affine.IDENTITY, col, None, p)
+    packed, layout = s.resolve()
+    for aa in (AaConfig.Area, AaConfig.Msaa16):
+        compare_frame(eng, packed, layout, 1600, 1600, BLACK, aa, f"{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+
+
+def test_emu_path_count_long_lines(emu_engine):
+    path_count_long_lines(emu_engine, "emu_pc_long")
+
+
 @pytest.mark.parametrize("case", range(8))
 def test_emu_stroked_line_kernel(emu_engine, case):
     name, packed, layout, w, h = _stroke_kernel_cases()[case]

@@ -683,6 +683,13 @@ def test_gpu_path_count_both_forms(gpu_engine):
 
 
 @pytest.mark.gpu
+def test_gpu_path_count_long_lines(gpu_engine):
+    from tests.test_emu_parity import path_count_long_lines
+
+    path_count_long_lines(gpu_engine, "gpu_pc_long")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", range(8))
 def test_gpu_stroked_line_kernel(gpu_engine, case):
     # flatten's stroked-line kernel (normally from 393 216 stroked lines on: the d2 scene) forced on the stroke catalogue
