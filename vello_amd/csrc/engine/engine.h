@@ -13,7 +13,10 @@ namespace vk {
 constexpr uint32_t SCAN_STATUS_AGG = 1, SCAN_STATUS_PREFIX = 2;
 constexpr uint32_t PATHTAG_PART_WORDS = 1024;  // 256 threads x 4 tag words (= 4096 tags)
 constexpr uint32_t DRAW_PART = 256;            // draw objects per partition
-constexpr uint32_t FLATTEN_TAGS_PER_THREAD = 4;
+#ifndef VK_FLATTEN_TPT
+#define VK_FLATTEN_TPT 4
+#endif
+constexpr uint32_t FLATTEN_TAGS_PER_THREAD = VK_FLATTEN_TPT;
 constexpr uint32_t FLATTEN_BLOCK_TAGS = 256 * FLATTEN_TAGS_PER_THREAD;
 #ifndef VK_PC_LPT
 #define VK_PC_LPT 4

@@ -168,6 +168,12 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 #ifndef VK_PC_TABLE_LOG2
 #define VK_PC_TABLE_LOG2 9
 #endif
+#ifndef VK_PC_GRID
+// the launch: as many workgroups as the chip holds at once (three per CU), striding over the chunks -- a grid sized for the pool's
+// capacity is thousands of workgroups that find no chunk, and each is dispatched with its 48 KB of LDS before it can say so
+// (r1mix one frame at a time +2.6 %, d2 four in flight +0.9 %, profiles/r04_ab_s18_constants.txt)
+#define VK_PC_GRID 768u
+#endif
 #ifndef VK_PC_STASH
 #define VK_PC_STASH 768
 #endif
@@ -673,12 +679,11 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 }
 
 void launch_path_count(const Frame &f, hipStream_t s) {
-    // grid sized for the pool capacity; workgroups beyond bump.lines exit after one load
     if (f.path_count_small) {
-        const uint32_t grid = clamp_grid(f.cfg.lines_size, 256u, 4096u * 4u);
+        const uint32_t grid = clamp_grid(f.cfg.lines_size, 256u, VK_PC_GRID);
         hipLaunchKernelGGL(k_path_count<1u>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
     } else {
-        const uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, 4096u * 4u / PATH_COUNT_LINES_PER_THREAD);
+        const uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, VK_PC_GRID);
         hipLaunchKernelGGL(k_path_count<PATH_COUNT_LINES_PER_THREAD>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
     }
 }
