@@ -82,6 +82,7 @@ struct CoarseLds {
     uint32_t part_off[PART_CHUNK];
     uint32_t wave_cnt[NW];
     uint32_t bcast;
+    uint32_t seg_tot[NW], seg_base[NW], seg_arrive;  // a batch's first-group segment demand per slice, its answer, the waves that have reported
 };
 
 __device__ __forceinline__ uint32_t popc64(u64 x) { return (uint32_t)__popcll(x); }
@@ -227,6 +228,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     const bool has_clips = cfg.layout.n_clips != 0u;
     const bool cull = allow_cull && !has_clips;
     const uint32_t ptcl_dyn_start = cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
+    if (tid == 0u) sh.seg_arrive = 0u;  // (read behind the barriers of the first batch)
 #ifdef VELLO_COARSE_PROF
     // Measurement build only (scripts/coarse_prof.py): shader-clock cycles per phase and workgroup, left in the last
     // 8192 words of the PTCL pool.  0 stream rounds, 1 batch front (transposes, occluders, clips), 2 allocation,
@@ -622,21 +624,54 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             // EMIT: one lane per (tile, object) pair, EMIT_GROUP wave steps at a time: the segment counts of the group's Tile
             // records are scanned once and the wave reserves the
             // group's segment slices with ONE atomic (a slice may sit anywhere: CMD_FILL carries its index)
-            bool bases_ready = false;
+            // The first group's slices of ALL eight waves behind one atomic: bump.segments is one address, an atomic on it is a
+            // queue of every wave of the launch that wants one (12 ns each), and a batch is a burst of them -- 1 400 on the road
+            // map, the last of which waited 16 us.  Every wave leaves its demand in LDS; the one that reports last adds them
+            // up and asks.
             CPROF(2);
-            for (uint32_t g0 = 0; g0 < n_iter; g0 += EMIT_GROUP) {
-                if (g0 != 0u) load_group(g0, info, tix, tl);
+            uint32_t seg_first;
+            {
                 uint32_t my_segs = 0u;
 #pragma unroll
-                for (uint32_t u = 0; u < EMIT_GROUP; u++) my_segs += tl[u].segment_count_or_ix;
+                for (uint32_t u = 0; u < EMIT_GROUP; u++) my_segs += tl[u].segment_count_or_ix;  // (no pairs: zeros)
                 const uint32_t seg_incl = wave_incl_scan_u32(my_segs, (int)lane);
                 const uint32_t seg_total = (uint32_t)__shfl((int)seg_incl, 63);
-                uint32_t seg_next = 0u;
-                if (lane == 0u && seg_total != 0u) seg_next = atomicAdd(&bump->segments, seg_total);
-                seg_next = (uint32_t)__shfl((int)seg_next, 0) + (seg_incl - my_segs);
-                if (!bases_ready) {
-                    __syncthreads();  // (3) wave 0 has published the word bases
-                    bases_ready = true;
+                uint32_t arrived = 0u;
+                if (lane == 0u) {
+                    sh.seg_tot[wave] = seg_total;
+#ifdef VELLO_SIMT_EMU
+                    arrived = atomicAdd(&sh.seg_arrive, 1u);
+#else
+                    // (release: the demand above is in LDS before the count says so; acquire: the last wave reads the others' behind it)
+                    arrived = __hip_atomic_fetch_add(&sh.seg_arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+                }
+                arrived = (uint32_t)__shfl((int)arrived, 0);
+                if (arrived == NW - 1u) {
+                    const uint32_t tot = lane < NW ? sh.seg_tot[lane] : 0u;
+                    const uint32_t incl = wave_incl_scan_u32(tot, (int)lane);
+                    const uint32_t all = (uint32_t)__shfl((int)incl, 63);
+                    uint32_t got = 0u;
+                    if (lane == 0u && all != 0u) got = atomicAdd(&bump->segments, all);
+                    got = (uint32_t)__shfl((int)got, 0);
+                    if (lane < NW) sh.seg_base[lane] = got + (incl - tot);
+                    if (lane == 0u) sh.seg_arrive = 0u;
+                }
+                __syncthreads();  // (3) wave 0 has published the word bases, the last wave the segment bases
+                seg_first = sh.seg_base[wave] + (seg_incl - my_segs);
+            }
+            for (uint32_t g0 = 0; g0 < n_iter; g0 += EMIT_GROUP) {
+                uint32_t seg_next = seg_first;
+                if (g0 != 0u) {  // (more than 512 pairs in a slice: seldom; a reservation of the wave's own)
+                    load_group(g0, info, tix, tl);
+                    uint32_t my_segs = 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < EMIT_GROUP; u++) my_segs += tl[u].segment_count_or_ix;
+                    const uint32_t seg_incl = wave_incl_scan_u32(my_segs, (int)lane);
+                    const uint32_t seg_total = (uint32_t)__shfl((int)seg_incl, 63);
+                    uint32_t got = 0u;
+                    if (lane == 0u && seg_total != 0u) got = atomicAdd(&bump->segments, seg_total);
+                    seg_next = (uint32_t)__shfl((int)got, 0) + (seg_incl - my_segs);
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < EMIT_GROUP; u++) {
@@ -681,7 +716,6 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
                     }
                 }
             }
-            if (!bases_ready) __syncthreads();  // (3) for the waves whose slice emits nothing
             CPROF(3);
             qh = (qh + n) & (QCAP - 1u);
             qlen -= n;

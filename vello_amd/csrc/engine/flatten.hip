@@ -891,9 +891,31 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
         }
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
     }
-    flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
-    if (tid < 3u) sh_heavy_base[tid] = sh_n_heavy[tid] ? atomicAdd(&control->heavy_count[tid], sh_n_heavy[tid]) : 0u;
+    // The workgroup's four reservations -- its lines in the soup, its entries in the three lists -- as ONE instruction of four
+    // lanes: a same-address atomic is a queue of every workgroup of the launch (12 ns each, 933 of them on the road map), and
+    // the soup's after the copy-out, then the lists', were two such queues in a row on every workgroup's way out.
     __syncthreads();
+    const uint32_t n_lds = minu(sh.count, sh.lds_end);
+    if (tid < 4u) {
+        uint32_t *const counter = tid == 0u ? &bump->lines : &control->heavy_count[tid - 1u];
+        const uint32_t n = tid == 0u ? n_lds : sh_n_heavy[tid - 1u];
+        const uint32_t got = n ? atomicAdd(counter, n) : 0u;
+        if (tid == 0u) sh.base = got;
+        else sh_heavy_base[tid - 1u] = got;
+    }
+    __syncthreads();
+    {
+        const uint32_t base = sh.base;
+        for (uint32_t i = tid; i < n_lds; i += 256u) {
+            const uint32_t o = base + i;
+            if (o < cfg.lines_size) {
+                LineSoup l;
+                l.path_ix = sh.path_ix[i]; l.pad = 0u;
+                l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
+                lines[o] = l;
+            }
+        }
+    }
     // curves fill heavy_list[0, n_tags), strokes [n_tags, 2 n_tags), stroked lines [2 n_tags, 3 n_tags) (the stroke workgroups
     // append the lines they hand on to [3 n_tags, 4 n_tags))
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];

@@ -148,22 +148,24 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 
 // ---- k_path_count: path_count.wgsl:51-202, the tile atomics of a whole workgroup chunk added up in LDS first ------------------
 //
-// A workgroup takes chunks of 256 x LPT lines (the reference: a thread per line, an atomicAdd(bump.seg_counts) per line and one
-// on the tile per crossing).  Here: one bump atomic per chunk, and --
-// What a scattered atomic costs is one request per (instruction, distinct cache line), 2.7e10 per second chip-wide, whether
-// the lines come from one XCD or from all (scripts/calib/atomic_rate.hip, atomic_scope.hip); a returning add per run of crossings
-// on one tile (rounds 1-3) was 2.0-2.3 M of them on the road map (scripts/pc_requests.py) and ran at that rate.  The 1 024 lines of a chunk are consecutive lines
-// of a few paths and cross the same tiles over and over: per chunk 1 430 crossings fall into 475 tiles on 207 cache lines of
-// the tile pool.  So the workgroup counts in LDS -- a small hash table keyed by the cache line (16 tiles), a word per tile:
-// crossings in the low half, the sum of the top-edge backdrop bumps in the high half -- and then asks memory ONCE per touched
-// tile, 16 lanes on the 16 tiles of a line: 0.7-0.9 M requests.  The returned old value of a tile becomes the cursor its
-// crossings draw their slot index from (a returning LDS add).  Which crossing of a tile gets which slot is as arbitrary as in
-// the reference (path_count.wgsl:189 is an atomicAdd in dispatch order).  A tile whose cache line finds no place in the table
-// (PC_PROBES slots taken by other lines) goes to memory directly, as every crossing used to.
+// A workgroup takes chunks of 256 x LPT lines; the reference is a thread per line, an atomicAdd(bump.seg_counts) per line and
+// one on the tile per crossing.  Here: one bump atomic per chunk, and the tile atomics of the chunk added up in LDS first.
 //
-// The walks stay in the registers of the threads that set them up (11 words a line).  The counting pass is a thread per
-// line; what a crossing learns there -- the address of its cursor, or the slot index itself when it went to memory directly
-// -- waits in a per-wave stash (PC_STASH crossings; the ones beyond it take the direct route afterwards), so that the
+// What a scattered atomic costs is one request per (instruction, distinct cache line), 2.7e10 per second chip-wide, whether
+// the lines come from one XCD or from all (scripts/calib/atomic_rate.hip, atomic_scope.hip).  A returning add per run of
+// crossings on one tile (rounds 1-3) was 2.0-2.3 M requests on the road map (scripts/pc_requests.py) and ran at that rate.
+// But the 1 024 lines of a chunk are consecutive lines of a few paths and cross the same tiles over and over: per chunk 1 430
+// crossings fall into 475 tiles on 207 cache lines of the tile pool.  So the workgroup counts in LDS -- a small hash table keyed
+// by the cache line (16 tiles), a word per tile: its crossings in the low half; in the high half the top-edge backdrop bumps of
+// the tile to its right, so that a crossing is one add -- and then asks memory ONCE per touched tile, 16 lanes on the 16 tiles
+// of a line: 0.7-0.9 M requests.  The returned old value of a tile becomes the cursor its crossings draw their slot index from
+// (a returning LDS add).  Which crossing of a tile gets which slot is as arbitrary as in the reference (path_count.wgsl:189 is
+// an atomicAdd in dispatch order).  A tile whose cache line finds no place in the table (PC_PROBES places taken by other
+// lines) goes to memory directly, as every crossing used to.
+//
+// The walks stay in the registers of the threads that set them up (9 words a line).  The counting pass is a thread per line;
+// what a crossing learns there -- the address of its cursor, or the slot index itself when it went to memory directly --
+// waits in a per-wave stash (PC_STASH crossings; the ones beyond it take the direct route afterwards), so that the
 // SegmentCount records are written by a pass with a crossing per lane that repeats none of the arithmetic.
 #ifndef VK_PC_TABLE_LOG2
 #define VK_PC_TABLE_LOG2 9
