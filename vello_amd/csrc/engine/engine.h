@@ -101,14 +101,19 @@ static_assert(sizeof(Control) == 512, "Control");
 static_assert(offsetof(Control, slice_items) == offsetof(Control, work_count) + 4u * FINE_WORK_BUCKETS, "Control::slice_items follows work_count");
 static_assert(offsetof(Control, cov_words) == offsetof(Control, slice_items) + 4u, "Control::cov_words follows slice_items");
 constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
-// the stroke workgroups of a scene of at most n_seg_max segments, and the arcs one shard of the arc list can be given
-// (256 per round of each of its workgroups); the list holds FLATTEN_ARC_SHARDS x that many 64-byte items
-inline uint32_t flatten_strokes_grid(uint32_t n_seg_max) {
-    uint32_t g = (n_seg_max + 255u) / 256u;
-    return g > 4096u ? 4096u : (g < 1u ? 1u : g);
+// Stroke workgroups of a scene of at most n_seg_max segments.  Side by side with the heavy list's workgroups (one frame in flight,
+// k_flatten_main): one per round of 256 stroked lines, up to 4 096.  As a launch of their own (frames in flight,
+// k_flatten_strokes): 512 -- the two a CU holds -- striding over the rounds: four frames in flight +1.9 % on the road map; the same
+// grid for k_flatten_main is 2.8 % slower one frame at a time (profiles/r04_ab_s21_strokes_grid.txt).
+inline uint32_t flatten_strokes_grid(uint32_t n_seg_max, bool side_by_side) {
+    const uint32_t cap = side_by_side ? 4096u : 512u;
+    const uint32_t g = (n_seg_max + 255u) / 256u;
+    return g > cap ? cap : (g < 1u ? 1u : g);
 }
-inline uint32_t flatten_arc_shard_cap(uint32_t n_seg_max) {
-    const uint32_t grid = flatten_strokes_grid(n_seg_max);
+// the arcs one shard of the arc list can be given (256 per round of each of its workgroups); the list holds FLATTEN_ARC_SHARDS x
+// that many 64-byte items
+inline uint32_t flatten_arc_shard_cap(uint32_t n_seg_max, bool side_by_side) {
+    const uint32_t grid = flatten_strokes_grid(n_seg_max, side_by_side);
     const uint32_t rounds = ((n_seg_max + 255u) / 256u + grid - 1u) / grid;
     return ((grid + FLATTEN_ARC_SHARDS - 1u) / FLATTEN_ARC_SHARDS) * (rounds < 1u ? 1u : rounds) * 256u;
 }

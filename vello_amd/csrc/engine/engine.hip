@@ -294,7 +294,7 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
         // one arc per stroked segment at most; a segment owns at least one word of path data (the tag stream is padded)
         const size_t n_tags = (size_t)sc.n_tag_words * 4u, n_data = (size_t)L.draw_tag_base - L.path_data_base;
         const uint32_t n_seg_max = (uint32_t)(n_tags < n_data ? n_tags : n_data);
-        if ((r = ensure(c, l.arc_items, (size_t)flatten_arc_shard_cap(n_seg_max) * FLATTEN_ARC_SHARDS * 64u))) return r;
+        if ((r = ensure(c, l.arc_items, (size_t)(flatten_arc_shard_cap(n_seg_max, true) > flatten_arc_shard_cap(n_seg_max, false) ? flatten_arc_shard_cap(n_seg_max, true) : flatten_arc_shard_cap(n_seg_max, false)) * FLATTEN_ARC_SHARDS * 64u))) return r;
     }
     return 0;
 }

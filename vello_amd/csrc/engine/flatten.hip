@@ -1297,8 +1297,8 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
     if (grid_heavy < 4u) grid_heavy = 4u;
     // (stroke workgroups leave at once when the scene has too few stroked lines for workgroups of their own; they are not
     // launched at all once a finished frame of the scene has shown that)
-    const uint32_t grid_strokes = f.launch_stroke_kernel ? flatten_strokes_grid(n_seg_max) : 0u;
-    const uint32_t arc_shard_cap = flatten_arc_shard_cap(n_seg_max);
+    const uint32_t grid_strokes = f.launch_stroke_kernel ? flatten_strokes_grid(n_seg_max, f.flatten_side_by_side) : 0u;
+    const uint32_t arc_shard_cap = flatten_arc_shard_cap(n_seg_max, f.flatten_side_by_side);
     const uint32_t min_lines = f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu;  // (no stroke workgroups: every line is the heavy ones')
     if (f.flatten_side_by_side) {
         hipLaunchKernelGGL(k_flatten_main, dim3(grid_heavy + grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
