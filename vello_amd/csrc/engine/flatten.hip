@@ -1107,24 +1107,49 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
         // (rare: one atomic each is fine.  A list of its own: the heavy workgroups of this launch read the lengths of the
         // other three while this one grows)
         if (hand_on) heavy_list[3u * n_tags + atomicAdd(&control->heavy_count[3], 1u)] = tag_ix;
-        // the round's arcs go to the frame's list behind one atomic
-        __syncthreads();
+        // The round's arcs go to the frame's list and -- when another round would no longer fit the staging area, or there is none --
+        // the staged lines to the soup: the two reservations as ONE instruction of two lanes (they were two round trips in a row;
+        // the soup's counter is one address for every workgroup of the launch: keep staging while another round still fits).
+        __syncthreads();  // (sh.count, arcs.count: every emit of the round is behind this)
         {
             const uint32_t n_arcs = arcs.count;
             const uint32_t shard = block % FLATTEN_ARC_SHARDS;
-            if (tid == 0u && n_arcs != 0u) arcs.base = atomicAdd(&control->arc_count[shard], n_arcs);
+            const bool last_round = base + n_blocks * 256u >= n_lines_q;
+            const bool do_flush = last_round || sh.count + FLATTEN_STROKE_ROUND_LINES > CAP;
+            const uint32_t n_lds = do_flush ? minu(sh.count, sh.lds_end) : 0u;
+            if (tid < 2u) {
+                uint32_t *const counter = tid == 0u ? &control->arc_count[shard] : &bump->lines;
+                const uint32_t n = tid == 0u ? n_arcs : n_lds;
+                const uint32_t got = n ? atomicAdd(counter, n) : 0u;
+                if (tid == 0u) arcs.base = got;
+                else sh.base = got;
+            }
             __syncthreads();
             // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
             if (tid < n_arcs && arcs.base + tid < arc_shard_cap) reinterpret_cast<ArcItem *>(arc_items)[shard * arc_shard_cap + arcs.base + tid] = arcs.item[tid];
+            if (do_flush) {
+                const uint32_t line_base = sh.base;
+                for (uint32_t i = tid; i < n_lds; i += 256u) {
+                    const uint32_t o = line_base + i;
+                    if (o < cfg.lines_size) {
+                        LineSoup l;
+                        l.path_ix = sh.path_ix[i]; l.pad = 0u;
+                        l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
+                        lines[o] = l;
+                    }
+                }
+            }
+            wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
             __syncthreads();
-            if (tid == 0u) arcs.count = 0u;
+            if (tid == 0u) {
+                arcs.count = 0u;
+                if (do_flush) {
+                    sh.count = 0u;
+                    sh.lds_end = 0xffffffffu;
+                }
+            }
+            __syncthreads();  // (the next round appends to both)
         }
-        wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
-        // The soup's bump counter takes one atomic per flush, and the ~3 000 of a road map's rounds, all to one address, are
-        // 33 us of the chip's time whatever else the workgroups do: keep staging while another round still fits (two rounds
-        // per flush, nearly always).  (sh.count: every emit of the round is behind the barriers of the arc block above)
-        const bool last_round = base + n_blocks * 256u >= n_lines_q;
-        if (last_round || sh.count + FLATTEN_STROKE_ROUND_LINES > CAP) flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
     }
 }
 
