@@ -105,8 +105,14 @@ constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
 // k_flatten_main): one per round of 256 stroked lines, up to 4 096.  As a launch of their own (frames in flight,
 // k_flatten_strokes): 512 -- the two a CU holds -- striding over the rounds: four frames in flight +1.9 % on the road map; the same
 // grid for k_flatten_main is 2.8 % slower one frame at a time (profiles/r04_ab_s21_strokes_grid.txt).
+#ifndef VK_STROKES_GRID_SIDE_BY_SIDE
+#define VK_STROKES_GRID_SIDE_BY_SIDE 4096u
+#endif
+#ifndef VK_STROKES_GRID_OWN_LAUNCH
+#define VK_STROKES_GRID_OWN_LAUNCH 512u  // (scripts/emu_variant_check.sh sets both to 2: several rounds per workgroup on the emulator's small scenes)
+#endif
 inline uint32_t flatten_strokes_grid(uint32_t n_seg_max, bool side_by_side) {
-    const uint32_t cap = side_by_side ? 4096u : 512u;
+    const uint32_t cap = side_by_side ? VK_STROKES_GRID_SIDE_BY_SIDE : VK_STROKES_GRID_OWN_LAUNCH;
     const uint32_t g = (n_seg_max + 255u) / 256u;
     return g > cap ? cap : (g < 1u ? 1u : g);
 }
