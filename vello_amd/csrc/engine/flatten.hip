@@ -98,6 +98,21 @@ struct Emitter {
     }
 };
 
+// the workgroup's staged lines to their reserved place in the soup: thread i writes the 24-byte record i
+template <uint32_t CAP>
+__device__ __forceinline__ void copy_staged_lines(const FlattenShared<CAP> &sh, LineSoup *lines, uint32_t lines_size, uint32_t base, uint32_t n_lds,
+                                                  uint32_t tid) {
+    for (uint32_t i = tid; i < n_lds; i += 256u) {
+        const uint32_t o = base + i;
+        if (o < lines_size) {
+            LineSoup l;
+            l.path_ix = sh.path_ix[i]; l.pad = 0u;
+            l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
+            lines[o] = l;
+        }
+    }
+}
+
 // ONE atomicAdd(bump.lines) for the staged lines of the workgroup (the reference issues one per line), then a
 // coalesced copy: thread i writes the 24-byte record i.  Resets the staging area for the next round.
 template <uint32_t CAP>
@@ -106,16 +121,7 @@ __device__ __forceinline__ void flush_staged_lines(FlattenShared<CAP> &sh, Bump 
     const uint32_t n_lds = minu(sh.count, sh.lds_end);
     if (tid == 0u) sh.base = n_lds ? atomicAdd(&bump->lines, n_lds) : 0u;
     __syncthreads();
-    const uint32_t base = sh.base;
-    for (uint32_t i = tid; i < n_lds; i += 256u) {
-        uint32_t o = base + i;
-        if (o < lines_size) {
-            LineSoup l;
-            l.path_ix = sh.path_ix[i]; l.pad = 0u;
-            l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
-            lines[o] = l;
-        }
-    }
+    copy_staged_lines(sh, lines, lines_size, sh.base, n_lds, tid);
     __syncthreads();
     if (tid == 0u) {
         sh.count = 0u;
@@ -904,18 +910,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
         else sh_heavy_base[tid - 1u] = got;
     }
     __syncthreads();
-    {
-        const uint32_t base = sh.base;
-        for (uint32_t i = tid; i < n_lds; i += 256u) {
-            const uint32_t o = base + i;
-            if (o < cfg.lines_size) {
-                LineSoup l;
-                l.path_ix = sh.path_ix[i]; l.pad = 0u;
-                l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
-                lines[o] = l;
-            }
-        }
-    }
+    copy_staged_lines(sh, lines, cfg.lines_size, sh.base, n_lds, tid);
     // curves fill heavy_list[0, n_tags), strokes [n_tags, 2 n_tags), stroked lines [2 n_tags, 3 n_tags) (the stroke workgroups
     // append the lines they hand on to [3 n_tags, 4 n_tags))
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
@@ -1127,18 +1122,7 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
             __syncthreads();
             // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
             if (tid < n_arcs && arcs.base + tid < arc_shard_cap) reinterpret_cast<ArcItem *>(arc_items)[shard * arc_shard_cap + arcs.base + tid] = arcs.item[tid];
-            if (do_flush) {
-                const uint32_t line_base = sh.base;
-                for (uint32_t i = tid; i < n_lds; i += 256u) {
-                    const uint32_t o = line_base + i;
-                    if (o < cfg.lines_size) {
-                        LineSoup l;
-                        l.path_ix = sh.path_ix[i]; l.pad = 0u;
-                        l.p0x = sh.p0x[i]; l.p0y = sh.p0y[i]; l.p1x = sh.p1x[i]; l.p1y = sh.p1y[i];
-                        lines[o] = l;
-                    }
-                }
-            }
+            if (do_flush) copy_staged_lines(sh, lines, cfg.lines_size, sh.base, n_lds, tid);
             wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
             __syncthreads();
             if (tid == 0u) {
