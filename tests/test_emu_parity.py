@@ -132,6 +132,19 @@ def test_emu_smoke_brush_goldens(emu_engine):
         assert np.array_equal(img[:, :, :3], rgb)
 
 
+def test_emu_property_images(emu_engine):
+    # vello_tests/tests/property.rs:107-199 on the kernel sources: Bgra8 bytes and premultiplied Rgba8 bytes come out as the colours
+    # they encode (the oracle is pinned to the same two tests in test_oracle_golden.py)
+    import vello_amd
+    from tests.test_oracle_golden import _premultiplied_distance
+
+    for kind, base, eps in (("bgra", BLACK, 1e-4), ("premultiplied", 0x00000000, 1e-2)):
+        scene, want = workloads.property_image_scene(kind)
+        r = vello_amd.Resolver().resolve(scene)
+        img, _, _ = compare_frame(emu_engine, r.packed, r.layout, 2, 2, base, AaConfig.Area, f"emu_property_{kind}", tol=1, resolved=r)
+        assert (_premultiplied_distance(img, want) <= eps).all(), (kind, img.reshape(-1, 4))
+
+
 def test_emu_auto_grow_reruns_until_the_frame_fits(built):
     # pools start far too small; robust mode grows lines -> seg_counts/segments -> ... round by round
     # (a failed stage hides the demand of the later ones) and the final frame equals the oracle's

@@ -140,6 +140,30 @@ def test_smoke_data_image_roundtrip_golden(built, extend):
     assert np.array_equal(img[:, :, :3], rgb), f"max diff {np.abs(img[:, :, :3].astype(int) - rgb.astype(int)).max()}"
 
 
+def _premultiplied_distance(img, want):
+    """color::PremulColor::difference: the Euclidean distance of the premultiplied components"""
+    got = img.reshape(-1, 4).astype(np.float64) / 255.0
+    got[:, :3] *= got[:, 3:4]
+    return np.sqrt(((got - want) ** 2).sum(axis=1))
+
+
+def test_property_bgra_image(built):
+    # vello_tests/tests/property.rs:107-149: Bgra8 bytes come out as the colours they encode (pixel_format, fine.wgsl:837-851),
+    # each within 1e-4 of RED, BLUE, LIME, WHITE (premultiplied distance); the target is 2 x 2 over the default black.
+    scene, want = workloads.property_image_scene("bgra")
+    img = _render_resolved(scene, 2, 2, 0, base=BLACK)
+    assert (_premultiplied_distance(img, want) <= 1e-4).all(), img.reshape(-1, 4)
+
+
+def test_property_premultiplied_image(built):
+    # property.rs:151-199: premultiplied Rgba8 bytes (alpha 0.5) over a transparent base come out un-premultiplied such that
+    # premultiplying them again is within 1e-2 of what went in (maybe_premul_alpha, fine.wgsl:853-863; the output's
+    # un-premultiplication, fine.wgsl:1386-1397)
+    scene, want = workloads.property_image_scene("premultiplied")
+    img = _render_resolved(scene, 2, 2, 0, base=0x00000000)
+    assert (_premultiplied_distance(img, want) <= 1e-2).all(), img.reshape(-1, 4)
+
+
 def test_oracle_pools_grow_on_overflow():
     """a frame that overflows a pool doubles the oracle's pools and runs again (auto_grow), so scenes beyond
     any fixed pool are still checked by something; without auto_grow the overflow is reported as before."""

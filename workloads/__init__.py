@@ -7,7 +7,7 @@ concrete, seeded, synthetic inputs.  Harness code, not a product feature.
   C4  mmark_scene             port of examples/scenes/src/mmark.rs with a seeded RNG, 50k elements
   C5  8 x C3 with seeds 0x5EED0001..8, one per GPU (bench.py --gpus 8)
 """
-from .scenes import (circle_scene, smoke_circle_scene, smoke_square_scene, smoke_gradient_alpha_scene, smoke_data_image_scene, paris_like_scene, paris_like_scene_d2, mmark_scene,
+from .scenes import (circle_scene, smoke_circle_scene, smoke_square_scene, smoke_gradient_alpha_scene, smoke_data_image_scene, property_image_scene, paris_like_scene, paris_like_scene_d2, mmark_scene,
                      random_test_scene, clip_blend_scene, stroke_styles_scene, brushes_scene, heavy_strokes_scene)
 from .pico_svg import load_svg, tiger_scene
 from .ref_scenes import (tricky_strokes_scene, fill_types_scene, robust_paths_scene, gradient_extend_scene, blend_grid_scene,

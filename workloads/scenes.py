@@ -55,6 +55,30 @@ def smoke_data_image_scene(rgba, extend):
     return s
 
 
+def property_image_scene(kind):
+    """vello_tests/tests/property.rs:107-199: a 2 x 2 image of RED, BLUE, LIME, WHITE drawn at identity with nearest sampling --
+    `bgra_image` (Bgra8 bytes, straight alpha) and `premultiplied_image` (Rgba8, alpha 0.5, premultiplied bytes).  Returns the
+    scene and the four colours as the tests compare them (rgba floats, premultiplied)."""
+    from vello_amd import ImageAlphaType, ImageBrush, ImageData, ImageFormat, ImageQuality
+    rgba = np.array([[255, 0, 0, 255], [0, 0, 255, 255], [0, 255, 0, 255], [255, 255, 255, 255]], dtype=np.float64) / 255.0
+    if kind == "bgra":
+        px = np.round(rgba[:, [2, 1, 0, 3]] * 255.0).astype(np.uint8).reshape(2, 2, 4)
+        image = ImageData(px, ImageFormat.Bgra8, ImageAlphaType.Alpha)
+        want = rgba.copy()
+        want[:, :3] *= want[:, 3:4]
+    else:
+        pm = rgba.copy()
+        pm[:, 3] = 0.5
+        pm[:, :3] *= 0.5  # palette colour .with_alpha(0.5).premultiply()
+        # PremulColor::to_rgba8: round(255 x)
+        px = np.floor(pm * 255.0 + 0.5).astype(np.uint8).reshape(2, 2, 4)
+        image = ImageData(px, ImageFormat.Rgba8, ImageAlphaType.AlphaPremultiplied)
+        want = pm
+    s = Scene()
+    s.draw_image(ImageBrush(image, quality=ImageQuality.Low), Affine.IDENTITY)
+    return s, want
+
+
 def _polyline(pts, closed):
     n = len(pts)
     verbs = np.full(n + (1 if closed else 0), LINE_TO, dtype=np.uint8)
