@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from tests.emu_lib import emu_library_path  # noqa: E402
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -18,7 +20,7 @@ def built():
     import __graft_entry__
 
     libs = [os.path.join(ROOT, "vello_amd", "lib", "libvello_hip.so"), os.path.join(ROOT, "oracle", "libvello_oracle.so"),
-            os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so")]
+            os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"), os.path.join(ROOT, "tests", "device_checks", "libvello_devcheck.so")]
     if not all(os.path.exists(p) for p in libs):
         __graft_entry__.build()
     return True
@@ -30,7 +32,7 @@ def emu_engine(built):
     import vello_amd
     import vello_amd._lib as L
 
-    L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         yield vello_amd.Engine()
     finally:

@@ -31,7 +31,9 @@ def _worker(rank, world, port, n_scenes, result_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import vello_amd._lib as L
 
-    L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
+    from tests.emu_lib import emu_library_path
+
+    L._use_library(emu_library_path())
     import vello_amd
     import workloads
     from vello_amd.distributed import gather_frames, shard_scenes

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import workloads
+from tests.emu_lib import emu_library_path
 from tests.parity import compare_frame
 from vello_amd import AaConfig, Layout
 
@@ -53,7 +54,7 @@ def test_emu_capacity_overflow_leaves_target_untouched(built):
     import vello_amd
     import vello_amd._lib as L
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine(capacities={"lines": 64, "seg_counts": 64, "segments": 64})
         packed, layout = workloads.stroke_styles_scene().resolve()
@@ -71,7 +72,7 @@ def test_emu_frames_in_flight_rotate_lanes(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine()
         packed, layout = workloads.stroke_styles_scene().resolve()
@@ -152,7 +153,7 @@ def test_emu_auto_grow_reruns_until_the_frame_fits(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         tiny = {"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 256, "bin_data": 512, "ptcl": 64 * 256 + 512, "blend_spill": 16}
         eng = vello_amd.Engine(capacities=tiny)
@@ -216,7 +217,7 @@ def test_emu_render_frame_keeps_a_scene_per_lane(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine()
         eng.set_frames_in_flight(3)
@@ -356,7 +357,7 @@ def test_emu_fuzz_auto_grow_from_tiny_pools(built):
     import vello_amd._lib as L
     from workloads.fuzz import fuzz_scene
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         for seed in range(0, 30):
             eng = vello_amd.Engine(capacities={"lines": 64, "binning": 64, "tile": 64, "seg_counts": 64, "segments": 64, "blend": 16,
@@ -602,7 +603,7 @@ def test_emu_auto_grow_covers_large_targets(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine(capacities={"ptcl": 64 * 16 + 512})          # enough for 16 tiles only
         packed, layout = workloads.stroke_styles_scene().resolve()
@@ -625,7 +626,7 @@ def test_emu_auto_grow_with_frames_in_flight(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine(capacities={"lines": 64, "seg_counts": 64, "segments": 64, "tiles": 64})
         eng.set_frames_in_flight(3)
@@ -661,7 +662,7 @@ def test_emu_resident_frames_show_the_uploaded_scene(built):
     import vello_amd._lib as L
     from oracle.oracle import Oracle
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         eng = vello_amd.Engine()
         eng.set_frames_in_flight(2)
@@ -707,7 +708,7 @@ def test_emu_estimator_presizes_the_pools(built):
     from oracle.oracle import Oracle
     from vello_amd.renderer import estimate_capacities
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         tiger = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiger_scene.npz"))
         cases = [workloads.stroke_styles_scene().resolve() + (256, 256), workloads.clip_blend_scene().resolve() + (256, 256),
@@ -741,7 +742,7 @@ def test_emu_gather_frames_between_contexts(built):
     from oracle.oracle import Oracle
     from vello_amd.renderer import gather_frames
 
-    L._use_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt_emu", "libvello_emu.so"))
+    L._use_library(emu_library_path())
     try:
         scenes = [workloads.stroke_styles_scene(), workloads.clip_blend_scene()]
         engines, srcs, refs = [], [], []

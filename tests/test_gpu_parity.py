@@ -862,6 +862,41 @@ def test_fine_slices_repeatable_across_frames_in_flight(built):
         assert np.array_equal(first, t.cpu().numpy())
 
 
+def test_fine_slice_handoff_stress_across_xcds(built):
+    # The slice -> compositor hand-off of k_fine (fine.hip: write-through sc1 stores, s_waitcnt vmcnt(0), a relaxed agent-scope
+    # ticket, agent-scope loads in the winning wave) is outside what the HSA memory model promises and is pinned to gfx950 by a
+    # compile-time guard.  This is the stress half of that bargain: workgroup b of a launch runs on XCD
+    # b mod 8 (profiles/r04_atomic_scope.txt: HW_REG_XCC_ID, 4 096 of 4 096) and the slices of a tile are CONSECUTIVE workgroups
+    # of k_fine's grid, so with every tile cut into slices of 4 fills each tile's slices sit on different XCDs -- different L2s --
+    # by construction.  The road-map scene (thousands of sliced tiles per frame), four frames in flight so that other kernels'
+    # traffic shares the caches, 64 frames: every frame must equal the unsliced image bit for bit.
+    import torch
+    import vello_amd
+
+    packed, layout = workloads.paris_like_scene().resolve()
+    eng = vello_amd.Engine()
+    eng.upload_scene(packed, layout)
+    ref = torch.zeros((1600, 1600, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.render_resident(1600, 1600, WHITE, AaConfig.Msaa16, out=ref)
+    assert eng.sync() == 0
+    ref_np = ref.cpu().numpy()
+    eng.set_debug_flags(fine_slices=True)
+    eng.set_frames_in_flight(4)
+    targets = [torch.zeros((1600, 1600, 4), dtype=torch.uint8, device="cuda:0") for _ in range(8)]
+    torch.cuda.synchronize()
+    for rnd in range(8):
+        for t in targets:
+            eng.render_resident(1600, 1600, WHITE, AaConfig.Msaa16, out=t)
+        assert eng.sync() == 0
+        # (every sliced tile has >= 2 slice items -- a tile is cut only from FINE_SLICE_MIN_FILLS_FORCED = 5 fills on, into slices
+        # of 4 -- so >= 2 XCDs a tile; r1mix: 13 fills a tile on average, thousands of items a frame)
+        assert eng.fine_slice_stats()[0] >= 8000, eng.fine_slice_stats()
+        for i, t in enumerate(targets):
+            assert np.array_equal(ref_np, t.cpu().numpy()), f"round {rnd}, frame {i}: a sliced tile differs from the unsliced image"
+    eng.set_debug_flags()
+
+
 def test_kernel_ms_splits_the_stages_of_several_kernels(built):
     # vello_hip_get_kernel_ms: flatten (light / strokes / heavy) and coarse (prep / coarse) timed kernel by kernel with events
     # between the launches; the parts add up to the stage (they share its first and last event)

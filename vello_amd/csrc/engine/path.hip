@@ -207,6 +207,12 @@ struct PcShared {
     uint32_t base;
 };
 constexpr uint32_t PC_NOBODY = 0xfffffffeu;
+// The packed fields above hold only for these sizes (the constants are -D-overridable for sweeps and for
+// scripts/emu_variant_check.sh; a value beyond them would corrupt slots and backdrops silently instead of failing the build):
+static_assert(PC_CNT_WORDS + 64u <= 65536u, "a stash word keeps the cursor's word index (spare words included) in bits 0-15");
+static_assert(PC_TABLE <= 65536u, "PcShared::occupied is uint16_t");
+static_assert(4u * PC_STASH < 32768u, "a cnt word: crossings in bits 0-15, the SIGNED sum of backdrop bumps above -- both bounded by the chunk's stashed crossings (4 waves x PC_STASH)");
+static_assert(PC_PROBES >= 1u, "an entry is looked for in at least one place");
 
 struct PcWalk {
     float a, b, x0, y0;
