@@ -12,8 +12,10 @@ import bench
 from vello_amd.renderer import Engine
 
 NAMES = ["interpreter", "batch: scan", "batch: segments", "batch: items", "fill: apply", "fill: prefix", "fill: sparse eval",
-         "fill: restore", "fill: even-odd", "fill: unbatched", "blend", "rare commands"]
-SLOTS = 16
+         "fill: restore", "fill: even-odd", "fill: unbatched", "blend", "rare: begin_clip", "rare: end_clip (blend)",
+         "rare: gradients", "rare: image / blur"]
+NP = len(NAMES)  # phases; behind them: fills, batches, crossing records, command words, rare commands
+SLOTS = NP + 5
 
 
 def report(key, width=None, height=None, aa=2):
@@ -21,18 +23,24 @@ def report(key, width=None, height=None, aa=2):
     width, height = width or bench.WIDTH, height or bench.HEIGHT
     eng = Engine(0, 4, wl.caps)
     eng.upload_scene(wl.packed, wl.layout)
+    report_engine(key, eng, width, height, aa)
+    del eng
+
+
+def report_engine(key, eng, width, height, aa=2):
+    """The phase table of the scene `eng` holds (uploaded by the caller: any scene, brushes included)."""
     for _ in range(3):
         eng.render_resident(width, height, bench.BASE_COLOR, aa)
         eng.sync()
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
     cap = eng.capacities()["blend_spill"]
     raw = eng.read_buffer("blend_spill", np.uint32)[cap - n_tiles * SLOTS:cap].reshape(n_tiles, SLOTS).astype(np.float64)
-    cyc, fills, batches, items, words = raw[:, :12], raw[:, 12], raw[:, 13], raw[:, 14], raw[:, 15]
+    cyc, fills, batches, items, words, rare = raw[:, :NP], raw[:, NP], raw[:, NP + 1], raw[:, NP + 2], raw[:, NP + 3], raw[:, NP + 4]
     tot = cyc.sum(axis=1)
     order = np.argsort(tot)
     top = order[-max(1, n_tiles // 256):]  # the slowest 0.4 % of the tiles
     print(f"{key}: {n_tiles} tiles, {fills.sum():.0f} fills in {batches.sum():.0f} batches, {items.sum():.0f} crossing records, "
-          f"{words.sum():.0f} command words")
+          f"{words.sum():.0f} command words, {rare.sum():.0f} rare commands")
     print(f"  cycles per tile: mean {tot.mean():.0f}, max {tot.max():.0f} (= {tot.max() / 2400:.0f} us at 2.4 GHz); per fill: "
           f"{tot.sum() / max(fills.sum(), 1):.0f}; slowest tiles: {fills[top].mean():.0f} fills, {words[top].mean():.0f} words, "
           f"{tot[top].sum() / max(fills[top].sum(), 1):.0f} cycles per fill")
@@ -42,7 +50,8 @@ def report(key, width=None, height=None, aa=2):
               f"{cyc[:, i].sum() / max(fills.sum(), 1):12.0f} {cyc[top, i].sum() / max(fills[top].sum(), 1):10.0f}")
     print(f"  per batch: {fills.sum() / max(batches.sum(), 1):.1f} fills, {items.sum() / max(batches.sum(), 1):.0f} records; "
           f"batch build {cyc[:, 1:4].sum() / max(batches.sum(), 1):.0f} cycles")
-    del eng
+    if rare.sum():
+        print(f"  per rare command: {cyc[:, 11:15].sum() / rare.sum():.0f} cycles ({rare.sum() / n_tiles:.1f} a tile)")
 
 
 if __name__ == "__main__":

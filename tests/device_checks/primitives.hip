@@ -44,30 +44,39 @@ __global__ void __launch_bounds__(64) k_wave(uint32_t seed, unsigned long long *
     __syncthreads();
     const uint32_t row_pos = lane & 15u;
     auto at = [&](uint32_t l) { return sh[l & 63u]; };
-    // row_shr<K> (defined for lanes whose source is in the row), row_shr0<K> (0 elsewhere)
-    if (row_pos >= 1u && vk::row_shr<1>(v) != at(lane - 1u)) atomicAdd(&bad[2], 1ull);
-    if (row_pos >= 2u && vk::row_shr<2>(v) != at(lane - 2u)) atomicAdd(&bad[2], 1ull);
-    if (row_pos >= 3u && vk::row_shr<3>(v) != at(lane - 3u)) atomicAdd(&bad[2], 1ull);
-    if (vk::row_shr0<1>(v) != (row_pos >= 1u ? at(lane - 1u) : 0u)) atomicAdd(&bad[3], 1ull);
-    if (vk::row_shr0<2>(v) != (row_pos >= 2u ? at(lane - 2u) : 0u)) atomicAdd(&bad[3], 1ull);
-    if (vk::row_shr0<3>(v) != (row_pos >= 3u ? at(lane - 3u) : 0u)) atomicAdd(&bad[3], 1ull);
-    if (vk::bcast_byte3(v) != (v >> 24) * 0x1010101u) atomicAdd(&bad[4], 1ull);
-    if (vk::lane_value<0>(v) != at(0u) || vk::lane_value<12>(v) != at(12u) || vk::lane_value<63>(v) != at(63u)) atomicAdd(&bad[5], 1ull);
+    // Every cross-lane primitive is evaluated with ALL 64 lanes active, as the kernels use them (a DPP move or a ds_bpermute
+    // whose source lane is switched off returns the old / a zero value: under `if (row_pos >= K && ...)` the lane at position K
+    // would read a disabled lane); only the comparisons are per lane.
+    const uint32_t s1 = vk::row_shr<1>(v), s2 = vk::row_shr<2>(v), s3 = vk::row_shr<3>(v);
+    const uint32_t z1 = vk::row_shr0<1>(v), z2 = vk::row_shr0<2>(v), z3 = vk::row_shr0<3>(v);
+    const uint32_t lv0 = vk::lane_value<0>(v), lv12 = vk::lane_value<12>(v), lv63 = vk::lane_value<63>(v);
     const uint32_t src = (v >> 7) & 63u;
-    if (vk::wave_shfl(v, src) != at(src)) atomicAdd(&bad[6], 1ull);
+    const uint32_t shf = vk::wave_shfl(v, src);
     const uint32_t usrc = (at(5u) >> 3) & 63u;  // a wave-uniform lane number
-    if (vk::wave_read(v, usrc) != at(usrc)) atomicAdd(&bad[7], 1ull);
+    const uint32_t rd = vk::wave_read(v, usrc);
     const unsigned long long m = __ballot((v & 1u) != 0u);
+    const uint32_t rank = vk::mask_rank_below(m, lane), scan_add = vk::wave_incl_scan_u32(v, (int)lane), scan_max = vk::wave_incl_scan_max_u32(v, (int)lane);
+    // row_shr<K> (defined for lanes whose source is in the row), row_shr0<K> (0 elsewhere)
+    if (row_pos >= 1u && s1 != at(lane - 1u)) atomicAdd(&bad[2], 1ull);
+    if (row_pos >= 2u && s2 != at(lane - 2u)) atomicAdd(&bad[2], 1ull);
+    if (row_pos >= 3u && s3 != at(lane - 3u)) atomicAdd(&bad[2], 1ull);
+    if (z1 != (row_pos >= 1u ? at(lane - 1u) : 0u)) atomicAdd(&bad[3], 1ull);
+    if (z2 != (row_pos >= 2u ? at(lane - 2u) : 0u)) atomicAdd(&bad[3], 1ull);
+    if (z3 != (row_pos >= 3u ? at(lane - 3u) : 0u)) atomicAdd(&bad[3], 1ull);
+    if (vk::bcast_byte3(v) != (v >> 24) * 0x1010101u) atomicAdd(&bad[4], 1ull);
+    if (lv0 != at(0u) || lv12 != at(12u) || lv63 != at(63u)) atomicAdd(&bad[5], 1ull);
+    if (shf != at(src)) atomicAdd(&bad[6], 1ull);
+    if (rd != at(usrc)) atomicAdd(&bad[7], 1ull);
     uint32_t below = 0u;
     for (uint32_t l = 0; l < lane; l++) below += at(l) & 1u;
-    if (vk::mask_rank_below(m, lane) != below) atomicAdd(&bad[8], 1ull);
+    if (rank != below) atomicAdd(&bad[8], 1ull);
     uint32_t sum = 0u, mx = 0u;
     for (uint32_t l = 0; l <= lane; l++) {
         sum += at(l);
         mx = at(l) > mx ? at(l) : mx;
     }
-    if (vk::wave_incl_scan_u32(v, (int)lane) != sum) atomicAdd(&bad[9], 1ull);
-    if (vk::wave_incl_scan_max_u32(v, (int)lane) != mx) atomicAdd(&bad[10], 1ull);
+    if (scan_add != sum) atomicAdd(&bad[9], 1ull);
+    if (scan_max != mx) atomicAdd(&bad[10], 1ull);
 }
 
 }  // namespace

@@ -38,8 +38,12 @@ enum {
     FP_FILL_EVENODD,    // even-odd fills of a batch (dense path)
     FP_FILL_UNBATCHED,  // fill_path_ms
     FP_BLEND,           // CMD_COLOR src-over
-    FP_RARE,            // clip / brush commands
+    FP_RARE,            // rare_command: BEGIN_CLIP (and anything not listed below)
+    FP_RARE_END_CLIP,   // ... END_CLIP: the blend (blend_mix_compose, luminance masks)
+    FP_RARE_GRAD,       // ... LIN / RAD / SWEEP gradients
+    FP_RARE_IMAGE,      // ... IMAGE, BLUR_RECT
     FP_N_FILLS, FP_N_BATCHES, FP_N_ITEMS, FP_N_WORDS,  // counts: fills, batches, crossing records, command words
+    FP_N_RARE,          // count: rare commands
     FP_SLOTS
 };
 #ifdef VELLO_FINE_PROF
@@ -350,9 +354,12 @@ __device__ __forceinline__ uint32_t ms_item_su(const MsSetup &su, uint32_t sub_i
     else mask = (mask_lut[mask_ix / 4u] >> ((mask_ix % 4u) * 8u)) & 0xffu;
     if (sub_ix == 0u && !is_bump) mask &= su.edge_masks & 0xffffu;
     if (last_pixel && (su.flags & SU_END_OK) != 0u) mask &= su.edge_masks >> 16;
-    // pix_ix >= 256 only guards memory: tile-clipped segments never produce it
-    return (pix_ix & 0xffu) | ((mask & FULL) << 8) | (pix_ix < 256u ? REC_PIX_VALID : 0u) | (is_down ? REC_IS_DOWN : 0u) |
-           (is_bump ? REC_IS_BUMP : 0u) | (delta_ok ? REC_DELTA_OK : 0u);
+    // pix_ix >= 256 only guards memory: tile-clipped segments never produce it.  Such a record is all zeros (delta_ok implies a
+    // pixel inside the tile, so nothing of it would be used): a zero record adds zeros wherever it is applied, which is what lets
+    // ms_fill_simple apply records without testing them.
+    const uint32_t rec = (pix_ix & 0xffu) | ((mask & FULL) << 8) | REC_PIX_VALID | (is_down ? REC_IS_DOWN : 0u) | (is_bump ? REC_IS_BUMP : 0u) |
+                         (delta_ok ? REC_DELTA_OK : 0u);
+    return pix_ix < 256u ? rec : 0u;
 }
 
 template <int AA>
@@ -570,10 +577,11 @@ template <int AA>
 __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment *__restrict__ segments,
                                    const uint32_t *__restrict__ mask_lut, uint32_t win, uint32_t win_base, uint32_t cmd_ix,
                                    uint32_t lane_in, uint32_t &after_batch, FineProf &pf, uint32_t &n_fast, uint32_t &after_fast,
-                                   SlotRegs &slots) {
+                                   SlotRegs &slots, uint32_t &simple_mask) {
     const uint32_t lane = opaque(lane_in);  // (the LDS addresses and lane tests below are recomputed per batch, not held)
     n_fast = 0u;
     after_fast = 0u;
+    simple_mask = 0u;
     // The scan of the window for the FILLs of the batch, by all lanes at once (a scalar walk, one readlane per word with
     // its hazard slots, cost 600+ issue slots per batch).  Lane i looks at word i as if a command started there:
     // next[i] = i + its size, stopping at END / JUMP / unknown tags and where a FILL's four words would leave the window.
@@ -691,6 +699,8 @@ __device__ uint32_t ms_build_batch(FineShared &sh, FineBatch &bt, const Segment 
     {
         uint32_t my_begin = wave_shfl(my_end, lane - 1u & 63u);  // (only lanes < 12 matter)
         if (lane == 0u) my_begin = 0u;
+        // the staged fills ms_fill_simple may take: non-zero rule, 1 .. 64 crossing records
+        simple_mask = (uint32_t)__ballot(lane < n_fit && (my_rule_n & 1u) == 0u && my_end - my_begin - 1u < 64u);
         slots.pack = (my_begin & SLOT_IX_MASK) | ((my_end & SLOT_IX_MASK) << SLOT_END_SHIFT) | ((my_rule_n & 1u) << SLOT_EO_SHIFT);
         slots.backdrop = my_backdrop;
         // (unpacked by the slot's lane once, read back with one broadcast load per fill: every lane converting the four
@@ -947,6 +957,89 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
             }
         }
     }
+    const float4 a = *reinterpret_cast<const float4 *>(&sh.px.area[lane * 4u]);
+    area[0] = a.x; area[1] = a.y; area[2] = a.z; area[3] = a.w;
+    pf.mark(FP_FILL_RESTORE);
+}
+
+// ms_fill_from_batch for the fill it is nearly always asked for -- non-zero rule, 1 .. 64 crossing records, the sample counters
+// clean -- as straight-line code (round 5).  The general routine decides even-odd / clean / one round / records prefetched /
+// no records / which lanes hold a record with scalar branches and exec-mask ladders: 70 scalar instructions per fill around
+// ~180 vector ones, and a scalar instruction takes an issue slot like a vector one.  Here a lane without a record
+// holds the ZERO record, which adds zeros to pixel 0's counters and winding word, reads pixel 0's counters, puts the cleared value
+// back where it already is (or where the pixel's own lane puts it in the same instruction) and sends its coverage to a word of
+// its own: the same LDS operations on the same values for every lane that does hold a record, nothing conditional but the
+// address of the last store.  Coverage is bit-identical to ms_fill_from_batch's (tests: every MSAA image against the oracle).
+template <int AA>
+__device__ __forceinline__ void ms_fill_simple(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, const SlotRegs &slots, uint32_t lane,
+                                               float (&area)[4], uint32_t &pre, uint32_t &pre_begin, FineProf &pf) {
+    constexpr bool MSAA16 = AA == 2;
+    constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
+    const uint32_t pack = (uint32_t)__builtin_amdgcn_readlane((int)slots.pack, (int)slot);
+    const int32_t backdrop = __builtin_amdgcn_readlane((int)slots.backdrop, (int)slot);
+    const uint32_t begin = pack & SLOT_IX_MASK, end = (pack >> SLOT_END_SHIFT) & SLOT_IX_MASK;
+    uint32_t rec = pre;
+    if (pre_begin != begin) rec = bt.item[minu(begin + lane, MS_ITEM_CAP - 1u)];  // (wave-uniform: the first fill of a run)
+    pre = bt.item[minu(end + lane, MS_ITEM_CAP - 1u)];  // the next fill's records start where this one's end
+    pre_begin = end;
+    if (begin + lane >= end) rec = 0u;
+    wave_lds_sync();
+    // ---- the records into the counters (ms_apply, non-zero rule, without its tests) ----
+    const uint32_t pix_ix = rec & 0xffu;
+    const bool is_down = (rec & REC_IS_DOWN) != 0u;
+    {
+        const uint32_t delta_pix = pix_ix + 1u;
+        uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
+        if (!(rec & REC_DELTA_OK)) d = 0u;
+        atomicAdd(&sh.winding[(delta_pix >> 2) & 63u], d);  // (& 63: pixel 255 of a record without a delta)
+        const uint32_t bump = (rec & REC_IS_BUMP) != 0u ? 0x1010101u : 0u;
+        uint32_t *word = &sh_samples[(pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2)];
+#pragma unroll
+        for (uint32_t w = 0; w < SWPP; w++) {
+            const uint32_t v = ((((rec >> (8u + 4u * w)) & 0xfu) * 0x204081u) & 0x1010101u) - bump;
+            atomicAdd(&word[w * 64u], is_down ? 0u - v : v);
+        }
+    }
+    wave_lds_sync();
+    pf.mark(FP_FILL_APPLY);
+    // ---- x winding prefix, 0 / 1 coverage of the untouched pixels: as ms_fill_from_batch ----
+    const uint32_t lx = lane & 3u, ly = lane >> 2;
+    uint32_t packed_w = sh.winding[lane];
+    sh.winding[lane] = 0x80808080u;
+    packed_w += (packed_w - 0x808080u) << 8;
+    packed_w += (packed_w - 0x8080u) << 16;
+    const uint32_t prefix_x = bcast_byte3(packed_w) - 0x80808080u;
+    packed_w += row_shr0<1>(lx <= 2u ? prefix_x : 0u);
+    packed_w += row_shr0<2>(lx <= 1u ? prefix_x : 0u);
+    packed_w += row_shr0<3>(lx == 0u ? prefix_x : 0u);
+    const bool zero_possible = (uint32_t)backdrop + 128u < 256u;
+    const uint32_t differs = packed_w ^ sh.px.zero_at[slot][ly];
+    uint32_t nz = (((differs & 0x7f7f7f7fu) + 0x7f7f7f7fu) | differs) & 0x80808080u;
+    if (!zero_possible) nz = 0x80808080u;
+    const uint32_t ones = nz >> 7;
+#pragma unroll
+    for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) area[i] = (float)((ones >> (i * 8u)) & 0xffu);
+    sh.px.pw[lane] = packed_w;
+    *reinterpret_cast<float4 *>(&sh.px.area[lane * 4u]) = make_float4(area[0], area[1], area[2], area[3]);
+    wave_lds_sync();
+    pf.mark(FP_FILL_PREFIX);
+    // ---- a lane per record: its pixel's counters read, put back, evaluated ----
+    {
+        const uint32_t xb = sh.px.pw[pix_ix >> 2] >> ((pix_ix & 3u) << 3);
+        const uint32_t eb = (xb - sh.px.zero_at[slot][pix_ix >> 4] + 0x80u + (uint32_t)backdrop) & 0xffu;
+        const uint32_t e = eb - (uint32_t)backdrop;
+        const uint32_t so = (pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2);
+        const uint32_t s0 = sh_samples[so], s1 = sh_samples[so + 64u];
+        const uint32_t s2 = MSAA16 ? sh_samples[so + 128u] : 0u, s3 = MSAA16 ? sh_samples[so + 192u] : 0u;
+        wave_lds_sync();
+#pragma unroll
+        for (uint32_t w = 0; w < SWPP; w++) sh_samples[so + w * 64u] = 0x80808080u;
+        // (e >= 256: coverage 1, as the pixel's lane has it; a lane without a record: into sh.count, idle while a batch is staged)
+        float *dst = rec != 0u && e < 256u ? &sh.px.area[pix_ix] : reinterpret_cast<float *>(&sh.count[lane]);
+        *dst = ms_pixel_area<AA>(e, s0, s1, s2, s3);
+    }
+    wave_lds_sync();
+    pf.mark(FP_FILL_SPARSE);
     const float4 a = *reinterpret_cast<const float4 *>(&sh.px.area[lane * 4u]);
     area[0] = a.x; area[1] = a.y; area[2] = a.z; area[3] = a.w;
     pf.mark(FP_FILL_RESTORE);
@@ -1708,6 +1801,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
     uint32_t pf_win = 0u, pf_base = 0xffffffffu;  // MSAA: the command window requested ahead for the next batch
     uint32_t fast_left = 0u, fast_after = 0u;     // MSAA: fills left in the batch's regular prefix / where the list goes on behind it
     SlotRegs slots{0u, 0u};                       // MSAA: lane k holds the parameters of the batch's slot k
+    uint32_t simple_mask = 0u;                    // MSAA: bit k: slot k is a fill ms_fill_simple may take
     uint32_t rec_pre = 0u, rec_pre_begin = ~0u;   // MSAA: the records requested ahead for the next fill
     for (;;) {
         ensure(cmd_ix, 4u);
@@ -1755,9 +1849,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     uint32_t after_batch = 0xffffffffu;
                     prof.mark(FP_INTERP);
                     prof.count(FP_N_BATCHES, 1u);
-                    uint32_t n_fast = 0u, after_fast = 0u;
+                    uint32_t n_fast = 0u, after_fast = 0u, simple = 0u;
                     batch_n = (uint32_t)__builtin_amdgcn_readfirstlane(
-                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, n_fast, after_fast, slots));
+                        (int)ms_build_batch<AA>(sh, bt, segments, mask_lut, win, win_base, cmd_ix, lane, after_batch, prof, n_fast, after_fast, slots, simple));
+                    simple_mask = (uint32_t)__builtin_amdgcn_readfirstlane((int)simple);
                     batch_pos = 0u;
                     rec_pre_begin = ~0u;
                     pf_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)after_batch);
@@ -1777,7 +1872,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     const bool fast = fast_left != 0u;
                     for (;;) {
                         prof.count(FP_N_FILLS, 1u);
-                        ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, samples_clean, rec_pre, rec_pre_begin, prof);
+                        if (samples_clean && ((simple_mask >> batch_pos) & 1u) != 0u)
+                            ms_fill_simple<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, rec_pre, rec_pre_begin, prof);
+                        else
+                            ms_fill_from_batch<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, samples_clean, rec_pre, rec_pre_begin, prof);
                         batch_pos += 1u;
                         if (!fast) break;
                         if (mode == MODE_COV) store_cov();
@@ -1867,7 +1965,10 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             }
             clip_depth = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.clip_depth);
             cmd_ix = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.cmd_ix);
-            prof.mark(FP_RARE);
+            prof.mark(tag == CMD_END_CLIP ? FP_RARE_END_CLIP
+                      : tag == CMD_LIN_GRAD || tag == CMD_RAD_GRAD || tag == CMD_SWEEP_GRAD ? FP_RARE_GRAD
+                      : tag == CMD_IMAGE || tag == CMD_BLUR_RECT ? FP_RARE_IMAGE : FP_RARE);
+            prof.count(FP_N_RARE, 1u);
         }
     }
     if (AA != 0 && mode == MODE_COV) {

@@ -25,6 +25,90 @@ constexpr float K1_THRESH = 1e-3f;
 constexpr float DIST_THRESH = 1e-3f;
 constexpr float TANGENT_THRESH = 1e-6f;
 
+// Measurement build only (EXTRA=-DVELLO_FLATTEN_PROF, scripts/flatten_prof.py): where the waves of the heavy / stroke / tail
+// workgroups spend their cycles.  Lanes of a wave walk different curves, so the timers are the WAVE's: whichever lanes are active
+// when the wave passes a mark, its first active lane books the cycles since the wave's previous mark (kept in LDS per wave) to
+// the phase, and counts the passage -- the number of times the wave executed that piece of code (the union of its lanes' loops).
+// Lane-level event counts (iterations, pieces, lines) go beside them: count / (64 x passages) is the lane use.  Without the
+// macro every call is nothing and the product kernels' code is the same with or without these lines.
+enum {
+    FLP_TAG = 0,     // list entry -> tag monoid -> style / transform / points (flatten_tag's head)
+    FLP_SUBDIV,      // flatten_euler: one turn of the subdivision loop up to the accept test (eval_cubic_and_deriv, cubic_from_points_derivs)
+    FLP_PIECE,       // ... an accepted range: es_params_from_angles, the per-side integrals, n, the reservation
+    FLP_EMIT,        // ... the lines of an accepted range (es_seg_eval_with_offset per line)
+    FLP_STRAIGHT,    // ... the straight-segment shortcut
+    FLP_JOIN,        // draw_join / draw_cap up to flatten_arc (tangents, atan2)
+    FLP_ARC_SETUP,   // flatten_arc: acos, sincos, the reservation
+    FLP_ARC_LINES,   // flatten_arc: the rotation loop
+    FLP_BBOX_FLUSH,  // wave_bbox_update + the workgroup's flush
+    FLP_OTHER,
+    FLP_PHASES,
+    FLC_ENTRIES = 0, FLC_ITERS, FLC_PIECES, FLC_EULER_LINES, FLC_ARCS, FLC_ARC_LINES, FLC_COUNTS
+};
+#ifdef VELLO_FLATTEN_PROF
+__device__ unsigned long long g_flatten_prof[2 * FLP_PHASES + FLC_COUNTS + 2];  // cycles, passages per phase; lane-level counts; waves, wave cycles
+struct FlProfLds {
+    unsigned long long prev[4], t0[4];
+    uint32_t cyc[4][FLP_PHASES], pass[4][FLP_PHASES], cnt[4][FLC_COUNTS];
+};
+__device__ __forceinline__ FlProfLds &flp_lds() {
+    __shared__ FlProfLds s;
+    return s;
+}
+__device__ __forceinline__ bool flp_leader() {
+    const unsigned long long ex = __builtin_amdgcn_read_exec();
+    return (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)ex) - 1);
+}
+__device__ __forceinline__ void flp_start() {
+    FlProfLds &s = flp_lds();
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const unsigned long long t = clock64();
+    if (l < FLP_PHASES) { s.cyc[w][l] = 0u; s.pass[w][l] = 0u; }
+    if (l < FLC_COUNTS) s.cnt[w][l] = 0u;
+    if (l == 0u) { s.prev[w] = t; s.t0[w] = t; }
+}
+__device__ __forceinline__ void flp_mark(int k) {
+    const unsigned long long t = clock64();
+    if (flp_leader()) {
+        FlProfLds &s = flp_lds();
+        const uint32_t w = threadIdx.x >> 6;
+        s.cyc[w][k] += (uint32_t)(t - s.prev[w]);
+        s.pass[w][k] += 1u;
+        s.prev[w] = t;
+    }
+}
+__device__ __forceinline__ void flp_count(int k, uint32_t n) { atomicAdd(&flp_lds().cnt[threadIdx.x >> 6][k], n); }
+__device__ __forceinline__ void flp_store() {  // whole wave, converged
+    FlProfLds &s = flp_lds();
+    const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63u;
+    const unsigned long long t = clock64();
+    if (l < FLP_PHASES) {
+        atomicAdd(&g_flatten_prof[l], (unsigned long long)s.cyc[w][l]);
+        atomicAdd(&g_flatten_prof[FLP_PHASES + l], (unsigned long long)s.pass[w][l]);
+    }
+    if (l < FLC_COUNTS) atomicAdd(&g_flatten_prof[2 * FLP_PHASES + l], (unsigned long long)s.cnt[w][l]);
+    if (l == 0u) {
+        atomicAdd(&g_flatten_prof[2 * FLP_PHASES + FLC_COUNTS], 1ull);
+        atomicAdd(&g_flatten_prof[2 * FLP_PHASES + FLC_COUNTS + 1], t - s.t0[w]);
+    }
+}
+#else
+__device__ __forceinline__ void flp_start() {}
+__device__ __forceinline__ void flp_mark(int) {}
+__device__ __forceinline__ void flp_count(int, uint32_t) {}
+__device__ __forceinline__ void flp_store() {}
+#endif
+
+
+// (out of line ON PURPOSE, round 5: inlined, the fp64 polynomial constants of every copy of these routines are hoisted to the top
+// of the kernel as loop invariants -- hundreds of live registers, spilled to scratch and reloaded at every use)
+struct SinCos { float s, c; };
+__device__ __attribute__((noinline)) SinCos fl_sincos_call(float x) { SinCos r; sincos_cr(x, r.s, r.c); return r; }
+__device__ __forceinline__ void fl_sincos(float x, float &s, float &c) { const SinCos r = fl_sincos_call(x); s = r.s; c = r.c; }
+__device__ __forceinline__ float fl_sin(float x) { return fl_sincos_call(x).s; }
+__device__ __attribute__((noinline)) float fl_atan2(float y, float x) { return atan2_cr(y, x); }
+__device__ __attribute__((noinline)) float fl_asin(float x) { return asin_cr(x); }
+__device__ __attribute__((noinline)) float fl_acos(float x) { return acos_cr(x); }
 struct CubicParams { float th0, th1, chord_len, err; };
 struct EulerParams { float th0, k0, k1, ch; };
 struct CubicPoints { vec2 p0, p1, p2, p3; };
@@ -96,6 +180,33 @@ struct Emitter {
     __device__ __forceinline__ void write_xf(uint32_t ix, uint32_t path_ix, vec2 p0, vec2 p1, const Xform &t) {
         write(ix, path_ix, xf_apply(t, p0), xf_apply(t, p1));
     }
+    // The cooperative flattener (flatten_euler_coop) writes a line's two ends from different lanes: ONE end of line `ix`
+    // (which = 0: p0, 1: p1) and, once per line, its path index.  No box here: the owner lane's box is kept in LDS there.
+    __device__ __forceinline__ void write_end(uint32_t ix, uint32_t which, vec2 p) {
+        if (ix & LINE_IX_GLOBAL) {
+            ix &= ~LINE_IX_GLOBAL;
+            if (ix < lines_size) {
+                float *d = which ? &lines[ix].p1x : &lines[ix].p0x;
+                d[0] = p.x;
+                d[1] = p.y;
+            }
+        } else if (which) {
+            s_p1x[ix] = p.x; s_p1y[ix] = p.y;
+        } else {
+            s_p0x[ix] = p.x; s_p0y[ix] = p.y;
+        }
+    }
+    __device__ __forceinline__ void write_path(uint32_t ix, uint32_t path_ix) {
+        if (ix & LINE_IX_GLOBAL) {
+            ix &= ~LINE_IX_GLOBAL;
+            if (ix < lines_size) {
+                lines[ix].path_ix = path_ix;
+                lines[ix].pad = 0u;
+            }
+        } else {
+            s_path_ix[ix] = path_ix;
+        }
+    }
 };
 
 // the workgroup's staged lines to their reserved place in the soup: thread i writes the 24-byte record i
@@ -158,14 +269,14 @@ __device__ CubicParams cubic_from_points_derivs(vec2 p0, vec2 p1, vec2 q0, vec2 
     }
     float scale = dt / chord_squared;
     vec2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
-    float th0 = atan2_cr(h0.y, h0.x);
+    float th0 = fl_atan2(h0.y, h0.x);
     float d0 = length(h0) * scale;
     vec2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
-    float th1 = atan2_cr(h1.y, h1.x);
+    float th1 = fl_atan2(h1.y, h1.x);
     float d1 = length(h1) * scale;
     float cth0, cth1, s0, s1;
-    sincos_cr(th0, s0, cth0);
-    sincos_cr(th1, s1, cth1);
+    fl_sincos(th0, s0, cth0);
+    fl_sincos(th1, s1, cth1);
     float err = 2.0f;
     if (cth0 * cth1 >= 0.0f) {
         float e0 = (2.0f / 3.0f) / maxf(1.0f + cth0, 1e-9f);
@@ -257,13 +368,13 @@ __device__ vec2 es_seg_eval_with_offset(vec2 p0, vec2 p1, const EulerParams &p, 
     vec2 uv = integ_euler_10((k0 + k1 * (0.5f * t - 0.5f)) * t, k1 * t * t);
     float scale = t / p.ch;
     float sin_thm, cos_thm, sin_th, cos_th;
-    sincos_cr(thm, sin_thm, cos_thm);
+    fl_sincos(thm, sin_thm, cos_thm);
     float s = scale * sin_thm;
     float cs = scale * cos_thm;
     float ex = uv.x * cs - uv.y * s;
     float ey = -uv.y * cs - uv.x * s;
     float th = es_params_eval_th(p, t);
-    sincos_cr(th, sin_th, cos_th);
+    fl_sincos(th, sin_th, cos_th);
     vec2 xy = v2(ex + normalized_offset * sin_th, ey + normalized_offset * cos_th);
     vec2 chord = p1 - p0;
     return v2(p0.x + (chord.x * xy.x - chord.y * xy.y), p0.y + (chord.x * xy.y + chord.y * xy.x));
@@ -286,7 +397,7 @@ __device__ float espc_int_approx(float x) {
     float y = fabsf(x);
     float a;
     if (y < BREAK1) {
-        a = sin_cr(SIN_SCALE * y) * (1.0f / SIN_SCALE);
+        a = fl_sin(SIN_SCALE * y) * (1.0f / SIN_SCALE);
     } else if (y < BREAK2) {
         a = SQRT8_OVER_3 * pow_1_5_signed(y - 1.0f) + FRAC_PI_4;
     } else {
@@ -303,7 +414,7 @@ __device__ float espc_int_inv_approx(float x) {
     float y = fabsf(x);
     float a;
     if (y < 0.7010707591262915f) {
-        a = asin_cr(y * SIN_SCALE) * (1.0f / SIN_SCALE);
+        a = fl_asin(y * SIN_SCALE) * (1.0f / SIN_SCALE);
     } else if (y < 0.903249293595206f) {
         float b = y - FRAC_PI_4;
         float u = pow_cr(fabsf(b), 2.0f / 3.0f) * signf(b);
@@ -398,6 +509,7 @@ __device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t pa
                     em.write_xf(line_ix + (uint32_t)side, path_ix, l0, l1, transform);
                 }
             }
+            flp_mark(FLP_STRAIGHT);
             return;
         }
     }
@@ -425,6 +537,8 @@ __device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t pa
         }
         float actual_dt = t1 - last_t;
         CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
+        flp_mark(FLP_SUBDIV);
+        flp_count(FLC_ITERS, 1u);
         if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
             EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
             float k0 = ep.k0 - 0.5f * ep.k1;
@@ -462,6 +576,9 @@ __device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t pa
                 float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
                 uint32_t n_u = f2u(n);
                 uint32_t line_ix = em.alloc(n_u);
+                flp_mark(FLP_PIECE);
+                flp_count(FLC_PIECES, 1u);
+                flp_count(FLC_EULER_LINES, n_u);
                 {
                     vec2 lp = lp0[side];
                     for (uint32_t i = 0; i < n_u; i++) {
@@ -484,6 +601,7 @@ __device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t pa
                         vec2 l1 = off >= 0.0f ? lp1 : lp;
                         em.write_xf(line_ix + i, path_ix, l0, l1, transform);
                         lp = lp1;
+                        flp_mark(FLP_EMIT);
                     }
                     lp0[side] = lp;
                 }
@@ -502,6 +620,321 @@ __device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t pa
     }
 }
 
+// ---- the wave-cooperative form of flatten_euler (round 5) ------------------------------------------------------------------
+// flatten_euler above is one lane walking one curve: the subdivision loop and, per accepted range and side, a loop over the
+// range's lines with two fp64 sincos and an inverse integral per line.  Lanes of a wave hold DIFFERENT curves, so the wave runs
+// the union of all those loops: on mmark-50k the line loop was 45 % of the heavy waves' cycles at 10 % lane use, on the tiger
+// (a wave per curve) the launch was as long as its longest curve's serial chain (profiles/r05_flatten_prof_start.txt).
+// A line of an accepted range depends only on the range's parameters and its number i (flatten.wgsl:447-470): here the lanes
+// walk their subdivisions in lockstep, one turn per pass of the loop, and after every turn ALL 64 lanes flatten the lines of the
+// ranges accepted in that turn -- a POINT per lane (point i + 1 of a range is the end of line i and the start of line i + 1),
+// the range's parameters read out of the owning lane's registers (ds_bpermute).  Same operations on the same values per point as
+// flatten_euler, so the lines are bit-identical; what changes is who computes them and the order they land in the (unordered) soup.
+// The owner's box (flatten.wgsl:766-773) is kept in LDS as order-preserving integers (min / max commute); the end point of a
+// side's newest range comes back to the owner through LDS (it is the next range's first point).
+// Lanes whose inputs are not finite or absurdly large walk flatten_euler instead: NaNs make min / max depend on the order of the
+// operands, and the extreme-coordinate tests hold the boxes to the oracle's bit for bit.
+constexpr uint32_t EC_PIECES = 32u;  // ranges flattened per pass (a turn in which more lanes accept one takes two passes)
+struct EulerPiece {  // what the lines of an accepted range are made of (both sides), written by its owner, read by every lane
+    float p0x, p0y, p1x, p1y;        // the range's end points on the cubic (this_p0, this_p1)
+    float th0, k0, k1, ch;           // EulerParams
+    float noff;                      // offset / chord length of side 0 (side 1: its negative)
+    float a[2], b[2], integral[2], int0[2], n[2];
+    uint32_t line[2], nu[2];         // first line index, number of lines
+    uint32_t flags;                  // robust of side 0 | side 1 << 2 | is_last << 4 | (offset >= 0) << 5 | (-offset >= 0) << 6 | owner lane << 8
+    uint32_t first;                  // number of the range's first point among the pass's points
+};
+struct EulerCoopLds {
+    uint32_t bbox[64][4];     // per owner lane: min x, min y, max x, max y of every point written for it (f32_ordered)
+    float endpt[64][2][2];    // per owner lane and side: the last point of the newest range (local coordinates)
+    EulerPiece piece[EC_PIECES];
+};
+__device__ __forceinline__ uint32_t f32_ordered(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float f32_from_ordered(uint32_t e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+__device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __uint_as_float(wave_shfl(__float_as_uint(v), src)); }
+#ifdef VELLO_SIMT_EMU
+#define FL_WAVE_ANY(c) (__ballot(c) != 0ull)
+#else
+#define FL_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#endif
+
+// Called by ALL 64 lanes of a wave (valid = this lane has a curve).  Arguments as flatten_euler's.
+__device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
+                                   float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n, uint32_t lane) {
+    vec2 p0 = v2(0.0f, 0.0f), p1 = p0, p2 = p0, p3 = p0;
+    float scale = 1.0f;
+    Xform transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    vec2 t_start[2] = {start_p, start_n}, t_end[2] = {end_p, end_n};
+    bool active = valid;
+    if (valid) {
+        if (offset == 0.0f) {
+            p0 = xf_apply(local_to_device, cubic.p0);
+            p1 = xf_apply(local_to_device, cubic.p1);
+            p2 = xf_apply(local_to_device, cubic.p2);
+            p3 = xf_apply(local_to_device, cubic.p3);
+            t_start[0] = p0;
+            t_end[0] = p3;
+        } else {
+            p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
+            transform = local_to_device;
+            scale = 0.5f * (length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
+                            length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
+        }
+        // (NaN fails every comparison: it is "not tame" too)
+        const float LIM = 1.0e15f;
+        const bool tame = fabsf(p0.x) <= LIM && fabsf(p0.y) <= LIM && fabsf(p1.x) <= LIM && fabsf(p1.y) <= LIM && fabsf(p2.x) <= LIM &&
+                          fabsf(p2.y) <= LIM && fabsf(p3.x) <= LIM && fabsf(p3.y) <= LIM && fabsf(offset) <= LIM && fabsf(transform.m0) <= LIM &&
+                          fabsf(transform.m1) <= LIM && fabsf(transform.m2) <= LIM && fabsf(transform.m3) <= LIM && fabsf(transform.t0) <= LIM &&
+                          fabsf(transform.t1) <= LIM && fabsf(t_start[0].x) <= LIM && fabsf(t_start[0].y) <= LIM && fabsf(t_end[0].x) <= LIM &&
+                          fabsf(t_end[0].y) <= LIM && fabsf(t_start[1].x) <= LIM && fabsf(t_start[1].y) <= LIM && fabsf(t_end[1].x) <= LIM &&
+                          fabsf(t_end[1].y) <= LIM;
+        if (!tame) {
+            flatten_euler(em, cubic, path_ix, local_to_device, offset, start_p, end_p, two_sided, start_n, end_n);
+            active = false;
+        } else if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) {
+            active = false;
+        } else if (cubic_is_straight(p0, p1, p2, p3, scale, offset)) {
+            // the straight-segment shortcut, as flatten_euler takes it
+            const uint32_t n_sides_u = two_sided ? 2u : 1u;
+            const uint32_t line_ix = em.alloc(n_sides_u);
+            for (uint32_t side = 0; side < n_sides_u; side++) {
+                const float off = side ? -offset : offset;
+                vec2 l0 = off >= 0.0f ? t_start[side] : t_end[side];
+                vec2 l1 = off >= 0.0f ? t_end[side] : t_start[side];
+                em.write_xf(line_ix + side, path_ix, l0, l1, transform);
+            }
+            flp_mark(FLP_STRAIGHT);
+            active = false;
+        }
+    }
+    if (!FL_WAVE_ANY(active)) return;
+    const float tol = 0.25f;
+    // the owner's box of the points other lanes write for it
+    wave_lds_sync();
+    cl.bbox[lane][0] = f32_ordered(1e31f); cl.bbox[lane][1] = f32_ordered(1e31f);
+    cl.bbox[lane][2] = f32_ordered(-1e31f); cl.bbox[lane][3] = f32_ordered(-1e31f);
+    wave_lds_sync();
+    const bool walked = active;
+    uint32_t t0_u = 0u;
+    float dt = 1.0f;
+    vec2 last_p = p0;
+    vec2 last_q = p1 - p0;
+    if (active && dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
+    float last_t = 0.0f;
+    vec2 lp0[2] = {t_start[0], t_start[1]};
+    const uint32_t off_fwd = (offset >= 0.0f ? 1u : 0u) | ((-offset) >= 0.0f ? 2u : 0u);  // `off >= 0` of side 0 / side 1
+    while (FL_WAVE_ANY(active)) {
+        // ---- one turn of every active lane's walk (flatten.wgsl:395-446) ----
+        bool push = false, is_last = false;
+        vec2 this_p0 = v2(0.0f, 0.0f), this_p1 = this_p0;
+        EulerParams ep{0.0f, 0.0f, 0.0f, 1.0f};
+        float noff = 0.0f;
+        float s_a[2] = {0.0f, 0.0f}, s_b[2] = {0.0f, 0.0f}, s_integral[2] = {0.0f, 0.0f}, s_int0[2] = {0.0f, 0.0f}, s_n[2] = {1.0f, 1.0f};
+        uint32_t s_robust[2] = {0u, 0u}, s_nu[2] = {0u, 0u}, s_line[2] = {0u, 0u};
+        if (active) {
+            const float t0 = (float)t0_u * dt;
+            if (t0 == 1.0f) {
+                active = false;
+            } else {
+                float t1 = t0 + dt;
+                PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+                if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+                    PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+                    this_pq1.deriv = new_pq1.deriv;
+                    if (t1 < 1.0f) {
+                        this_pq1.point = new_pq1.point;
+                        t1 = t1 - DERIV_EPS;
+                    }
+                }
+                const float actual_dt = t1 - last_t;
+                const CubicParams cp = cubic_from_points_derivs(last_p, this_pq1.point, last_q, this_pq1.deriv, actual_dt);
+                flp_mark(FLP_SUBDIV);
+                flp_count(FLC_ITERS, 1u);
+                if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
+                    ep = es_params_from_angles(cp.th0, cp.th1);
+                    const float k0 = ep.k0 - 0.5f * ep.k1;
+                    const float k1 = ep.k1;
+                    const float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
+                    noff = offset / cp.chord_len;
+#pragma unroll
+                    for (int side = 0; side < 2; side++) {
+                        if (side == 1 && !two_sided) break;
+                        const float off = side ? -offset : offset;
+                        const float normalized_offset = off / cp.chord_len;
+                        const float dist_scaled = normalized_offset * ep.ch;
+                        float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+                        uint32_t robust = ESPC_ROBUST_NORMAL;
+                        if (fabsf(k1) < K1_THRESH) {
+                            const float k = ep.k0;
+                            n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
+                            robust = ESPC_ROBUST_LOW_K1;
+                        } else if (fabsf(dist_scaled) < DIST_THRESH) {
+                            a = k1;
+                            b = k0;
+                            int0 = pow_1_5_signed(b);
+                            const float int1 = pow_1_5_signed(a + b);
+                            integral = int1 - int0;
+                            n_frac = (2.0f / 3.0f) * integral / a;
+                            robust = ESPC_ROBUST_LOW_DIST;
+                        } else {
+                            a = -2.0f * dist_scaled * k1;
+                            b = -1.0f - 2.0f * dist_scaled * k0;
+                            int0 = espc_int_approx(b);
+                            const float int1 = espc_int_approx(a + b);
+                            integral = int1 - int0;
+                            const float k_peak = k0 - k1 * b / a;
+                            const float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
+                            n_frac = integral * integrand_peak / a;
+                        }
+                        const float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
+                        s_a[side] = a; s_b[side] = b; s_integral[side] = integral; s_int0[side] = int0; s_n[side] = n;
+                        s_robust[side] = robust;
+                        s_nu[side] = f2u(n);
+                        s_line[side] = em.alloc(s_nu[side]);
+                        flp_count(FLC_PIECES, 1u);
+                        flp_count(FLC_EULER_LINES, s_nu[side]);
+                    }
+                    flp_mark(FLP_PIECE);
+                    push = true;
+                    is_last = t1 == 1.0f;
+                    this_p0 = last_p;
+                    this_p1 = this_pq1.point;
+                    last_p = this_pq1.point;
+                    last_q = this_pq1.deriv;
+                    last_t = t1;
+                    t0_u += 1u;
+                    const uint32_t shift = (uint32_t)(__ffs((int)t0_u) - 1);
+                    t0_u >>= shift;
+                    dt *= (float)(1u << shift);
+                } else {
+                    t0_u = t0_u * 2u;
+                    dt *= 0.5f;
+                }
+            }
+        }
+        unsigned long long pending = __ballot(push);
+        // ---- the lines of the ranges accepted in this turn, a point per lane (flatten.wgsl:447-470): the owners leave their ranges in
+        // LDS (EC_PIECES at a time, by rank among the accepting lanes), every lane takes points ----
+        while (pending != 0ull) {
+            const uint32_t rank = mask_rank_below(pending, lane);
+            const bool mine = push && ((pending >> lane) & 1ull) != 0ull && rank < EC_PIECES;
+            const uint32_t cnt = mine ? s_nu[0] + s_nu[1] : 0u;
+            const uint32_t incl = wave_incl_scan_u32(cnt, (int)lane);
+            const uint32_t total = wave_read(incl, 63u);
+            const uint32_t n_pieces = minu((uint32_t)__popcll(pending), EC_PIECES);
+            wave_lds_sync();
+            if (mine) {
+                EulerPiece &pc = cl.piece[rank];
+                pc.p0x = this_p0.x; pc.p0y = this_p0.y; pc.p1x = this_p1.x; pc.p1y = this_p1.y;
+                pc.th0 = ep.th0; pc.k0 = ep.k0; pc.k1 = ep.k1; pc.ch = ep.ch;
+                pc.noff = noff;
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    pc.a[sd] = s_a[sd]; pc.b[sd] = s_b[sd]; pc.integral[sd] = s_integral[sd]; pc.int0[sd] = s_int0[sd]; pc.n[sd] = s_n[sd];
+                    pc.line[sd] = s_line[sd]; pc.nu[sd] = s_nu[sd];
+                }
+                pc.flags = s_robust[0] | (s_robust[1] << 2) | (is_last ? 16u : 0u) | (off_fwd << 5) | (lane << 8);
+                pc.first = incl - cnt;
+            }
+            wave_lds_sync();
+            for (uint32_t base = 0u; base < total; base += 64u) {
+                const bool on = base + lane < total;
+                const uint32_t q = on ? base + lane : total - 1u;
+                // the range: the last one whose first point is <= q (a range has at least one line)
+                uint32_t pi = 0u;
+#pragma unroll
+                for (uint32_t step = EC_PIECES / 2u; step >= 1u; step >>= 1) {
+                    const uint32_t probe = pi + step;
+                    if (probe < n_pieces && cl.piece[probe].first <= q) pi = probe;
+                }
+                const EulerPiece &pc = cl.piece[pi];
+                const uint32_t local = q - pc.first;
+                const uint32_t o_nA = pc.nu[0];
+                const uint32_t side = local >= o_nA ? 1u : 0u;
+                const uint32_t i = local - (side ? o_nA : 0u);
+                const uint32_t e_flags = pc.flags;
+                const uint32_t owner = e_flags >> 8;
+                const vec2 e_p0 = v2(pc.p0x, pc.p0y), e_p1 = v2(pc.p1x, pc.p1y);
+                EulerParams e_ep;
+                e_ep.th0 = pc.th0; e_ep.k0 = pc.k0; e_ep.k1 = pc.k1; e_ep.ch = pc.ch;
+                const float a = pc.a[side], b = pc.b[side], integral = pc.integral[side], int0 = pc.int0[side], n = pc.n[side];
+                const uint32_t n_u = pc.nu[side], line_ix = pc.line[side];
+                const uint32_t robust = (e_flags >> (side * 2u)) & 3u;
+                const bool e_last = (e_flags & 16u) != 0u, fwd = ((e_flags >> (5u + side)) & 1u) != 0u;
+                const float normalized_offset = side ? -pc.noff : pc.noff;
+                // (what does not change from turn to turn stays in the owner's registers: the curve's end and start points, its
+                // transform and path; every lane takes part in a ds_bpermute, so they are fetched outside the branches)
+                const vec2 te0 = v2(shfl_f(t_end[0].x, owner), shfl_f(t_end[0].y, owner)), te1 = v2(shfl_f(t_end[1].x, owner), shfl_f(t_end[1].y, owner));
+                vec2 lp1;
+                if (i + 1u == n_u && e_last) {
+                    lp1 = side ? te1 : te0;
+                } else {
+                    const float t = (float)(i + 1u) / n;
+                    float sv = t;
+                    if (robust != ESPC_ROBUST_LOW_K1) {
+                        const float u = integral * t + int0;
+                        float inv;
+                        if (robust == ESPC_ROBUST_LOW_DIST) inv = pow_cr(fabsf(u), 2.0f / 3.0f) * signf(u);
+                        else inv = espc_int_inv_approx(u);
+                        sv = (inv - b) / a;
+                    }
+                    lp1 = es_seg_eval_with_offset(e_p0, e_p1, e_ep, sv, normalized_offset);
+                }
+                Xform e_t;
+                e_t.m0 = shfl_f(transform.m0, owner); e_t.m1 = shfl_f(transform.m1, owner); e_t.m2 = shfl_f(transform.m2, owner);
+                e_t.m3 = shfl_f(transform.m3, owner); e_t.t0 = shfl_f(transform.t0, owner); e_t.t1 = shfl_f(transform.t1, owner);
+                const uint32_t e_path = wave_shfl(path_ix, owner);
+                const vec2 ls0 = v2(shfl_f(lp0[0].x, owner), shfl_f(lp0[0].y, owner)), ls1 = v2(shfl_f(lp0[1].x, owner), shfl_f(lp0[1].y, owner));
+                if (on) {
+                    // point i + 1: the far end of line i, the near end of line i + 1 (flatten.wgsl:463-468: the ends swap for a
+                    // negative offset); the range's first point (the previous range's last, or the curve's start) from the lane of i = 0
+                    const vec2 P = xf_apply(e_t, lp1);
+                    em.write_end(line_ix + i, fwd ? 1u : 0u, P);
+                    em.write_path(line_ix + i, e_path);
+                    if (i + 1u < n_u) {
+                        em.write_end(line_ix + i + 1u, fwd ? 0u : 1u, P);
+                    } else {
+                        cl.endpt[owner][side][0] = lp1.x;
+                        cl.endpt[owner][side][1] = lp1.y;
+                    }
+                    float bx0 = P.x, by0 = P.y, bx1 = P.x, by1 = P.y;
+                    if (i == 0u) {
+                        const vec2 S = xf_apply(e_t, side ? ls1 : ls0);
+                        em.write_end(line_ix, fwd ? 0u : 1u, S);
+                        bx0 = minf(bx0, S.x); by0 = minf(by0, S.y); bx1 = maxf(bx1, S.x); by1 = maxf(by1, S.y);
+                    }
+                    atomicMin(&cl.bbox[owner][0], f32_ordered(bx0));
+                    atomicMin(&cl.bbox[owner][1], f32_ordered(by0));
+                    atomicMax(&cl.bbox[owner][2], f32_ordered(bx1));
+                    atomicMax(&cl.bbox[owner][3], f32_ordered(by1));
+                }
+                flp_mark(FLP_EMIT);
+            }
+            // the first EC_PIECES accepting lanes are served
+            {
+                unsigned long long m = pending;
+                for (uint32_t k = 0; k < n_pieces; k++) m &= m - 1ull;
+                pending = m;
+            }
+        }
+        wave_lds_sync();
+        if (push) {
+            lp0[0] = v2(cl.endpt[lane][0][0], cl.endpt[lane][0][1]);
+            if (two_sided) lp0[1] = v2(cl.endpt[lane][1][0], cl.endpt[lane][1][1]);
+        }
+        wave_lds_sync();
+    }
+    if (walked) {
+        em.bx0 = minf(em.bx0, f32_from_ordered(cl.bbox[lane][0]));
+        em.by0 = minf(em.by0, f32_from_ordered(cl.bbox[lane][1]));
+        em.bx1 = maxf(em.bx1, f32_from_ordered(cl.bbox[lane][2]));
+        em.by1 = maxf(em.by1, f32_from_ordered(cl.bbox[lane][3]));
+    }
+}
+
 // flatten.wgsl:494-521
 __device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float angle,
                             const Xform &transform) {
@@ -510,20 +943,25 @@ __device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end,
     const float MIN_THETA = 0.0001f;
     const float tol = 0.25f;
     float radius = maxf(tol, length(p0 - xf_apply(transform, center)));
-    float theta = maxf(MIN_THETA, 2.0f * acos_cr(1.0f - tol / radius));
+    float theta = maxf(MIN_THETA, 2.0f * fl_acos(1.0f - tol / radius));
     uint32_t n_lines = maxu(1u, f2u(ceilf(angle / theta)));
     uint32_t line_ix = em.alloc(n_lines);
     {
         float cs, sn;
-        sincos_cr(theta, sn, cs);
+        fl_sincos(theta, sn, cs);
+        flp_mark(FLP_ARC_SETUP);
+        flp_count(FLC_ARCS, 1u);
+        flp_count(FLC_ARC_LINES, n_lines);
         for (uint32_t i = 0; i < n_lines - 1u; i++) {
             r = v2(cs * r.x + sn * r.y, -sn * r.x + cs * r.y);
             vec2 p1 = xf_apply(transform, center + r);
             em.write(line_ix + i, path_ix, p0, p1);
             p0 = p1;
+            flp_mark(FLP_ARC_LINES);
         }
         vec2 p1 = xf_apply(transform, end);
         em.write(line_ix + n_lines - 1u, path_ix, p0, p1);
+        flp_mark(FLP_ARC_LINES);
     }
 }
 
@@ -532,6 +970,7 @@ template <bool WITH_ROUND = true>  // (false: the caller has taken the round sty
 __device__ void draw_cap(Emitter &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
                          vec2 offset_tangent, const Xform &transform) {
     if (WITH_ROUND && cap_style == STYLE_FLAGS_CAP_ROUND) {
+        flp_mark(FLP_JOIN);
         flatten_arc(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
         return;
     }
@@ -606,10 +1045,13 @@ __device__ void draw_join(Emitter &em, uint32_t path_ix, uint32_t style_flags, v
         vec2 arc0, arc1, other0, other1;
         if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
         else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
-        flatten_arc(em, path_ix, arc0, arc1, p0, fabsf(atan2_cr(cr, d)), transform);
+        const float angle = fabsf(fl_atan2(cr, d));
+        flp_mark(FLP_JOIN);
+        flatten_arc(em, path_ix, arc0, arc1, p0, angle, transform);
         uint32_t ix = em.alloc(1u);
         em.write_xf(ix, path_ix, other0, other1, transform);
     }
+    flp_mark(FLP_JOIN);
 }
 
 struct PathTagData {
@@ -715,6 +1157,7 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
     bool is_stroke = (style_flags & STYLE_FLAGS_STYLE) != 0u;
     Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
     CubicPoints pts = read_path_segment(pd, tag, is_stroke);
+    flp_count(FLC_ENTRIES, 1u);
     if (is_stroke) {
         float linewidth = __uint_as_float(scene[cfg.layout.style_base + style_ix + 1u]);
         float offset = 0.5f * linewidth;
@@ -750,8 +1193,10 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
             vec2 tnn = normalize(tan_next) * offset;
             vec2 n_next = v2(-tnn.y, tnn.x);
 
+            flp_mark(FLP_TAG);
             flatten_euler(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev, true, pts.p0 - n_start,
                                 pts.p3 - n_prev);
+            flp_mark(FLP_SUBDIV);  // (the loop's exit test, and the lanes that waited for the wave's longest walk)
             if (do_join) {
                 draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
             } else {
@@ -760,7 +1205,89 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
             }
         }
     } else {
+        flp_mark(FLP_TAG);
         flatten_euler(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3, false, pts.p0, pts.p3);
+        flp_mark(FLP_SUBDIV);
+    }
+    return path_ix;
+}
+
+// flatten_tag for a whole wave (has_tag = this lane has a list entry): the same three steps -- decode, the two offset curves (or
+// the fill's curve), join or cap -- with the middle one taken by all 64 lanes together (flatten_euler_coop).
+__device__ uint32_t flatten_tag_coop(Emitter &em, EulerCoopLds &cl, bool has_tag, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
+                                     uint32_t ix, uint32_t lane) {
+    em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
+    uint32_t path_ix = 0xffffffffu, style_flags = 0u;
+    bool euler = false, two_sided = false, start_cap = false, do_join = false, end_cap = false;
+    CubicPoints pts{v2(0.0f, 0.0f), v2(0.0f, 0.0f), v2(0.0f, 0.0f), v2(0.0f, 0.0f)};
+    Xform transform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    float offset = 0.0f;
+    vec2 e_start_p = v2(0.0f, 0.0f), e_end_p = e_start_p, e_start_n = e_start_p, e_end_n = e_start_p;
+    vec2 tan_prev = e_start_p, tan_next = e_start_p, n_prev = e_start_p, n_next = e_start_p, offset_tangent = e_start_p;
+    if (has_tag) {
+        PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
+        const uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
+        path_ix = tag.monoid.path_ix;
+        // (a PATH marker's draw flags / transform index, flatten.wgsl:813-817: stored by k_pathtag_scan, scan.hip)
+        if (seg_type != 0u) {
+            const uint32_t style_ix = tag.monoid.style_ix;
+            style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
+            const uint32_t *pd = scene + cfg.layout.path_data_base;
+            const bool is_stroke = (style_flags & STYLE_FLAGS_STYLE) != 0u;
+            transform = read_transform(scene, cfg.layout.transform_base, tag.monoid.trans_ix);
+            pts = read_path_segment(pd, tag, is_stroke);
+            flp_count(FLC_ENTRIES, 1u);
+            if (is_stroke) {
+                const float linewidth = __uint_as_float(scene[cfg.layout.style_base + style_ix + 1u]);
+                offset = 0.5f * linewidth;
+                const bool is_open = seg_type != PATH_TAG_LINETO;
+                const bool is_stroke_cap_marker = (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+                if (is_stroke_cap_marker) {
+                    if (is_open) {
+                        const vec2 tangent = pts.p3 - pts.p0;
+                        offset_tangent = normalize(tangent) * offset;
+                        start_cap = true;
+                    }
+                } else {
+                    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
+                    PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
+                    CubicPoints npts = read_path_segment(pd, ntag, true);
+                    const bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
+                    const bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+                    do_join = !n_is_marker || n_is_closed;
+                    end_cap = !do_join;
+                    vec2 n_tangent = npts.p3 - npts.p0;
+                    if (!n_is_marker) n_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
+                    vec2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                    if (dot(tan_start, tan_start) < TANGENT_THRESH * TANGENT_THRESH) tan_start = v2(TANGENT_THRESH, 0.0f);
+                    tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
+                    if (dot(tan_prev, tan_prev) < TANGENT_THRESH * TANGENT_THRESH) tan_prev = v2(TANGENT_THRESH, 0.0f);
+                    tan_next = n_tangent;
+                    if (dot(tan_next, tan_next) < TANGENT_THRESH * TANGENT_THRESH) tan_next = v2(TANGENT_THRESH, 0.0f);
+                    const vec2 n_start = normalize(v2(-tan_start.y, tan_start.x)) * offset;
+                    offset_tangent = normalize(tan_prev) * offset;
+                    n_prev = v2(-offset_tangent.y, offset_tangent.x);
+                    const vec2 tnn = normalize(tan_next) * offset;
+                    n_next = v2(-tnn.y, tnn.x);
+                    euler = two_sided = true;
+                    e_start_p = pts.p0 + n_start; e_end_p = pts.p3 + n_prev; e_start_n = pts.p0 - n_start; e_end_n = pts.p3 - n_prev;
+                }
+            } else {
+                euler = true;
+                e_start_p = pts.p0; e_end_p = pts.p3; e_start_n = pts.p0; e_end_n = pts.p3;
+            }
+        }
+    }
+    flp_mark(FLP_TAG);
+    flatten_euler_coop(em, cl, euler, pts, path_ix, transform, offset, e_start_p, e_end_p, two_sided, e_start_n, e_end_n, lane);
+    flp_mark(FLP_SUBDIV);  // (the walk's exit, and the lanes that had nothing to walk)
+    if (start_cap) {
+        const vec2 n = v2(-offset_tangent.y, offset_tangent.x);
+        draw_cap(em, path_ix, (style_flags & STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n, -offset_tangent, transform);
+    } else if (do_join) {
+        draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
+    } else if (end_cap) {
+        draw_cap(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev, offset_tangent, transform);
     }
     return path_ix;
 }
@@ -1057,10 +1584,12 @@ __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg
 //    handed on (heavy_list's fourth section).
 // k_flatten_tail: what the stroke workgroups set aside -- the arcs, densely, and the handed-on lines -- by the heavy
 // code once more.  Launched only with stroke workgroups.
-constexpr uint32_t FLATTEN_LDS_LINES = 3072u;  // 5 words each: 60 KB of staging per workgroup; with a stroke workgroup's arc queue (16 KB) two fit a CU
+constexpr uint32_t FLATTEN_LDS_LINES = 2816u;  // 5 words each: 55 KB of staging per workgroup; with the four waves' EulerCoopLds (21 KB; a stroke workgroup: its arc queue, 16 KB) two fit a CU
 constexpr uint32_t FLATTEN_STROKE_ROUND_LINES = 1536u;  // what one round of a stroke workgroup (256 stroked lines) emits at most, nearly always
 constexpr size_t FLATTEN_ARCS_AT = (sizeof(FlattenShared<FLATTEN_LDS_LINES>) + 15u) & ~(size_t)15u;  // the stroke workgroups' arc queue behind the staging
-constexpr size_t FLATTEN_MAIN_LDS = FLATTEN_ARCS_AT + sizeof(ArcQueue);
+constexpr size_t FLATTEN_MAIN_LDS = FLATTEN_ARCS_AT + (sizeof(ArcQueue) > 4u * sizeof(EulerCoopLds) ? sizeof(ArcQueue) : 4u * sizeof(EulerCoopLds));  // (the heavy workgroups' EulerCoopLds in the arc queue's place)
+static_assert(FLATTEN_MAIN_LDS <= 80u * 1024u && sizeof(FlattenShared<FLATTEN_LDS_LINES>) + 4u * sizeof(EulerCoopLds) <= 80u * 1024u, "two heavy workgroups per CU");
+
 
 template <uint32_t CAP>
 __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueue &arcs, uint32_t block, uint32_t n_blocks, const Config &cfg,
@@ -1140,8 +1669,12 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
 // The heavy code over its list.  LISTS & HEAVY_FIRST: [curves | strokes | stroked lines below the threshold] as k_flatten_light
 // left them; LISTS & HEAVY_SET_ASIDE: [handed-on lines | arcs] as stroke workgroups -- of an EARLIER launch -- left them.
 constexpr uint32_t HEAVY_FIRST = 1u, HEAVY_SET_ASIDE = 2u;
+#ifndef VK_FL_LPW_DIV
+#define VK_FL_LPW_DIV 1024u          // a long list is spread over this many waves ...
+#define VK_FL_LPW_DIV_STROKES 3072u  // ... a list with many stroked curves over this many (sweep constants)
+#endif
 template <uint32_t LISTS>
-__device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES> &sh, uint32_t block, uint32_t n_blocks, const Config &cfg, uint32_t n_tags,
+__device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES> &sh, EulerCoopLds *coop, uint32_t block, uint32_t n_blocks, const Config &cfg, uint32_t n_tags,
                                                  const uint32_t *__restrict__ scene, const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                  Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
                                                  uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
@@ -1169,7 +1702,13 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
     // loops: tiger flatten 190 -> 146 us against two entries per wave).  Beyond: pack -- the launch is the sum of its
     // waves, and denser waves are fewer of them (mmark-50k 334 -> 294 us with 49 entries per wave against 25; the road map
     // pays 6 us one frame at a time and gains 3 % with frames in flight).  Round 3, measured over 1 / 2 / 4 K divisors.
-    const uint32_t lpw = n_heavy <= 4096u ? 1u : minu(maxu((n_heavy + 1023u) / 1024u, 1u), 64u);
+    // Round 5 (the Euler flattener is wave-cooperative now: what a wave pays per entry is the union of its lanes' SUBDIVISION walks,
+    // the lines are spread over all lanes whoever owns them): a list with many stroked curves (two offset curves per walk, a dozen
+    // turns, wildly different from lane to lane) is spread over three times as many waves -- mmark-50k flatten 204 -> 182 us -- while
+    // fills' curves, stroked lines and arcs stay dense (the road map's blobs and arcs: 136 us dense, 170 at a third of the density;
+    // profiles/r05_ab_flatten_coop.txt).
+    const uint32_t lpw_div = n_strokes * 4u > n_heavy ? VK_FL_LPW_DIV_STROKES : VK_FL_LPW_DIV;
+    const uint32_t lpw = n_heavy <= 4096u ? 1u : minu(maxu((n_heavy + lpw_div - 1u) / lpw_div, 1u), 64u);
     if (block * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
         sh.count = 0u;
@@ -1178,6 +1717,7 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
     __syncthreads();
     Bump *bump = &control->bump;
     const uint32_t lane = tid & 63u, wave = block * 4u + (tid >> 6);
+    flp_start();
     // no indirect dispatch in HIP: a fixed grid strides over the list
 #pragma unroll 1
     for (uint32_t base = 0u; base + block * 4u * lpw < n_heavy; base += n_waves * lpw) {
@@ -1200,13 +1740,19 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
             arc_shard = minu(arc_shard, 63u);
             arc_local = a - wave_shfl(arc_incl - arc_n, arc_shard);
         }
-        if (lane < lpw && e < n_tag_entries) {
+        // (every lane of the wave goes through flatten_tag_coop: the lanes without an entry flatten the others' lines)
+        const bool has_tag = lane < lpw && e < n_tag_entries;
+        uint32_t tag_ix = 0u;
+        if (has_tag) {
             const uint32_t e1 = e - n_curves, e3 = e1 - n_strokes, e2 = e3 - n_handed;
-            const uint32_t tag_ix = e < n_curves     ? heavy_list[e]
-                                    : e1 < n_strokes ? heavy_list[n_tags + e1]
-                                    : e3 < n_handed  ? heavy_list[3u * n_tags + e3]
-                                                     : heavy_list[2u * n_tags + e2];
-            key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
+            tag_ix = e < n_curves     ? heavy_list[e]
+                     : e1 < n_strokes ? heavy_list[n_tags + e1]
+                     : e3 < n_handed  ? heavy_list[3u * n_tags + e3]
+                                      : heavy_list[2u * n_tags + e2];
+        }
+        const uint32_t tag_key = flatten_tag_coop(em, coop[tid >> 6], has_tag, cfg, scene, tag_monoids, tag_ix, lane);
+        if (has_tag) {
+            key = tag_key;
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
             }
@@ -1216,7 +1762,7 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
             const ArcItem it = reinterpret_cast<const ArcItem *>(arc_items)[arc_shard * arc_shard_cap + arc_local];
             em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
             const Xform t = read_transform(scene, cfg.layout.transform_base, it.trans_ix);
-            const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(atan2_cr(it.cr, it.d));
+            const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(fl_atan2(it.cr, it.d));
             flatten_arc(em, it.path_ix, v2(it.bx, it.by), v2(it.ex, it.ey), v2(it.cx, it.cy), angle, t);
             key = it.path_ix;
             const float mx0 = minf(em.bx0, it.box[0]), my0 = minf(em.by0, it.box[1]), mx1 = maxf(em.bx1, it.box[2]), my1 = maxf(em.by1, it.box[3]);
@@ -1225,9 +1771,12 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
             }
         }
         // list entries of one source workgroup keep tag order, so equal path keys still come in runs
+        flp_mark(FLP_OTHER);
         wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
         flush_staged_lines(sh, bump, lines, cfg.lines_size, tid);
+        flp_mark(FLP_BBOX_FLUSH);
     }
+    flp_store();
 }
 
 __global__ void __launch_bounds__(256, 2) k_flatten_main(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
@@ -1237,7 +1786,9 @@ __global__ void __launch_bounds__(256, 2) k_flatten_main(Config cfg, uint32_t n_
                                                          uint32_t n_heavy_blocks) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[FLATTEN_MAIN_LDS];
     if (blockIdx.x < n_heavy_blocks) {
-        heavy_workgroups<HEAVY_FIRST>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), blockIdx.x, n_heavy_blocks, cfg, n_tags, scene, tag_monoids,
+        // (the heavy workgroups keep their four waves' EulerCoopLds where the stroke workgroups keep their arc queue)
+        heavy_workgroups<HEAVY_FIRST>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), reinterpret_cast<EulerCoopLds *>(smem + FLATTEN_ARCS_AT),
+                                      blockIdx.x, n_heavy_blocks, cfg, n_tags, scene, tag_monoids,
                                       path_bboxes, control, lines, heavy_list, stroke_kernel_min_lines, arc_items, arc_shard_cap);
     } else {
         stroke_workgroup(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), *reinterpret_cast<ArcQueue *>(smem + FLATTEN_ARCS_AT),
@@ -1251,7 +1802,8 @@ __global__ void __launch_bounds__(256, 2) k_flatten_tail(Config cfg, uint32_t n_
                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
                                                          const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
-    heavy_workgroups<HEAVY_SET_ASIDE>(sh, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, 0u, arc_items,
+    __shared__ EulerCoopLds coop[4];
+    heavy_workgroups<HEAVY_SET_ASIDE>(sh, coop, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, 0u, arc_items,
                                       arc_shard_cap);
 }
 
@@ -1275,9 +1827,23 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
                                                           uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items,
                                                           uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
-    heavy_workgroups<HEAVY_FIRST | HEAVY_SET_ASIDE>(sh, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list,
+    __shared__ EulerCoopLds coop[4];
+    heavy_workgroups<HEAVY_FIRST | HEAVY_SET_ASIDE>(sh, coop, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list,
                                                     stroke_kernel_min_lines, arc_items, arc_shard_cap);
 }
+
+#ifdef VELLO_FLATTEN_PROF
+}  // namespace vk
+// measurement build only: the counters of g_flatten_prof, read and cleared (scripts/flatten_prof.py binds it with ctypes)
+extern "C" int vello_flatten_prof_read(unsigned long long *out) {
+    unsigned long long zero[2 * vk::FLP_PHASES + vk::FLC_COUNTS + 2] = {};
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(vk::g_flatten_prof), sizeof(zero));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(vk::g_flatten_prof), zero, sizeof(zero));
+    return (int)e;
+}
+namespace vk {
+#endif
 
 void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_draw_scan) {
     uint32_t n_tags = f.n_tag_words * 4u;
