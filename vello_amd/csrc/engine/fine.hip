@@ -966,9 +966,9 @@ __device__ void ms_fill_from_batch(FineShared &sh, FineBatch &bt, uint32_t *sh_s
 // clean -- as straight-line code (round 5).  The general routine decides even-odd / clean / one round / records prefetched /
 // no records / which lanes hold a record with scalar branches and exec-mask ladders: 70 scalar instructions per fill around
 // ~180 vector ones, and a scalar instruction takes an issue slot like a vector one.  Here a lane without a record
-// holds the ZERO record, which adds zeros to pixel 0's counters and winding word, reads pixel 0's counters, puts the cleared value
-// back where it already is (or where the pixel's own lane puts it in the same instruction) and sends its coverage to a word of
-// its own: the same LDS operations on the same values for every lane that does hold a record, nothing conditional but the
+// holds the ZERO record, which adds zeros to the counters and the winding word of a pixel of the lane's own, reads that pixel's
+// counters, puts the cleared value back where it already is (or where the pixel's own lane puts it in the same instruction) and
+// sends its coverage to a word of its own: the same LDS operations on the same values for every lane that does hold a record, nothing conditional but the
 // address of the last store.  Coverage is bit-identical to ms_fill_from_batch's (tests: every MSAA image against the oracle).
 template <int AA>
 __device__ __forceinline__ void ms_fill_simple(FineShared &sh, FineBatch &bt, uint32_t *sh_samples, uint32_t slot, const SlotRegs &slots, uint32_t lane,
@@ -985,7 +985,9 @@ __device__ __forceinline__ void ms_fill_simple(FineShared &sh, FineBatch &bt, ui
     if (begin + lane >= end) rec = 0u;
     wave_lds_sync();
     // ---- the records into the counters (ms_apply, non-zero rule, without its tests) ----
-    const uint32_t pix_ix = rec & 0xffu;
+    // (a lane without a record works on a pixel of its own, 4 x lane: thirty idle lanes adding their zeros to ONE word are thirty
+    // LDS atomics in a row -- k_fine 150 -> 226 us on the road map when they all took pixel 0, profiles/r05_ab_fine_simple.txt)
+    const uint32_t pix_ix = rec != 0u ? rec & 0xffu : lane * 4u;
     const bool is_down = (rec & REC_IS_DOWN) != 0u;
     {
         const uint32_t delta_pix = pix_ix + 1u;
@@ -1324,8 +1326,14 @@ struct RareState {
     uint32_t clip_depth;
     uint32_t cmd_ix;
 };
+// (round 5: the body is inlined into the BRUSH kernels' interpreter -- k_fine<.., true> -- and called out of line everywhere else.
+// Out of line, the pixel state crosses the call through scratch memory, written by the caller and read back by the callee with
+// FLAT loads, and returns the same way: two memory round trips per command, ~10 us under load.  A solid-colour scene meets a clip
+// command now and then and its hot loop must not carry these arms; a scene with gradients, images or blend layers meets such a
+// command ten times a tile: blend_grid 900^2 fine 185 -> 70 us, gradient_extend 32 -> 21, image_sampling 31 -> 24
+// (profiles/r05_brush_prof.txt).)
 template <bool BRUSHES>
-__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, uint32_t ptcl_size,
+__device__ __forceinline__ void rare_command_body(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, uint32_t ptcl_size,
                                                        uint32_t blend_size,
                                                        const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
                                                        uint32_t *blend_spill, uint32_t blend_offset, uint32_t lane, float xy_x,
@@ -1506,6 +1514,17 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
     st.clip_depth = clip_depth;
     st.cmd_ix = cmd_ix;
 }
+template <bool BRUSHES>
+__device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, uint32_t ptcl_size,
+                                                       uint32_t blend_size,
+                                                       const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
+                                                       uint32_t *blend_spill, uint32_t blend_offset, uint32_t lane, float xy_x,
+                                                       float xy_y, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
+                                                       const uint32_t *__restrict__ atlas_texels, uint32_t atlas_w, uint32_t atlas_h) {
+    rare_command_body<BRUSHES>(st, blend_stack, tag, ptcl_size, blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps, atlas_texels,
+                               atlas_w, atlas_h);
+}
+
 
 // The compositing pass of a sliced tile (k_fine, FINE_SLICE_FILLS): the tile's whole list once more, every FILL's
 // coverage read back from the coverage scratch (a byte per pixel, the number of covered samples).  Out of line, called
@@ -1956,8 +1975,12 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
             }
             st.clip_depth = clip_depth;
             st.cmd_ix = cmd_ix;
-            rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
-                                  atlas_texels, atlas_w, atlas_h);
+            if constexpr (BRUSHES)
+                rare_command_body<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps,
+                                           n_ramps, atlas_texels, atlas_w, atlas_h);
+            else
+                rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+                                      atlas_texels, atlas_w, atlas_h);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 rgba[i] = st.rgba[i];

@@ -663,12 +663,12 @@ __device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __uint_a
 
 // Called by ALL 64 lanes of a wave (valid = this lane has a curve).  Arguments as flatten_euler's.
 __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
-                                   float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n, uint32_t lane) {
+                                   float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n, uint32_t lane, bool few_entries) {
     vec2 p0 = v2(0.0f, 0.0f), p1 = p0, p2 = p0, p3 = p0;
     float scale = 1.0f;
     Xform transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
     vec2 t_start[2] = {start_p, start_n}, t_end[2] = {end_p, end_n};
-    bool active = valid;
+    bool active = valid, tame = true;
     if (valid) {
         if (offset == 0.0f) {
             p0 = xf_apply(local_to_device, cubic.p0);
@@ -685,16 +685,33 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
         }
         // (NaN fails every comparison: it is "not tame" too)
         const float LIM = 1.0e15f;
-        const bool tame = fabsf(p0.x) <= LIM && fabsf(p0.y) <= LIM && fabsf(p1.x) <= LIM && fabsf(p1.y) <= LIM && fabsf(p2.x) <= LIM &&
-                          fabsf(p2.y) <= LIM && fabsf(p3.x) <= LIM && fabsf(p3.y) <= LIM && fabsf(offset) <= LIM && fabsf(transform.m0) <= LIM &&
-                          fabsf(transform.m1) <= LIM && fabsf(transform.m2) <= LIM && fabsf(transform.m3) <= LIM && fabsf(transform.t0) <= LIM &&
-                          fabsf(transform.t1) <= LIM && fabsf(t_start[0].x) <= LIM && fabsf(t_start[0].y) <= LIM && fabsf(t_end[0].x) <= LIM &&
-                          fabsf(t_end[0].y) <= LIM && fabsf(t_start[1].x) <= LIM && fabsf(t_start[1].y) <= LIM && fabsf(t_end[1].x) <= LIM &&
-                          fabsf(t_end[1].y) <= LIM;
-        if (!tame) {
+        tame = fabsf(p0.x) <= LIM && fabsf(p0.y) <= LIM && fabsf(p1.x) <= LIM && fabsf(p1.y) <= LIM && fabsf(p2.x) <= LIM &&
+               fabsf(p2.y) <= LIM && fabsf(p3.x) <= LIM && fabsf(p3.y) <= LIM && fabsf(offset) <= LIM && fabsf(transform.m0) <= LIM &&
+               fabsf(transform.m1) <= LIM && fabsf(transform.m2) <= LIM && fabsf(transform.m3) <= LIM && fabsf(transform.t0) <= LIM &&
+               fabsf(transform.t1) <= LIM && fabsf(t_start[0].x) <= LIM && fabsf(t_start[0].y) <= LIM && fabsf(t_end[0].x) <= LIM &&
+               fabsf(t_end[0].y) <= LIM && fabsf(t_start[1].x) <= LIM && fabsf(t_start[1].y) <= LIM && fabsf(t_end[1].x) <= LIM &&
+               fabsf(t_end[1].y) <= LIM;
+    }
+    // Which waves walk together: a pass over the points of a turn costs ~2.6 line evaluations (who owns the point, 25 words of the
+    // range out of LDS, the ends of two lines and the owner's box through LDS) whoever takes part, so it pays where a lane alone would
+    // loop long -- a wave with a handful of curves (the tiger: one), or a wave of stroked curves (two sides, a dozen lines a turn:
+    // mmark) -- and not for a wave full of fills' curves with two or three lines a range.  Wave-uniform; the lanes with untame
+    // inputs walk alone in any case.
+    {
+        const unsigned long long m_valid = __ballot(valid), m_two = __ballot(valid && two_sided);
+#ifdef VK_FL_NO_COOP  // (sweep switch: every lane on its own, always)
+        const bool alone = true;
+#else
+        const bool alone = !few_entries && (uint32_t)__popcll(m_two) * 2u < (uint32_t)__popcll(m_valid);
+#endif
+        if (valid && (alone || !tame)) {
             flatten_euler(em, cubic, path_ix, local_to_device, offset, start_p, end_p, two_sided, start_n, end_n);
             active = false;
-        } else if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) {
+        }
+        if (alone) return;
+    }
+    if (active) {
+        if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) {
             active = false;
         } else if (cubic_is_straight(p0, p1, p2, p3, scale, offset)) {
             // the straight-segment shortcut, as flatten_euler takes it
@@ -1215,7 +1232,7 @@ __device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *
 // flatten_tag for a whole wave (has_tag = this lane has a list entry): the same three steps -- decode, the two offset curves (or
 // the fill's curve), join or cap -- with the middle one taken by all 64 lanes together (flatten_euler_coop).
 __device__ uint32_t flatten_tag_coop(Emitter &em, EulerCoopLds &cl, bool has_tag, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
-                                     uint32_t ix, uint32_t lane) {
+                                     uint32_t ix, uint32_t lane, bool few_entries) {
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
     uint32_t path_ix = 0xffffffffu, style_flags = 0u;
     bool euler = false, two_sided = false, start_cap = false, do_join = false, end_cap = false;
@@ -1279,7 +1296,7 @@ __device__ uint32_t flatten_tag_coop(Emitter &em, EulerCoopLds &cl, bool has_tag
         }
     }
     flp_mark(FLP_TAG);
-    flatten_euler_coop(em, cl, euler, pts, path_ix, transform, offset, e_start_p, e_end_p, two_sided, e_start_n, e_end_n, lane);
+    flatten_euler_coop(em, cl, euler, pts, path_ix, transform, offset, e_start_p, e_end_p, two_sided, e_start_n, e_end_n, lane, few_entries);
     flp_mark(FLP_SUBDIV);  // (the walk's exit, and the lanes that had nothing to walk)
     if (start_cap) {
         const vec2 n = v2(-offset_tangent.y, offset_tangent.x);
@@ -1707,7 +1724,8 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
     // turns, wildly different from lane to lane) is spread over three times as many waves -- mmark-50k flatten 204 -> 182 us -- while
     // fills' curves, stroked lines and arcs stay dense (the road map's blobs and arcs: 136 us dense, 170 at a third of the density;
     // profiles/r05_ab_flatten_coop.txt).
-    const uint32_t lpw_div = n_strokes * 4u > n_heavy ? VK_FL_LPW_DIV_STROKES : VK_FL_LPW_DIV;
+    // (n_strokes counts the cap markers of open subpaths too -- a QUADTO tag each, vello_encoding/src/path.rs -- hence "most of the list")
+    const uint32_t lpw_div = n_strokes * 2u > n_heavy + n_curves * 2u ? VK_FL_LPW_DIV_STROKES : VK_FL_LPW_DIV;
     const uint32_t lpw = n_heavy <= 4096u ? 1u : minu(maxu((n_heavy + lpw_div - 1u) / lpw_div, 1u), 64u);
     if (block * 4u * lpw >= n_heavy || (control->bump.failed & FAILED_SCENE) != 0u) return;
     if (tid == 0u) {
@@ -1750,7 +1768,11 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
                      : e3 < n_handed  ? heavy_list[3u * n_tags + e3]
                                       : heavy_list[2u * n_tags + e2];
         }
-        const uint32_t tag_key = flatten_tag_coop(em, coop[tid >> 6], has_tag, cfg, scene, tag_monoids, tag_ix, lane);
+        // (a dense list without stroked curves -- the road map's blobs, joins and caps -- takes flatten_tag, every lane on its own:
+        // nothing there for the lanes to share, and the plain routine is 5-10 % less code on the way; launch-uniform)
+        uint32_t tag_key = 0u;
+        if (lpw <= 4u || lpw_div == VK_FL_LPW_DIV_STROKES) tag_key = flatten_tag_coop(em, coop[tid >> 6], has_tag, cfg, scene, tag_monoids, tag_ix, lane, lpw <= 4u);
+        else if (has_tag) tag_key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
         if (has_tag) {
             key = tag_key;
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
