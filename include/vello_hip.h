@@ -215,8 +215,13 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * 524 288 clips (clip_reduce.wgsl / clip_leaf.wgsl run as partitioned kernels below that): same clip boxes.
  * VELLO_HIP_DEBUG_FINE_SLICES cuts EVERY tile's command list into slices of 4 fills for fine's MSAA modes (normally only
  * lists of >= 96 fills are cut, into slices of 32: the slices' coverage is computed by separate waves and the last one to
- * finish composites the tile): same image -- so that small test scenes exercise the sliced path. */
-enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8 };
+ * finish composites the tile): same image -- so that small test scenes exercise the sliced path.
+ * VELLO_HIP_DEBUG_FLATTEN_COOP / _ALONE pick the kernels that flatten the scene's curves, stroked curves, joins and caps: the
+ * wave-cooperative walk, or every lane on its own (normally the engine picks by what an earlier frame of the same scene put on
+ * the list, and by the scene's size before there is one): same line soup as a multiset -- so that tests can hold both sets of
+ * kernels to the oracle on the same scenes. */
+enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8,
+       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -1,5 +1,5 @@
 """Flatten's kernels one by one (HIP events between the launches, one frame at a time) on d2 / r1mix / mmark / tiger.
-   python scripts/flatten_kernels.py [A|<variant letter>]      (ab_tmp/libvello_hip_<letter>.so)"""
+   python scripts/flatten_kernels.py [A|<variant letter>] [workloads ...]     (ab_tmp/libvello_hip_<letter>.so)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +10,7 @@ if which != "A":
 import bench
 from vello_amd.renderer import Engine
 
-for key in ("d2", "r1mix", "mmark", "tiger"):
+for key in (sys.argv[2:] or ("d2", "r1mix", "mmark", "tiger")):
     wl = bench.Workload(key, 0)
     eng = Engine(0, 1 << int(wl.aa), wl.caps)
     eng.upload_scene(wl.packed, wl.layout)

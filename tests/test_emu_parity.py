@@ -931,6 +931,43 @@ def test_emu_stroked_line_kernel(emu_engine, case):
         emu_engine.set_auto_grow(False)
 
 
+def flatten_kernel_sets(engine, name, packed, layout, w, h, bg=WHITE, in_flight=True):
+    """Both sets of kernels for flatten's heavy list -- the wave-cooperative walk (k_flatten_main<true> / k_flatten_heavy<true>)
+    and every lane on its own (<false>, round 4's) -- forced on the same scene, one frame in flight (the stroke workgroups beside
+    the heavy list's: k_flatten_main) and two (k_flatten_heavy): stages, line soup as a multiset and images against the oracle."""
+    try:
+        for which in ("flatten_coop", "flatten_alone"):
+            engine.set_debug_flags(**{which: True})
+            for aa in (AaConfig.Area, AaConfig.Msaa16):
+                compare_frame(engine, packed, layout, w, h, bg, aa, f"{name}_{which}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+            if in_flight:
+                engine.set_frames_in_flight(2)
+                compare_frame(engine, packed, layout, w, h, bg, AaConfig.Msaa16, f"{name}_{which}_2inflight")
+                engine.set_frames_in_flight(1)
+    finally:
+        engine.set_frames_in_flight(1)
+        engine.set_debug_flags()
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_emu_flatten_kernel_sets(emu_engine, case):
+    name, packed, layout, w, h = _stroke_kernel_cases()[case]
+    emu_engine.set_auto_grow(True)
+    try:
+        flatten_kernel_sets(emu_engine, "emu_flsets_" + name, packed, layout, w, h)
+    finally:
+        emu_engine.set_auto_grow(False)
+
+
+def test_emu_flatten_kernel_sets_curves(emu_engine):
+    # fills' curves (the cardioid, funky paths) and stroked curves with every join / cap
+    for name, fn in (("cardioid", workloads.cardioid_scene), ("funky", workloads.funky_paths_scene)):
+        r = fn()
+        s, w, h = r if isinstance(r, tuple) else (r, 512, 512)
+        packed, layout = s.resolve()
+        flatten_kernel_sets(emu_engine, "emu_flsets_" + name, packed, layout, w, h, in_flight=False)
+
+
 def test_emu_clip_stage_partitioned(emu_engine):
     # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip) and as the one-wave stack machine, against the oracle's stack
     from tests.parity import clip_structures, compare_clip_stage

@@ -711,6 +711,34 @@ def test_gpu_stroked_line_kernel(gpu_engine, case):
         gpu_engine.set_auto_grow(False)
 
 
+@pytest.mark.parametrize("case", range(8))
+def test_gpu_flatten_kernel_sets(gpu_engine, case):
+    # flatten's two sets of heavy-list kernels (flatten_walk.inc), forced, on the stroke catalogue
+    from tests.test_emu_parity import _stroke_kernel_cases, flatten_kernel_sets
+
+    name, packed, layout, w, h = _stroke_kernel_cases()[case]
+    gpu_engine.set_auto_grow(True)
+    try:
+        flatten_kernel_sets(gpu_engine, "gpu_flsets_" + name, packed, layout, w, h)
+    finally:
+        gpu_engine.set_auto_grow(False)
+
+
+def test_gpu_flatten_kernel_sets_baseline_configs(gpu_engine):
+    # ... and on BASELINE's C2 (tiger: a wave per curve) and C4 (mmark-50k: a list of stroked curves), whichever set the engine
+    # would pick for them by itself
+    from tests.test_emu_parity import flatten_kernel_sets
+
+    d = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+    flatten_kernel_sets(gpu_engine, "gpu_flsets_tiger", d["packed"], Layout(*[int(v) for v in d["layout"]]), 1024, 1024)
+    packed, layout = workloads.mmark_scene().resolve()
+    gpu_engine.set_auto_grow(True)
+    try:
+        flatten_kernel_sets(gpu_engine, "gpu_flsets_mmark", packed, layout, 2048, 2048, in_flight=False)
+    finally:
+        gpu_engine.set_auto_grow(False)
+
+
 def test_clip_stage_partitioned(gpu_engine):
     # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip: 256 clips per workgroup, one workgroup over the partitions, a
     # second pass per partition) and as the one-wave stack machine, against the oracle's sequential stack; up to 300 000 clips and

@@ -171,6 +171,7 @@ struct Frame {
     bool path_count_small;  // path_count: chunks of 256 lines (PATH_COUNT_SMALL_MAX_LINES)
     bool flatten_side_by_side;  // flatten: stroke workgroups in the heavy list's launch (one frame in flight) instead of a kernel before it
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that stroke workgroups would exit at once
+    bool flatten_coop;          // flatten's heavy list by the kernels of the wave-cooperative walk (flatten_walk.inc) instead of round 4's
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)

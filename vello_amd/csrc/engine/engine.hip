@@ -49,6 +49,9 @@ struct SceneSlot {
     // lines in the soup of a finished frame of this scene (-1 unknown): picks path_count's chunk size (path.hip, k_path_count<LPT>)
     int64_t soup_lines = -1;
     int64_t slice_demand = -1;  // slice items coarse asked for in a finished MSAA frame of this scene (max seen), -1 unknown
+    // what k_flatten_light put on flatten's heavy list in a finished frame of this scene: fills' curves, stroked curves (+ the cap
+    // markers of open subpaths), stroked lines (-1: not known yet): picks the kernels that take the list (Frame::flatten_coop)
+    int64_t heavy_curves = -1, heavy_strokes = -1;
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
 };
 
@@ -447,6 +450,25 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.path_count_small = sc.soup_lines >= 0 && sc.soup_lines < PATH_COUNT_SMALL_MAX_LINES;
     f.flatten_side_by_side = c->n_active == 1u;
     f.launch_stroke_kernel = sc.stroke_lines < 0 || (uint64_t)sc.stroke_lines >= f.stroke_kernel_min_lines;
+    // Which kernels take flatten's heavy list (flatten_walk.inc).  The wave-cooperative walk pays where a lane alone would loop
+    // long: a list short enough for a wave per entry (<= 4 096: the tiger's 2 300 curves, a circle's four), or one that is mostly
+    // stroked curves (mmark: two offset curves a walk, a dozen lines a turn); the road map's blobs, joins and caps are 10 % faster
+    // with every lane on its own and the fp64 routines inline.  Known from a finished frame of the scene; before there is one, by
+    // the scene's size (a segment owns at least one word of path data).
+    {
+        const uint64_t n_data = sc.layout.draw_tag_base - sc.layout.path_data_base, n_tags4 = (uint64_t)sc.n_tag_words * 4u;
+        const uint64_t n_seg_max = n_tags4 < n_data ? n_tags4 : n_data;
+        bool coop = n_seg_max <= 16384u;
+        if (sc.heavy_curves >= 0 && sc.stroke_lines >= 0) {
+            const uint64_t nc = (uint64_t)sc.heavy_curves, ns = (uint64_t)sc.heavy_strokes;
+            const uint64_t nl = (uint64_t)sc.stroke_lines < f.stroke_kernel_min_lines ? (uint64_t)sc.stroke_lines : 0u;
+            const uint64_t n_heavy = nc + ns + nl;
+            coop = n_heavy <= 4096u || ns * 2u > n_heavy + nc * 2u;
+        }
+        if (c->debug_flags & VELLO_HIP_DEBUG_FLATTEN_COOP) coop = true;
+        if (c->debug_flags & VELLO_HIP_DEBUG_FLATTEN_ALONE) coop = false;
+        f.flatten_coop = coop;
+    }
     l.frame_generation = sc.generation;
     f.atlas = c->atlas_w ? (const uint32_t *)c->atlas.ptr : nullptr;
     f.atlas_w = c->atlas_w;
@@ -779,6 +801,7 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     // (draw.rs:15-51) makes coarse emit a gradient, image or blur command.
     sc.brushes = false;
     sc.stroke_lines = -1;
+    sc.heavy_curves = sc.heavy_strokes = -1;
     sc.soup_lines = -1;
     sc.slice_demand = -1;
     sc.generation += 1u;
@@ -968,6 +991,8 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
         HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
         if (ctl.bump.failed == 0u) {
             sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            sc.heavy_curves = (int64_t)ctl.heavy_count[0];
+            sc.heavy_strokes = (int64_t)ctl.heavy_count[1];
             sc.soup_lines = (int64_t)ctl.bump.lines;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }
@@ -988,6 +1013,8 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
         SceneSlot &sc = slot_of(c, l);
         if (l.flatten_ran && l.frame_generation == sc.generation) {  // (flatten ran to its end)
             sc.stroke_lines = (int64_t)ctl.heavy_count[2];
+            sc.heavy_curves = (int64_t)ctl.heavy_count[0];
+            sc.heavy_strokes = (int64_t)ctl.heavy_count[1];
             sc.soup_lines = (int64_t)ctl.bump.lines;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }

@@ -101,7 +101,15 @@ __device__ __forceinline__ void flp_store() {}
 
 
 // (out of line ON PURPOSE, round 5: inlined, the fp64 polynomial constants of every copy of these routines are hoisted to the top
-// of the kernel as loop invariants -- hundreds of live registers, spilled to scratch and reloaded at every use)
+// of the kernel as loop invariants -- hundreds of live registers, spilled to scratch and reloaded at every use: 88 VGPRs in the
+// cooperative walk, whose every turn then took twice as long.  The price: a call drains every counter at the callee's entry and
+// redirects the instruction fetch -- round 4's kernels with nothing changed but these calls are 10-20 % slower (k_flatten_main on
+// the road map 64 -> 71 us, r1mix 64 -> 78, mmark-50k 267 -> 321, the tiger 114 -> 124), which is what the road map's flatten pays
+// for the cooperative walk's -37 % on mmark-50k and -26 % on the tiger.  Tried and measured, profiles/r05_ab_flatten_coop.txt: the
+// walk compiled twice (inline routines for lanes on their own, calls under the cooperative walk) in one kernel -- the inline
+// copy's constants spill everywhere, 94 / 100 us -- and the cooperative walk as an out-of-line function of its own with a register
+// allocation of its own -- the kernel spills its state around the call, 120 / 116 us.  Larger out-of-line units (a turn's
+// cubic_from_points_derivs, a point's es_seg_eval_with_offset, an arc's acos + sincos) take a third of the calls back.)
 struct SinCos { float s, c; };
 __device__ __attribute__((noinline)) SinCos fl_sincos_call(float x) { SinCos r; sincos_cr(x, r.s, r.c); return r; }
 __device__ __forceinline__ void fl_sincos(float x, float &s, float &c) { const SinCos r = fl_sincos_call(x); s = r.s; c = r.c; }
@@ -109,6 +117,20 @@ __device__ __forceinline__ float fl_sin(float x) { return fl_sincos_call(x).s; }
 __device__ __attribute__((noinline)) float fl_atan2(float y, float x) { return atan2_cr(y, x); }
 __device__ __attribute__((noinline)) float fl_asin(float x) { return asin_cr(x); }
 __device__ __attribute__((noinline)) float fl_acos(float x) { return acos_cr(x); }
+// flatten_arc's theta = max(min_theta, 2 acos(x)) with its sine and cosine: one call for the three
+struct ArcMath { float theta, sn, cs; };
+__device__ __attribute__((noinline)) ArcMath fl_arc_math(float x, float min_theta) {
+    ArcMath r;
+    r.theta = maxf(min_theta, 2.0f * acos_cr(x));
+    sincos_cr(r.theta, r.sn, r.cs);
+    return r;
+}
+__device__ __forceinline__ ArcMath arc_math_inline(float x, float min_theta) {
+    ArcMath r;
+    r.theta = maxf(min_theta, 2.0f * acos_cr(x));
+    sincos_cr(r.theta, r.sn, r.cs);
+    return r;
+}
 struct CubicParams { float th0, th1, chord_len, err; };
 struct EulerParams { float th0, k0, k1, ch; };
 struct CubicPoints { vec2 p0, p1, p2, p3; };
@@ -256,369 +278,143 @@ __device__ __forceinline__ bool cubic_is_straight(vec2 p0, vec2 p1, vec2 p2, vec
            ay1 * S <= 0.02f * h1x && aoff * ay0 <= 2.5e-3f * h0x * clen && aoff * ay1 <= 2.5e-3f * h1x * clen;
 }
 
-// flatten.wgsl:94-133
-__device__ CubicParams cubic_from_points_derivs(vec2 p0, vec2 p1, vec2 q0, vec2 q1, float dt) {
-    CubicParams r;
-    vec2 chord = p1 - p0;
-    float chord_squared = dot(chord, chord);
-    float chord_len = sqrtf(chord_squared);
-    if (chord_squared < DERIV_THRESH_SQUARED) {
-        float chord_err = sqrtf((9.0f / 32.0f) * (dot(q0, q0) + dot(q1, q1))) * dt;
-        r.th0 = 0.0f; r.th1 = 0.0f; r.chord_len = DERIV_THRESH; r.err = chord_err;
-        return r;
+// (tag helpers: no transcendentals)
+// unpack2x16float()[0]; vello_encoding/src/math.rs:127-150
+__device__ float f16_to_f32(uint32_t bits) {
+    const uint32_t MAGIC = 113u << 23;
+    const uint32_t SHIFTED_EXP = 0x7c00u << 13;
+    uint32_t o = (bits & 0x7fffu) << 13;
+    uint32_t e = SHIFTED_EXP & o;
+    o += (127u - 15u) << 23;
+    if (e == SHIFTED_EXP) {
+        o += (128u - 16u) << 23;
+    } else if (e == 0u) {
+        o += 1u << 23;
+        o = __float_as_uint(__uint_as_float(o) - __uint_as_float(MAGIC));
     }
-    float scale = dt / chord_squared;
-    vec2 h0 = v2(q0.x * chord.x + q0.y * chord.y, q0.y * chord.x - q0.x * chord.y);
-    float th0 = fl_atan2(h0.y, h0.x);
-    float d0 = length(h0) * scale;
-    vec2 h1 = v2(q1.x * chord.x + q1.y * chord.y, q1.x * chord.y - q1.y * chord.x);
-    float th1 = fl_atan2(h1.y, h1.x);
-    float d1 = length(h1) * scale;
-    float cth0, cth1, s0, s1;
-    fl_sincos(th0, s0, cth0);
-    fl_sincos(th1, s1, cth1);
-    float err = 2.0f;
-    if (cth0 * cth1 >= 0.0f) {
-        float e0 = (2.0f / 3.0f) / maxf(1.0f + cth0, 1e-9f);
-        float e1 = (2.0f / 3.0f) / maxf(1.0f + cth1, 1e-9f);
-        float s01 = cth0 * s1 + cth1 * s0;
-        float amin = 0.15f * (2.0f * e0 * s0 + 2.0f * e1 * s1 - e0 * e1 * s01);
-        float a = 0.15f * (2.0f * d0 * s0 + 2.0f * d1 * s1 - d0 * d1 * s01);
-        float aerr = fabsf(a - amin);
-        float symm = fabsf(th0 + th1);
-        float asymm = fabsf(th0 - th1);
-        float dist = length(v2(d0 - e0, d1 - e1));
-        float symm2 = symm * symm;
-        float ctr = (4.625e-6f * symm * symm2 + 7.5e-3f * asymm) * symm2;
-        float halo = (5e-3f * symm + 7e-2f * asymm) * dist;
-        err = ctr + 1.55f * aerr + halo;
-    }
-    err *= chord_len;
-    r.th0 = th0; r.th1 = th1; r.chord_len = chord_len; r.err = err;
+    return __uint_as_float(o | ((bits & 0x8000u) << 16));
+}
+
+struct PathTagData {
+    uint32_t tag_byte;
+    TagMonoid monoid;
+};
+
+__device__ __forceinline__ TagMonoid reduce_tag_f(uint32_t tag_word) {
+    TagMonoid c;
+    uint32_t point_count = tag_word & 0x3030303u;
+    c.pathseg_ix = __popc((point_count * 7u) & 0x4040404u);
+    c.trans_ix = __popc(tag_word & (PATH_TAG_TRANSFORM * 0x1010101u));
+    uint32_t n_points = point_count + ((tag_word >> 2) & 0x1010101u);
+    uint32_t a = n_points + (n_points & (((tag_word >> 3) & 0x1010101u) * 15u));
+    a += a >> 8;
+    a += a >> 16;
+    c.pathseg_offset = a & 0xffu;
+    c.path_ix = __popc(tag_word & (PATH_TAG_PATH * 0x1010101u));
+    c.style_ix = __popc(tag_word & (PATH_TAG_STYLE * 0x1010101u)) * STYLE_SIZE_IN_WORDS;
+    return c;
+}
+
+// flatten.wgsl:684-701
+__device__ PathTagData compute_tag_monoid(const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix) {
+    uint32_t tag_word = scene[cfg.layout.path_tag_base + (ix >> 2)];
+    uint32_t shift = (ix & 3u) * 8u;
+    TagMonoid tm = reduce_tag_f(tag_word & ((1u << shift) - 1u));
+    TagMonoid pre = tag_monoids[ix >> 2];
+    PathTagData r;
+    r.tag_byte = (tag_word >> shift) & 0xffu;
+    r.monoid.trans_ix = pre.trans_ix + tm.trans_ix - 1u;
+    r.monoid.pathseg_ix = pre.pathseg_ix + tm.pathseg_ix;
+    r.monoid.pathseg_offset = pre.pathseg_offset + tm.pathseg_offset;
+    r.monoid.style_ix = pre.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS;
+    r.monoid.path_ix = pre.path_ix + tm.path_ix;
     return r;
 }
 
-// flatten.wgsl:135-158
-__device__ EulerParams es_params_from_angles(float th0, float th1) {
-    EulerParams r;
-    float k0 = th0 + th1;
-    float dth = th1 - th0;
-    float d2 = dth * dth;
-    float k2 = k0 * k0;
-    float a = 6.0f;
-    a -= d2 * (1.0f / 70.0f);
-    a -= (d2 * d2) * (1.0f / 10780.0f);
-    a += (d2 * d2 * d2) * 2.769178184818219e-07f;
-    float b = -0.1f + d2 * (1.0f / 4200.0f) + d2 * d2 * 1.6959677820260655e-05f;
-    float cc = -1.0f / 1400.0f + d2 * 6.84915970574303e-05f - k2 * 7.936475029053326e-06f;
-    a += (b + cc * k2) * k2;
-    float k1 = dth * a;
-    float ch = 1.0f;
-    ch -= d2 * (1.0f / 40.0f);
-    ch += (d2 * d2) * 0.00034226190482569864f;
-    ch -= (d2 * d2 * d2) * 1.9349474568904524e-06f;
-    float b_ = -1.0f / 24.0f + d2 * 0.0024702380951963226f - d2 * d2 * 3.7297408997537985e-05f;
-    float c_ = 1.0f / 1920.0f - d2 * 4.87350869747975e-05f - k2 * 3.1001936068463107e-06f;
-    ch += (b_ + c_ * k2) * k2;
-    r.th0 = th0; r.k0 = k0; r.k1 = k1; r.ch = ch;
-    return r;
+__device__ __forceinline__ vec2 read_f32_point(const uint32_t *pd, uint32_t ix) {
+    return v2(__uint_as_float(pd[ix]), __uint_as_float(pd[ix + 1u]));
+}
+__device__ __forceinline__ vec2 read_i16_point(const uint32_t *pd, uint32_t ix) {
+    uint32_t raw = pd[ix];
+    float x = (float)(((int32_t)(raw << 16)) >> 16);
+    float y = (float)(((int32_t)raw) >> 16);
+    return v2(x, y);
 }
 
-__device__ __forceinline__ float es_params_eval_th(const EulerParams &p, float t) {
-    return (p.k0 + 0.5f * p.k1 * (t - 1.0f)) * t - p.th0;
-}
-
-// flatten.wgsl:165-196
-__device__ vec2 integ_euler_10(float k0, float k1) {
-    float t1_1 = k0;
-    float t1_2 = 0.5f * k1;
-    float t2_2 = t1_1 * t1_1;
-    float t2_3 = 2.0f * (t1_1 * t1_2);
-    float t2_4 = t1_2 * t1_2;
-    float t3_4 = t2_2 * t1_2 + t2_3 * t1_1;
-    float t3_6 = t2_4 * t1_2;
-    float t4_4 = t2_2 * t2_2;
-    float t4_5 = 2.0f * (t2_2 * t2_3);
-    float t4_6 = 2.0f * (t2_2 * t2_4) + t2_3 * t2_3;
-    float t4_7 = 2.0f * (t2_3 * t2_4);
-    float t4_8 = t2_4 * t2_4;
-    float t5_6 = t4_4 * t1_2 + t4_5 * t1_1;
-    float t5_8 = t4_6 * t1_2 + t4_7 * t1_1;
-    float t6_6 = t4_4 * t2_2;
-    float t6_7 = t4_4 * t2_3 + t4_5 * t2_2;
-    float t6_8 = t4_4 * t2_4 + t4_5 * t2_3 + t4_6 * t2_2;
-    float t7_8 = t6_6 * t1_2 + t6_7 * t1_1;
-    float t8_8 = t6_6 * t2_2;
-    float u = 1.0f;
-    u -= (1.0f / 24.0f) * t2_2 + (1.0f / 160.0f) * t2_4;
-    u += (1.0f / 1920.0f) * t4_4 + (1.0f / 10752.0f) * t4_6 + (1.0f / 55296.0f) * t4_8;
-    u -= (1.0f / 322560.0f) * t6_6 + (1.0f / 1658880.0f) * t6_8;
-    u += (1.0f / 92897280.0f) * t8_8;
-    float v = (1.0f / 12.0f) * t1_2;
-    v -= (1.0f / 480.0f) * t3_4 + (1.0f / 2688.0f) * t3_6;
-    v += (1.0f / 53760.0f) * t5_6 + (1.0f / 276480.0f) * t5_8;
-    v -= (1.0f / 11612160.0f) * t7_8;
-    return v2(u, v);
-}
-
-// flatten.wgsl:198-227
-__device__ vec2 es_seg_eval_with_offset(vec2 p0, vec2 p1, const EulerParams &p, float t, float normalized_offset) {
-    float thm = es_params_eval_th(p, t * 0.5f);
-    float k0 = p.k0, k1 = p.k1;
-    vec2 uv = integ_euler_10((k0 + k1 * (0.5f * t - 0.5f)) * t, k1 * t * t);
-    float scale = t / p.ch;
-    float sin_thm, cos_thm, sin_th, cos_th;
-    fl_sincos(thm, sin_thm, cos_thm);
-    float s = scale * sin_thm;
-    float cs = scale * cos_thm;
-    float ex = uv.x * cs - uv.y * s;
-    float ey = -uv.y * cs - uv.x * s;
-    float th = es_params_eval_th(p, t);
-    fl_sincos(th, sin_th, cos_th);
-    vec2 xy = v2(ex + normalized_offset * sin_th, ey + normalized_offset * cos_th);
-    vec2 chord = p1 - p0;
-    return v2(p0.x + (chord.x * xy.x - chord.y * xy.y), p0.y + (chord.x * xy.y + chord.y * xy.x));
-}
-
-__device__ __forceinline__ float pow_1_5_signed(float x) { return x * sqrtf(fabsf(x)); }
-
-constexpr float BREAK1 = 0.8f, BREAK2 = 1.25f, BREAK3 = 2.1f;
-constexpr float SIN_SCALE = 1.0976991822760038f;
-constexpr float QUAD_A1 = 0.6406f, QUAD_B1 = -0.81f, QUAD_C1 = 0.9148117935952064f;
-constexpr float QUAD_A2 = 0.5f, QUAD_B2 = -0.156f, QUAD_C2 = 0.16145779359520596f;
-constexpr float QUAD_W1 = 0.5f * QUAD_B1 / QUAD_A1, QUAD_V1 = 1.0f / QUAD_A1, QUAD_U1 = QUAD_W1 * QUAD_W1 - QUAD_C1 / QUAD_A1;
-constexpr float QUAD_W2 = 0.5f * QUAD_B2 / QUAD_A2, QUAD_V2 = 1.0f / QUAD_A2, QUAD_U2 = QUAD_W2 * QUAD_W2 - QUAD_C2 / QUAD_A2;
-constexpr float FRAC_PI_4 = 0.7853981633974483f;
-constexpr float CBRT_9_8 = 1.040041911525952f;
-constexpr float SQRT8_OVER_3 = 0.9428090415820634f;
-
-// flatten.wgsl:254-266
-__device__ float espc_int_approx(float x) {
-    float y = fabsf(x);
-    float a;
-    if (y < BREAK1) {
-        a = fl_sin(SIN_SCALE * y) * (1.0f / SIN_SCALE);
-    } else if (y < BREAK2) {
-        a = SQRT8_OVER_3 * pow_1_5_signed(y - 1.0f) + FRAC_PI_4;
+// flatten.wgsl:710-764
+__device__ CubicPoints read_path_segment(const uint32_t *pd, const PathTagData &tag, bool is_stroke) {
+    vec2 p0, p1, p2 = v2(0.0f, 0.0f), p3 = v2(0.0f, 0.0f);
+    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
+    uint32_t off = tag.monoid.pathseg_offset;
+    bool is_stroke_cap_marker = is_stroke && (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
+    bool is_open = seg_type == PATH_TAG_QUADTO;
+    if ((tag.tag_byte & PATH_TAG_F32) != 0u) {
+        p0 = read_f32_point(pd, off);
+        p1 = read_f32_point(pd, off + 2u);
+        if (seg_type >= PATH_TAG_QUADTO) {
+            p2 = read_f32_point(pd, off + 4u);
+            if (seg_type == PATH_TAG_CUBICTO) p3 = read_f32_point(pd, off + 6u);
+        }
     } else {
-        float qa = y < BREAK3 ? QUAD_A1 : QUAD_A2;
-        float qb = y < BREAK3 ? QUAD_B1 : QUAD_B2;
-        float qc = y < BREAK3 ? QUAD_C1 : QUAD_C2;
-        a = (qa * y + qb) * y + qc;
-    }
-    return a * signf(x);
-}
-
-// flatten.wgsl:268-282
-__device__ float espc_int_inv_approx(float x) {
-    float y = fabsf(x);
-    float a;
-    if (y < 0.7010707591262915f) {
-        a = fl_asin(y * SIN_SCALE) * (1.0f / SIN_SCALE);
-    } else if (y < 0.903249293595206f) {
-        float b = y - FRAC_PI_4;
-        float u = pow_cr(fabsf(b), 2.0f / 3.0f) * signf(b);
-        a = u * CBRT_9_8 + 1.0f;
-    } else {
-        bool lo = y < 2.038857793595206f;
-        float u = lo ? QUAD_U1 : QUAD_U2;
-        float v = lo ? QUAD_V1 : QUAD_V2;
-        float w = lo ? QUAD_W1 : QUAD_W2;
-        a = sqrtf(u + v * y) - w;
-    }
-    return a * signf(x);
-}
-
-// flatten.wgsl:289-297
-__device__ PointDeriv eval_cubic_and_deriv(vec2 p0, vec2 p1, vec2 p2, vec2 p3, float t) {
-    PointDeriv r;
-    float m = 1.0f - t;
-    float mm = m * m;
-    float mt = m * t;
-    float tt = t * t;
-    vec2 inner = (p1 * (3.0f * mm) + p2 * (3.0f * mt)) + p3 * tt;
-    r.point = p0 * (mm * m) + inner * t;
-    r.deriv = ((p1 - p0) * mm + (p2 - p1) * (2.0f * mt)) + (p3 - p2) * tt;
-    return r;
-}
-
-// flatten.wgsl:299-313
-__device__ vec2 cubic_start_tangent(vec2 p0, vec2 p1, vec2 p2, vec2 p3) {
-    const float EPS = 1e-12f;
-    vec2 d01 = p1 - p0, d02 = p2 - p0, d03 = p3 - p0;
-    if (dot(d01, d01) > EPS) return d01;
-    if (dot(d02, d02) > EPS) return d02;
-    return d03;
-}
-__device__ vec2 cubic_end_tangent(vec2 p0, vec2 p1, vec2 p2, vec2 p3) {
-    const float EPS = 1e-12f;
-    vec2 d23 = p3 - p2, d13 = p3 - p1, d03 = p3 - p0;
-    if (dot(d23, d23) > EPS) return d23;
-    if (dot(d13, d13) > EPS) return d13;
-    return d03;
-}
-
-enum { ESPC_ROBUST_NORMAL = 0, ESPC_ROBUST_LOW_K1 = 1, ESPC_ROBUST_LOW_DIST = 2 };
-
-// flatten.wgsl:328-481.  A stroke calls the reference routine twice (+offset, -offset) and both calls
-// re-derive the identical subdivision of the centre-line cubic; here one walk of the subdivision feeds both
-// offset curves (`two_sided`), which halves the Euler-spiral fitting work of the stroker.  Per side the
-// arithmetic is unchanged, only the order in which lines are appended differs (the soup is unordered).
-__device__ void flatten_euler(Emitter &em, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
-                              float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n) {
-    vec2 p0, p1, p2, p3;
-    float scale;
-    Xform transform;
-    vec2 t_start[2] = {start_p, start_n}, t_end[2] = {end_p, end_n};
-    if (offset == 0.0f) {
-        p0 = xf_apply(local_to_device, cubic.p0);
-        p1 = xf_apply(local_to_device, cubic.p1);
-        p2 = xf_apply(local_to_device, cubic.p2);
-        p3 = xf_apply(local_to_device, cubic.p3);
-        scale = 1.0f;
-        transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
-        t_start[0] = p0;
-        t_end[0] = p3;
-    } else {
-        p0 = cubic.p0; p1 = cubic.p1; p2 = cubic.p2; p3 = cubic.p3;
-        transform = local_to_device;
-        scale = 0.5f * (length(v2(transform.m0 + transform.m3, transform.m1 - transform.m2)) +
-                        length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
-    }
-    if (p0.x == p1.x && p0.y == p1.y && p0.x == p2.x && p0.y == p2.y && p0.x == p3.x && p0.y == p3.y) return;
-    const float tol = 0.25f;
-    const int n_sides = two_sided ? 2 : 1;
-    {
-        // Straight-segment shortcut (exact).  For a nearly straight cubic the general loop below accepts the
-        // whole range [0,1] in its first iteration and emits ONE line t_start -> t_end per side, whatever the
-        // (tiny) tangent angles are.  With q0 = p1-p0, q1 = p3-p2, chord = p3-p0, theta >= |th0|,|th1| (from
-        // |atan(y/x)| <= |y/x|), S = scale*|chord| and |q| <= |chord| (d0,d1 <= 1) the quantities the loop tests
-        // are bounded by  err*scale <= 2.05*theta*S  (tol = 0.25)  and  n_frac*scale_multiplier <=
-        // 4.5*sqrt(theta)*sqrt(S/2)  in each of the three ESPC branches (needs |offset/chord|*theta < 2.5e-3 in
-        // the parallel-curve branch); theta*S <= 0.02 keeps both decisions 2-6x inside their thresholds, far
-        // beyond f32 rounding, so "accept, n = 1" is what the loop would compute.  Polylines (most of a
-        // map-like scene) then cost ~40 flops per pass instead of six fp64 transcendentals.
-        const bool straight = cubic_is_straight(p0, p1, p2, p3, scale, offset);
-        if (straight) {
-            uint32_t line_ix = em.alloc((uint32_t)n_sides);
-            {
-                for (int side = 0; side < n_sides; side++) {
-                    const float off = side ? -offset : offset;
-                    vec2 l0 = off >= 0.0f ? t_start[side] : t_end[side];
-                    vec2 l1 = off >= 0.0f ? t_end[side] : t_start[side];
-                    em.write_xf(line_ix + (uint32_t)side, path_ix, l0, l1, transform);
-                }
-            }
-            flp_mark(FLP_STRAIGHT);
-            return;
+        p0 = read_i16_point(pd, off);
+        p1 = read_i16_point(pd, off + 1u);
+        if (seg_type >= PATH_TAG_QUADTO) {
+            p2 = read_i16_point(pd, off + 2u);
+            if (seg_type == PATH_TAG_CUBICTO) p3 = read_i16_point(pd, off + 3u);
         }
     }
-    uint32_t t0_u = 0u;
-    float dt = 1.0f;
-    vec2 last_p = p0;
-    vec2 last_q = p1 - p0;
-    if (dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
-    float last_t = 0.0f;
-    vec2 lp0[2] = {t_start[0], t_start[1]};
-    for (;;) {
-        float t0 = (float)t0_u * dt;
-        if (t0 == 1.0f) break;
-        float t1 = t0 + dt;
-        vec2 this_p0 = last_p;
-        vec2 this_q0 = last_q;
-        PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
-        if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
-            PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
-            this_pq1.deriv = new_pq1.deriv;
-            if (t1 < 1.0f) {
-                this_pq1.point = new_pq1.point;
-                t1 = t1 - DERIV_EPS;
-            }
-        }
-        float actual_dt = t1 - last_t;
-        CubicParams cp = cubic_from_points_derivs(this_p0, this_pq1.point, this_q0, this_pq1.deriv, actual_dt);
-        flp_mark(FLP_SUBDIV);
-        flp_count(FLC_ITERS, 1u);
-        if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
-            EulerParams ep = es_params_from_angles(cp.th0, cp.th1);
-            float k0 = ep.k0 - 0.5f * ep.k1;
-            float k1 = ep.k1;
-            float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
-#pragma unroll 1
-            for (int side = 0; side < n_sides; side++) {
-                const float off = side ? -offset : offset;
-                float normalized_offset = off / cp.chord_len;
-                float dist_scaled = normalized_offset * ep.ch;
-                float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
-                int robust = ESPC_ROBUST_NORMAL;
-                if (fabsf(k1) < K1_THRESH) {
-                    float k = ep.k0;
-                    n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
-                    robust = ESPC_ROBUST_LOW_K1;
-                } else if (fabsf(dist_scaled) < DIST_THRESH) {
-                    a = k1;
-                    b = k0;
-                    int0 = pow_1_5_signed(b);
-                    float int1 = pow_1_5_signed(a + b);
-                    integral = int1 - int0;
-                    n_frac = (2.0f / 3.0f) * integral / a;
-                    robust = ESPC_ROBUST_LOW_DIST;
-                } else {
-                    a = -2.0f * dist_scaled * k1;
-                    b = -1.0f - 2.0f * dist_scaled * k0;
-                    int0 = espc_int_approx(b);
-                    float int1 = espc_int_approx(a + b);
-                    integral = int1 - int0;
-                    float k_peak = k0 - k1 * b / a;
-                    float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
-                    n_frac = integral * integrand_peak / a;
-                }
-                float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
-                uint32_t n_u = f2u(n);
-                uint32_t line_ix = em.alloc(n_u);
-                flp_mark(FLP_PIECE);
-                flp_count(FLC_PIECES, 1u);
-                flp_count(FLC_EULER_LINES, n_u);
-                {
-                    vec2 lp = lp0[side];
-                    for (uint32_t i = 0; i < n_u; i++) {
-                        vec2 lp1;
-                        if (i + 1u == n_u && t1 == 1.0f) {
-                            lp1 = t_end[side];
-                        } else {
-                            float t = (float)(i + 1u) / n;
-                            float sv = t;
-                            if (robust != ESPC_ROBUST_LOW_K1) {
-                                float u = integral * t + int0;
-                                float inv;
-                                if (robust == ESPC_ROBUST_LOW_DIST) inv = pow_cr(fabsf(u), 2.0f / 3.0f) * signf(u);
-                                else inv = espc_int_inv_approx(u);
-                                sv = (inv - b) / a;
-                            }
-                            lp1 = es_seg_eval_with_offset(this_p0, this_pq1.point, ep, sv, normalized_offset);
-                        }
-                        vec2 l0 = off >= 0.0f ? lp : lp1;
-                        vec2 l1 = off >= 0.0f ? lp1 : lp;
-                        em.write_xf(line_ix + i, path_ix, l0, l1, transform);
-                        lp = lp1;
-                        flp_mark(FLP_EMIT);
-                    }
-                    lp0[side] = lp;
-                }
-            }
-            last_p = this_pq1.point;
-            last_q = this_pq1.deriv;
-            last_t = t1;
-            t0_u += 1u;
-            uint32_t shift = (uint32_t)(__ffs((int)t0_u) - 1);
-            t0_u >>= shift;
-            dt *= (float)(1u << shift);
-        } else {
-            t0_u = t0_u * 2u;
-            dt *= 0.5f;
-        }
+    if (is_stroke_cap_marker && is_open) {
+        p0 = p1;
+        p1 = p2;
+        seg_type = PATH_TAG_LINETO;
     }
+    const float third = 1.0f / 3.0f;
+    if (seg_type == PATH_TAG_LINETO) {
+        p3 = p1;
+        p2 = p3 + (p0 - p3) * third;
+        p1 = p0 + (p3 - p0) * third;
+    } else if (seg_type == PATH_TAG_QUADTO) {
+        p3 = p2;
+        p2 = p1 + (p2 - p1) * third;
+        p1 = p1 + (p0 - p1) * third;
+    }
+    return CubicPoints{p0, p1, p2, p3};
 }
+
+namespace inl {
+#define M_UNIT
+#define M_SINCOS(x, s, c) sincos_cr(x, s, c)
+#define M_SIN(x) sin_cr(x)
+#define M_ATAN2(y, x) atan2_cr(y, x)
+#define M_ASIN(x) asin_cr(x)
+#define M_ACOS(x) acos_cr(x)
+#define M_ARC_MATH(x, m) arc_math_inline(x, m)
+#include "flatten_walk.inc"
+#undef M_UNIT
+#undef M_SINCOS
+#undef M_SIN
+#undef M_ATAN2
+#undef M_ASIN
+#undef M_ACOS
+#undef M_ARC_MATH
+}  // namespace inl
+namespace outl {
+#define M_UNIT __attribute__((noinline))
+#define M_SINCOS(x, s, c) fl_sincos(x, s, c)
+#define M_SIN(x) fl_sin(x)
+#define M_ATAN2(y, x) fl_atan2(y, x)
+#define M_ASIN(x) fl_asin(x)
+#define M_ACOS(x) fl_acos(x)
+#define M_ARC_MATH(x, m) fl_arc_math(x, m)
+#include "flatten_walk.inc"
+#undef M_UNIT
+#undef M_SINCOS
+#undef M_SIN
+#undef M_ATAN2
+#undef M_ASIN
+#undef M_ACOS
+#undef M_ARC_MATH
+}  // namespace outl
 
 // ---- the wave-cooperative form of flatten_euler (round 5) ------------------------------------------------------------------
 // flatten_euler above is one lane walking one curve: the subdivision loop and, per accepted range and side, a loop over the
@@ -664,6 +460,7 @@ __device__ __forceinline__ float shfl_f(float v, uint32_t src) { return __uint_a
 // Called by ALL 64 lanes of a wave (valid = this lane has a curve).  Arguments as flatten_euler's.
 __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, const CubicPoints &cubic, uint32_t path_ix, const Xform &local_to_device,
                                    float offset, vec2 start_p, vec2 end_p, bool two_sided, vec2 start_n, vec2 end_n, uint32_t lane, bool few_entries) {
+    using namespace outl;  // (the walk's pieces with their transcendentals out of line: flatten_walk.inc)
     vec2 p0 = v2(0.0f, 0.0f), p1 = p0, p2 = p0, p3 = p0;
     float scale = 1.0f;
     Xform transform = Xform{1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
@@ -952,287 +749,11 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
     }
 }
 
-// flatten.wgsl:494-521
-__device__ void flatten_arc(Emitter &em, uint32_t path_ix, vec2 begin, vec2 end, vec2 center, float angle,
-                            const Xform &transform) {
-    vec2 p0 = xf_apply(transform, begin);
-    vec2 r = begin - center;
-    const float MIN_THETA = 0.0001f;
-    const float tol = 0.25f;
-    float radius = maxf(tol, length(p0 - xf_apply(transform, center)));
-    float theta = maxf(MIN_THETA, 2.0f * fl_acos(1.0f - tol / radius));
-    uint32_t n_lines = maxu(1u, f2u(ceilf(angle / theta)));
-    uint32_t line_ix = em.alloc(n_lines);
-    {
-        float cs, sn;
-        fl_sincos(theta, sn, cs);
-        flp_mark(FLP_ARC_SETUP);
-        flp_count(FLC_ARCS, 1u);
-        flp_count(FLC_ARC_LINES, n_lines);
-        for (uint32_t i = 0; i < n_lines - 1u; i++) {
-            r = v2(cs * r.x + sn * r.y, -sn * r.x + cs * r.y);
-            vec2 p1 = xf_apply(transform, center + r);
-            em.write(line_ix + i, path_ix, p0, p1);
-            p0 = p1;
-            flp_mark(FLP_ARC_LINES);
-        }
-        vec2 p1 = xf_apply(transform, end);
-        em.write(line_ix + n_lines - 1u, path_ix, p0, p1);
-        flp_mark(FLP_ARC_LINES);
-    }
-}
-
-// flatten.wgsl:523-547
-template <bool WITH_ROUND = true>  // (false: the caller has taken the round style itself -- no arc code in its kernel)
-__device__ void draw_cap(Emitter &em, uint32_t path_ix, uint32_t cap_style, vec2 point, vec2 cap0, vec2 cap1,
-                         vec2 offset_tangent, const Xform &transform) {
-    if (WITH_ROUND && cap_style == STYLE_FLAGS_CAP_ROUND) {
-        flp_mark(FLP_JOIN);
-        flatten_arc(em, path_ix, cap0, cap1, point, 3.1415927f, transform);
-        return;
-    }
-    vec2 start = cap0, end = cap1;
-    bool is_square = cap_style == STYLE_FLAGS_CAP_SQUARE;
-    uint32_t line_ix = em.alloc(is_square ? 3u : 1u);
-    if (is_square) {
-        vec2 v = offset_tangent;
-        vec2 p0 = start + v;
-        vec2 p1 = end + v;
-        em.write_xf(line_ix + 1u, path_ix, start, p0, transform);
-        em.write_xf(line_ix + 2u, path_ix, p1, end, transform);
-        start = p0;
-        end = p1;
-    }
-    em.write_xf(line_ix, path_ix, start, end, transform);
-}
-
-// unpack2x16float()[0]; vello_encoding/src/math.rs:127-150
-__device__ float f16_to_f32(uint32_t bits) {
-    const uint32_t MAGIC = 113u << 23;
-    const uint32_t SHIFTED_EXP = 0x7c00u << 13;
-    uint32_t o = (bits & 0x7fffu) << 13;
-    uint32_t e = SHIFTED_EXP & o;
-    o += (127u - 15u) << 23;
-    if (e == SHIFTED_EXP) {
-        o += (128u - 16u) << 23;
-    } else if (e == 0u) {
-        o += 1u << 23;
-        o = __float_as_uint(__uint_as_float(o) - __uint_as_float(MAGIC));
-    }
-    return __uint_as_float(o | ((bits & 0x8000u) << 16));
-}
-
-// flatten.wgsl:549-631
-template <bool WITH_ROUND = true>
-__device__ void draw_join(Emitter &em, uint32_t path_ix, uint32_t style_flags, vec2 p0, vec2 tan_prev, vec2 tan_next,
-                          vec2 n_prev, vec2 n_next, const Xform &transform) {
-    vec2 front0 = p0 + n_prev;
-    vec2 front1 = p0 + n_next;
-    vec2 back0 = p0 - n_next;
-    vec2 back1 = p0 - n_prev;
-    float cr = tan_prev.x * tan_next.y - tan_prev.y * tan_next.x;
-    float d = dot(tan_prev, tan_next);
-    uint32_t join = style_flags & STYLE_FLAGS_JOIN_MASK;
-    if (join == STYLE_FLAGS_JOIN_BEVEL) {
-        uint32_t ix = em.alloc(2u);
-        em.write_xf(ix, path_ix, front0, front1, transform);
-        em.write_xf(ix + 1u, path_ix, back0, back1, transform);
-    } else if (join == STYLE_FLAGS_JOIN_MITER) {
-        float hyp = length(v2(cr, d));
-        float miter_limit = f16_to_f32(style_flags & STYLE_MITER_LIMIT_MASK);
-        uint32_t line_ix;
-        if (2.0f * hyp < (hyp + d) * miter_limit * miter_limit && fabsf(cr) > TANGENT_THRESH * TANGENT_THRESH) {
-            bool is_backside = cr > 0.0f;
-            vec2 fp_last = is_backside ? back1 : front0;
-            vec2 fp_this = is_backside ? back0 : front1;
-            vec2 p = is_backside ? back0 : front0;
-            vec2 v = fp_this - fp_last;
-            float h = (tan_prev.x * v.y - tan_prev.y * v.x) / cr;
-            vec2 miter_pt = fp_this - tan_next * h;
-            line_ix = em.alloc(3u);
-            em.write_xf(line_ix, path_ix, p, miter_pt, transform);
-            line_ix += 1u;
-            if (is_backside) back0 = miter_pt; else front0 = miter_pt;
-        } else {
-            line_ix = em.alloc(2u);
-        }
-        em.write_xf(line_ix, path_ix, front0, front1, transform);
-        em.write_xf(line_ix + 1u, path_ix, back0, back1, transform);
-    } else if (WITH_ROUND && join == STYLE_FLAGS_JOIN_ROUND) {
-        vec2 arc0, arc1, other0, other1;
-        if (cr > 0.0f) { arc0 = back0; arc1 = back1; other0 = front0; other1 = front1; }
-        else { arc0 = front0; arc1 = front1; other0 = back0; other1 = back1; }
-        const float angle = fabsf(fl_atan2(cr, d));
-        flp_mark(FLP_JOIN);
-        flatten_arc(em, path_ix, arc0, arc1, p0, angle, transform);
-        uint32_t ix = em.alloc(1u);
-        em.write_xf(ix, path_ix, other0, other1, transform);
-    }
-    flp_mark(FLP_JOIN);
-}
-
-struct PathTagData {
-    uint32_t tag_byte;
-    TagMonoid monoid;
-};
-
-__device__ __forceinline__ TagMonoid reduce_tag_f(uint32_t tag_word) {
-    TagMonoid c;
-    uint32_t point_count = tag_word & 0x3030303u;
-    c.pathseg_ix = __popc((point_count * 7u) & 0x4040404u);
-    c.trans_ix = __popc(tag_word & (PATH_TAG_TRANSFORM * 0x1010101u));
-    uint32_t n_points = point_count + ((tag_word >> 2) & 0x1010101u);
-    uint32_t a = n_points + (n_points & (((tag_word >> 3) & 0x1010101u) * 15u));
-    a += a >> 8;
-    a += a >> 16;
-    c.pathseg_offset = a & 0xffu;
-    c.path_ix = __popc(tag_word & (PATH_TAG_PATH * 0x1010101u));
-    c.style_ix = __popc(tag_word & (PATH_TAG_STYLE * 0x1010101u)) * STYLE_SIZE_IN_WORDS;
-    return c;
-}
-
-// flatten.wgsl:684-701
-__device__ PathTagData compute_tag_monoid(const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix) {
-    uint32_t tag_word = scene[cfg.layout.path_tag_base + (ix >> 2)];
-    uint32_t shift = (ix & 3u) * 8u;
-    TagMonoid tm = reduce_tag_f(tag_word & ((1u << shift) - 1u));
-    TagMonoid pre = tag_monoids[ix >> 2];
-    PathTagData r;
-    r.tag_byte = (tag_word >> shift) & 0xffu;
-    r.monoid.trans_ix = pre.trans_ix + tm.trans_ix - 1u;
-    r.monoid.pathseg_ix = pre.pathseg_ix + tm.pathseg_ix;
-    r.monoid.pathseg_offset = pre.pathseg_offset + tm.pathseg_offset;
-    r.monoid.style_ix = pre.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS;
-    r.monoid.path_ix = pre.path_ix + tm.path_ix;
-    return r;
-}
-
-__device__ __forceinline__ vec2 read_f32_point(const uint32_t *pd, uint32_t ix) {
-    return v2(__uint_as_float(pd[ix]), __uint_as_float(pd[ix + 1u]));
-}
-__device__ __forceinline__ vec2 read_i16_point(const uint32_t *pd, uint32_t ix) {
-    uint32_t raw = pd[ix];
-    float x = (float)(((int32_t)(raw << 16)) >> 16);
-    float y = (float)(((int32_t)raw) >> 16);
-    return v2(x, y);
-}
-
-// flatten.wgsl:710-764
-__device__ CubicPoints read_path_segment(const uint32_t *pd, const PathTagData &tag, bool is_stroke) {
-    vec2 p0, p1, p2 = v2(0.0f, 0.0f), p3 = v2(0.0f, 0.0f);
-    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
-    uint32_t off = tag.monoid.pathseg_offset;
-    bool is_stroke_cap_marker = is_stroke && (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
-    bool is_open = seg_type == PATH_TAG_QUADTO;
-    if ((tag.tag_byte & PATH_TAG_F32) != 0u) {
-        p0 = read_f32_point(pd, off);
-        p1 = read_f32_point(pd, off + 2u);
-        if (seg_type >= PATH_TAG_QUADTO) {
-            p2 = read_f32_point(pd, off + 4u);
-            if (seg_type == PATH_TAG_CUBICTO) p3 = read_f32_point(pd, off + 6u);
-        }
-    } else {
-        p0 = read_i16_point(pd, off);
-        p1 = read_i16_point(pd, off + 1u);
-        if (seg_type >= PATH_TAG_QUADTO) {
-            p2 = read_i16_point(pd, off + 2u);
-            if (seg_type == PATH_TAG_CUBICTO) p3 = read_i16_point(pd, off + 3u);
-        }
-    }
-    if (is_stroke_cap_marker && is_open) {
-        p0 = p1;
-        p1 = p2;
-        seg_type = PATH_TAG_LINETO;
-    }
-    const float third = 1.0f / 3.0f;
-    if (seg_type == PATH_TAG_LINETO) {
-        p3 = p1;
-        p2 = p3 + (p0 - p3) * third;
-        p1 = p0 + (p3 - p0) * third;
-    } else if (seg_type == PATH_TAG_QUADTO) {
-        p3 = p2;
-        p2 = p1 + (p2 - p1) * third;
-        p1 = p1 + (p0 - p1) * third;
-    }
-    return CubicPoints{p0, p1, p2, p3};
-}
-
-// One tag: flatten.wgsl:831-923 (body of main).
-// Returns the path index of the tag; the per-tag bbox is left in `em` (invalid = no lines) for the caller.
-__device__ uint32_t flatten_tag(Emitter &em, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
-                                PathBbox *path_bboxes, uint32_t ix) {
-    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
-    uint32_t seg_type = tag.tag_byte & PATH_TAG_SEG_TYPE;
-    uint32_t path_ix = tag.monoid.path_ix;
-    em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
-    // (a PATH marker's draw flags / transform index, flatten.wgsl:813-817: stored by k_pathtag_scan, scan.hip)
-    if (seg_type == 0u) return path_ix;
-    uint32_t style_ix = tag.monoid.style_ix;
-    uint32_t trans_ix = tag.monoid.trans_ix;
-    uint32_t style_flags = scene[(uint32_t)(cfg.layout.style_base + style_ix)];
-    const uint32_t *pd = scene + cfg.layout.path_data_base;
-    bool is_stroke = (style_flags & STYLE_FLAGS_STYLE) != 0u;
-    Xform transform = read_transform(scene, cfg.layout.transform_base, trans_ix);
-    CubicPoints pts = read_path_segment(pd, tag, is_stroke);
-    flp_count(FLC_ENTRIES, 1u);
-    if (is_stroke) {
-        float linewidth = __uint_as_float(scene[cfg.layout.style_base + style_ix + 1u]);
-        float offset = 0.5f * linewidth;
-        bool is_open = seg_type != PATH_TAG_LINETO;
-        bool is_stroke_cap_marker = (tag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
-        if (is_stroke_cap_marker) {
-            if (is_open) {
-                vec2 tangent = pts.p3 - pts.p0;
-                vec2 offset_tangent = normalize(tangent) * offset;
-                vec2 n = v2(-offset_tangent.y, offset_tangent.x);
-                draw_cap(em, path_ix, (style_flags & STYLE_FLAGS_START_CAP_MASK) >> 2, pts.p0, pts.p0 - n, pts.p0 + n,
-                               -offset_tangent, transform);
-            }
-        } else {
-            // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
-            PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
-            CubicPoints npts = read_path_segment(pd, ntag, true);
-            bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
-            bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
-            bool do_join = !n_is_marker || n_is_closed;
-            vec2 n_tangent = npts.p3 - npts.p0;
-            if (!n_is_marker) n_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
-
-            vec2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
-            if (dot(tan_start, tan_start) < TANGENT_THRESH * TANGENT_THRESH) tan_start = v2(TANGENT_THRESH, 0.0f);
-            vec2 tan_prev = cubic_end_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
-            if (dot(tan_prev, tan_prev) < TANGENT_THRESH * TANGENT_THRESH) tan_prev = v2(TANGENT_THRESH, 0.0f);
-            vec2 tan_next = n_tangent;
-            if (dot(tan_next, tan_next) < TANGENT_THRESH * TANGENT_THRESH) tan_next = v2(TANGENT_THRESH, 0.0f);
-            vec2 n_start = normalize(v2(-tan_start.y, tan_start.x)) * offset;
-            vec2 offset_tangent = normalize(tan_prev) * offset;
-            vec2 n_prev = v2(-offset_tangent.y, offset_tangent.x);
-            vec2 tnn = normalize(tan_next) * offset;
-            vec2 n_next = v2(-tnn.y, tnn.x);
-
-            flp_mark(FLP_TAG);
-            flatten_euler(em, pts, path_ix, transform, offset, pts.p0 + n_start, pts.p3 + n_prev, true, pts.p0 - n_start,
-                                pts.p3 - n_prev);
-            flp_mark(FLP_SUBDIV);  // (the loop's exit test, and the lanes that waited for the wave's longest walk)
-            if (do_join) {
-                draw_join(em, path_ix, style_flags, pts.p3, tan_prev, tan_next, n_prev, n_next, transform);
-            } else {
-                draw_cap(em, path_ix, style_flags & STYLE_FLAGS_END_CAP_MASK, pts.p3, pts.p3 + n_prev, pts.p3 - n_prev,
-                               offset_tangent, transform);
-            }
-        }
-    } else {
-        flp_mark(FLP_TAG);
-        flatten_euler(em, pts, path_ix, transform, 0.0f, pts.p0, pts.p3, false, pts.p0, pts.p3);
-        flp_mark(FLP_SUBDIV);
-    }
-    return path_ix;
-}
-
 // flatten_tag for a whole wave (has_tag = this lane has a list entry): the same three steps -- decode, the two offset curves (or
 // the fill's curve), join or cap -- with the middle one taken by all 64 lanes together (flatten_euler_coop).
 __device__ uint32_t flatten_tag_coop(Emitter &em, EulerCoopLds &cl, bool has_tag, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                      uint32_t ix, uint32_t lane, bool few_entries) {
+    using namespace outl;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
     uint32_t path_ix = 0xffffffffu, style_flags = 0u;
     bool euler = false, two_sided = false, start_cap = false, do_join = false, end_cap = false;
@@ -1510,6 +1031,7 @@ __device__ __forceinline__ bool stroke_arc_one_line(Emitter &em, uint32_t path_i
 // false when the segment is not straight (the heavy kernel takes it).  Arcs that need the exact path are pushed to `q`.
 __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
                                      uint32_t ix, uint32_t &path_ix_out) {
+    using namespace inl;  // (tangents, joins and caps without arcs: no transcendentals either way)
     PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     const uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
@@ -1690,7 +1212,7 @@ constexpr uint32_t HEAVY_FIRST = 1u, HEAVY_SET_ASIDE = 2u;
 #define VK_FL_LPW_DIV 1024u          // a long list is spread over this many waves ...
 #define VK_FL_LPW_DIV_STROKES 3072u  // ... a list with many stroked curves over this many (sweep constants)
 #endif
-template <uint32_t LISTS>
+template <uint32_t LISTS, bool COOP>
 __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES> &sh, EulerCoopLds *coop, uint32_t block, uint32_t n_blocks, const Config &cfg, uint32_t n_tags,
                                                  const uint32_t *__restrict__ scene, const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                  Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
@@ -1768,11 +1290,11 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
                      : e3 < n_handed  ? heavy_list[3u * n_tags + e3]
                                       : heavy_list[2u * n_tags + e2];
         }
-        // (a dense list without stroked curves -- the road map's blobs, joins and caps -- takes flatten_tag, every lane on its own:
-        // nothing there for the lanes to share, and the plain routine is 5-10 % less code on the way; launch-uniform)
+        // (COOP is the host's choice for the scene, engine.hip Frame::flatten_coop: the kernels of the cooperative walk, with the fp64
+        // routines out of line, or round 4's, every lane on its own with the routines inline -- flatten_walk.inc's head says why)
         uint32_t tag_key = 0u;
-        if (lpw <= 4u || lpw_div == VK_FL_LPW_DIV_STROKES) tag_key = flatten_tag_coop(em, coop[tid >> 6], has_tag, cfg, scene, tag_monoids, tag_ix, lane, lpw <= 4u);
-        else if (has_tag) tag_key = flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
+        if (COOP) tag_key = flatten_tag_coop(em, coop[tid >> 6], has_tag, cfg, scene, tag_monoids, tag_ix, lane, lpw <= 4u);
+        else if (has_tag) tag_key = inl::flatten_tag(em, cfg, scene, tag_monoids, path_bboxes, tag_ix);
         if (has_tag) {
             key = tag_key;
             if (em.bx1 > em.bx0 || em.by1 > em.by0) {
@@ -1784,8 +1306,13 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
             const ArcItem it = reinterpret_cast<const ArcItem *>(arc_items)[arc_shard * arc_shard_cap + arc_local];
             em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
             const Xform t = read_transform(scene, cfg.layout.transform_base, it.trans_ix);
-            const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(fl_atan2(it.cr, it.d));
-            flatten_arc(em, it.path_ix, v2(it.bx, it.by), v2(it.ex, it.ey), v2(it.cx, it.cy), angle, t);
+            if (COOP) {
+                const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(fl_atan2(it.cr, it.d));
+                outl::flatten_arc(em, it.path_ix, v2(it.bx, it.by), v2(it.ex, it.ey), v2(it.cx, it.cy), angle, t);
+            } else {
+                const float angle = (it.flags & ARC_IS_CAP) != 0u ? 3.1415927f : fabsf(atan2_cr(it.cr, it.d));
+                inl::flatten_arc(em, it.path_ix, v2(it.bx, it.by), v2(it.ex, it.ey), v2(it.cx, it.cy), angle, t);
+            }
             key = it.path_ix;
             const float mx0 = minf(em.bx0, it.box[0]), my0 = minf(em.by0, it.box[1]), mx1 = maxf(em.bx1, it.box[2]), my1 = maxf(em.by1, it.box[3]);
             if (mx1 > mx0 || my1 > my0) {
@@ -1801,6 +1328,7 @@ __device__ __forceinline__ void heavy_workgroups(FlattenShared<FLATTEN_LDS_LINES
     flp_store();
 }
 
+template <bool COOP>
 __global__ void __launch_bounds__(256, 2) k_flatten_main(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                          Control *control, LineSoup *lines, uint32_t *heavy_list,
@@ -1809,7 +1337,7 @@ __global__ void __launch_bounds__(256, 2) k_flatten_main(Config cfg, uint32_t n_
     __shared__ __attribute__((aligned(16))) unsigned char smem[FLATTEN_MAIN_LDS];
     if (blockIdx.x < n_heavy_blocks) {
         // (the heavy workgroups keep their four waves' EulerCoopLds where the stroke workgroups keep their arc queue)
-        heavy_workgroups<HEAVY_FIRST>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), reinterpret_cast<EulerCoopLds *>(smem + FLATTEN_ARCS_AT),
+        heavy_workgroups<HEAVY_FIRST, COOP>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem), reinterpret_cast<EulerCoopLds *>(smem + FLATTEN_ARCS_AT),
                                       blockIdx.x, n_heavy_blocks, cfg, n_tags, scene, tag_monoids,
                                       path_bboxes, control, lines, heavy_list, stroke_kernel_min_lines, arc_items, arc_shard_cap);
     } else {
@@ -1824,8 +1352,8 @@ __global__ void __launch_bounds__(256, 2) k_flatten_tail(Config cfg, uint32_t n_
                                                          Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
                                                          const uint32_t *__restrict__ arc_items, uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
-    __shared__ EulerCoopLds coop[4];
-    heavy_workgroups<HEAVY_SET_ASIDE>(sh, coop, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, 0u, arc_items,
+    // (what the stroke workgroups set aside -- arcs, and lines that were not straight after all: every lane on its own)
+    heavy_workgroups<HEAVY_SET_ASIDE, false>(sh, nullptr, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list, 0u, arc_items,
                                       arc_shard_cap);
 }
 
@@ -1843,14 +1371,15 @@ __global__ void __launch_bounds__(256) k_flatten_strokes(Config cfg, uint32_t n_
                      arc_shard_cap);
 }
 
+template <bool COOP>
 __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                           Control *control, LineSoup *lines, const uint32_t *__restrict__ heavy_list,
                                                           uint32_t stroke_kernel_min_lines, const uint32_t *__restrict__ arc_items,
                                                           uint32_t arc_shard_cap) {
     __shared__ FlattenShared<FLATTEN_LDS_LINES> sh;
-    __shared__ EulerCoopLds coop[4];
-    heavy_workgroups<HEAVY_FIRST | HEAVY_SET_ASIDE>(sh, coop, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list,
+    __shared__ EulerCoopLds coop[COOP ? 4 : 1];
+    heavy_workgroups<HEAVY_FIRST | HEAVY_SET_ASIDE, COOP>(sh, coop, blockIdx.x, gridDim.x, cfg, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list,
                                                     stroke_kernel_min_lines, arc_items, arc_shard_cap);
 }
 
@@ -1898,8 +1427,12 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
     const uint32_t arc_shard_cap = flatten_arc_shard_cap(n_seg_max, f.flatten_side_by_side);
     const uint32_t min_lines = f.launch_stroke_kernel ? f.stroke_kernel_min_lines : 0xffffffffu;  // (no stroke workgroups: every line is the heavy ones')
     if (f.flatten_side_by_side) {
-        hipLaunchKernelGGL(k_flatten_main, dim3(grid_heavy + grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
-                           f.control, f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap, grid_heavy);
+        if (f.flatten_coop)
+            hipLaunchKernelGGL(k_flatten_main<true>, dim3(grid_heavy + grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
+                               f.control, f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap, grid_heavy);
+        else
+            hipLaunchKernelGGL(k_flatten_main<false>, dim3(grid_heavy + grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
+                               f.control, f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap, grid_heavy);
         if (mid) (void)hipEventRecord(mid[1], s);
         // what the stroke workgroups set aside (arcs: a few per cent of the lines; handed-on lines: nearly none)
         if (grid_strokes != 0u) {
@@ -1914,8 +1447,12 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
             hipLaunchKernelGGL(k_flatten_strokes, dim3(grid_strokes), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes,
                                f.control, f.lines, f.heavy_list, f.stroke_kernel_min_lines, f.arc_items, arc_shard_cap);
         if (mid) (void)hipEventRecord(mid[1], s);
-        hipLaunchKernelGGL(k_flatten_heavy, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                           f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap);
+        if (f.flatten_coop)
+            hipLaunchKernelGGL(k_flatten_heavy<true>, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                               f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap);
+        else
+            hipLaunchKernelGGL(k_flatten_heavy<false>, dim3(grid_heavy), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                               f.lines, f.heavy_list, min_lines, f.arc_items, arc_shard_cap);
     }
 }
 
