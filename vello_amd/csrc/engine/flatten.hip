@@ -444,6 +444,8 @@ struct EulerCoopLds {
     uint32_t bbox[64][4];     // per owner lane: min x, min y, max x, max y of every point written for it (f32_ordered)
     float endpt[64][2][2];    // per owner lane and side: the last point of the newest range (local coordinates)
     EulerPiece piece[EC_PIECES];
+    uint32_t lp_stack[32];    // level-parallel walk: the ranges still to be looked at, (level << 16 | range number at that level); the top is next
+    uint32_t lp_end_at[36];   // ... which lane's leaf ends at position p (in 32nds of the turn's range)
 };
 __device__ __forceinline__ uint32_t f32_ordered(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -539,99 +541,228 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
     if (active && dot(last_q, last_q) < DERIV_THRESH_SQUARED) last_q = eval_cubic_and_deriv(p0, p1, p2, p3, DERIV_EPS).deriv;
     float last_t = 0.0f;
     vec2 lp0[2] = {t_start[0], t_start[1]};
-    const uint32_t off_fwd = (offset >= 0.0f ? 1u : 0u) | ((-offset) >= 0.0f ? 2u : 0u);  // `off >= 0` of side 0 / side 1
-    while (FL_WAVE_ANY(active)) {
-        // ---- one turn of every active lane's walk (flatten.wgsl:395-446) ----
+    uint32_t off_fwd = (offset >= 0.0f ? 1u : 0u) | ((-offset) >= 0.0f ? 2u : 0u);  // `off >= 0` of side 0 / side 1
+    // ---- A wave with ONE curve (the tiger: a wave per curve) walks it LEVEL-PARALLEL.  In lockstep such a wave still pays a turn per
+    // range it tests -- the tiger's launch was as long as its longest curve's chain of turns -- but whether a range [t0, t0 + dt] is
+    // accepted is a pure function of the range as long as no DERIV_EPS nudge fires (its end points and derivatives are the cubic's at
+    // t0 and t0 + dt: what the previous range left in last_p / last_q is that same evaluation), and the ranges the walk accepts are
+    // exactly those that pass while every dyadic ancestor fails.  So lane j of the wave takes node j of the dyadic tree under the
+    // range on top of a small stack -- five levels, 63 ranges at once -- and one turn decides them all: the accepted leaves up to the
+    // first range that needs more than five levels are flattened in ONE pass (each leaf's first point is its predecessor's last,
+    // through LDS); that range goes back on the stack for a turn of its own, in front of the blocks to its right.  A tiny derivative
+    // anywhere in a turn sends the curve to the lockstep walk from where it stands (the reference's nudges depend on the order).
+    const unsigned long long m_active = __ballot(active);
+    bool lp_mode = few_entries && __popcll(m_active) == 1;
+    const uint32_t lp_owner = lp_mode ? (uint32_t)__ffsll((long long)m_active) - 1u : 0u;
+    uint32_t lp_sp = 0u;  // (wave-uniform)
+    if (lp_mode) {
+        // every lane holds the curve
+        p0 = v2(shfl_f(p0.x, lp_owner), shfl_f(p0.y, lp_owner)); p1 = v2(shfl_f(p1.x, lp_owner), shfl_f(p1.y, lp_owner));
+        p2 = v2(shfl_f(p2.x, lp_owner), shfl_f(p2.y, lp_owner)); p3 = v2(shfl_f(p3.x, lp_owner), shfl_f(p3.y, lp_owner));
+        scale = shfl_f(scale, lp_owner);
+        offset = shfl_f(offset, lp_owner);
+        two_sided = wave_shfl(two_sided ? 1u : 0u, lp_owner) != 0u;
+        off_fwd = wave_shfl(off_fwd, lp_owner);
+        path_ix = wave_shfl(path_ix, lp_owner);
+        transform.m0 = shfl_f(transform.m0, lp_owner); transform.m1 = shfl_f(transform.m1, lp_owner); transform.m2 = shfl_f(transform.m2, lp_owner);
+        transform.m3 = shfl_f(transform.m3, lp_owner); transform.t0 = shfl_f(transform.t0, lp_owner); transform.t1 = shfl_f(transform.t1, lp_owner);
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++) {
+            t_end[sd] = v2(shfl_f(t_end[sd].x, lp_owner), shfl_f(t_end[sd].y, lp_owner));
+            lp0[sd] = v2(shfl_f(lp0[sd].x, lp_owner), shfl_f(lp0[sd].y, lp_owner));
+        }
+        last_q = v2(shfl_f(last_q.x, lp_owner), shfl_f(last_q.y, lp_owner));  // (the derivative at t = 0 as the walk starts with it)
+        if (lane == 0u) cl.lp_stack[0] = 0u;  // the whole curve: level 0, range 0
+        lp_sp = 1u;
+        active = false;
+        wave_lds_sync();
+    }
+    for (;;) {
         bool push = false, is_last = false;
+        uint32_t pred = 64u;  // the lane whose range ends where this lane's begins (its last point is this range's first); 64: lp0
+        uint32_t lp_last = 64u;
         vec2 this_p0 = v2(0.0f, 0.0f), this_p1 = this_p0;
         EulerParams ep{0.0f, 0.0f, 0.0f, 1.0f};
         float noff = 0.0f;
         float s_a[2] = {0.0f, 0.0f}, s_b[2] = {0.0f, 0.0f}, s_integral[2] = {0.0f, 0.0f}, s_int0[2] = {0.0f, 0.0f}, s_n[2] = {1.0f, 1.0f};
         uint32_t s_robust[2] = {0u, 0u}, s_nu[2] = {0u, 0u}, s_line[2] = {0u, 0u};
-        if (active) {
-            const float t0 = (float)t0_u * dt;
-            if (t0 == 1.0f) {
-                active = false;
-            } else {
-                float t1 = t0 + dt;
-                PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
-                if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
-                    PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
-                    this_pq1.deriv = new_pq1.deriv;
-                    if (t1 < 1.0f) {
-                        this_pq1.point = new_pq1.point;
-                        t1 = t1 - DERIV_EPS;
-                    }
-                }
-                const float actual_dt = t1 - last_t;
-                const CubicParams cp = cubic_from_points_derivs(last_p, this_pq1.point, last_q, this_pq1.deriv, actual_dt);
-                flp_mark(FLP_SUBDIV);
-                flp_count(FLC_ITERS, 1u);
-                if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
-                    ep = es_params_from_angles(cp.th0, cp.th1);
-                    const float k0 = ep.k0 - 0.5f * ep.k1;
-                    const float k1 = ep.k1;
-                    const float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
-                    noff = offset / cp.chord_len;
+        // an accepted range [this_p0, this_p1] of chord parameters cp: its Euler segment, per side the integrals and the number of
+        // lines, the lines' places (flatten.wgsl:421-446)
+        auto accept = [&](const CubicParams &cp) {
+            ep = es_params_from_angles(cp.th0, cp.th1);
+            const float k0 = ep.k0 - 0.5f * ep.k1;
+            const float k1 = ep.k1;
+            const float scale_multiplier = sqrtf(0.125f * scale * cp.chord_len / (ep.ch * tol));
+            noff = offset / cp.chord_len;
 #pragma unroll
-                    for (int side = 0; side < 2; side++) {
-                        if (side == 1 && !two_sided) break;
-                        const float off = side ? -offset : offset;
-                        const float normalized_offset = off / cp.chord_len;
-                        const float dist_scaled = normalized_offset * ep.ch;
-                        float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
-                        uint32_t robust = ESPC_ROBUST_NORMAL;
-                        if (fabsf(k1) < K1_THRESH) {
-                            const float k = ep.k0;
-                            n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
-                            robust = ESPC_ROBUST_LOW_K1;
-                        } else if (fabsf(dist_scaled) < DIST_THRESH) {
-                            a = k1;
-                            b = k0;
-                            int0 = pow_1_5_signed(b);
-                            const float int1 = pow_1_5_signed(a + b);
-                            integral = int1 - int0;
-                            n_frac = (2.0f / 3.0f) * integral / a;
-                            robust = ESPC_ROBUST_LOW_DIST;
-                        } else {
-                            a = -2.0f * dist_scaled * k1;
-                            b = -1.0f - 2.0f * dist_scaled * k0;
-                            int0 = espc_int_approx(b);
-                            const float int1 = espc_int_approx(a + b);
-                            integral = int1 - int0;
-                            const float k_peak = k0 - k1 * b / a;
-                            const float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
-                            n_frac = integral * integrand_peak / a;
-                        }
-                        const float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
-                        s_a[side] = a; s_b[side] = b; s_integral[side] = integral; s_int0[side] = int0; s_n[side] = n;
-                        s_robust[side] = robust;
-                        s_nu[side] = f2u(n);
-                        s_line[side] = em.alloc(s_nu[side]);
-                        flp_count(FLC_PIECES, 1u);
-                        flp_count(FLC_EULER_LINES, s_nu[side]);
-                    }
-                    flp_mark(FLP_PIECE);
-                    push = true;
-                    is_last = t1 == 1.0f;
-                    this_p0 = last_p;
-                    this_p1 = this_pq1.point;
-                    last_p = this_pq1.point;
-                    last_q = this_pq1.deriv;
-                    last_t = t1;
-                    t0_u += 1u;
-                    const uint32_t shift = (uint32_t)(__ffs((int)t0_u) - 1);
-                    t0_u >>= shift;
-                    dt *= (float)(1u << shift);
+            for (int side = 0; side < 2; side++) {
+                if (side == 1 && !two_sided) break;
+                const float off = side ? -offset : offset;
+                const float normalized_offset = off / cp.chord_len;
+                const float dist_scaled = normalized_offset * ep.ch;
+                float a = 0.0f, b = 0.0f, integral = 0.0f, int0 = 0.0f, n_frac;
+                uint32_t robust = ESPC_ROBUST_NORMAL;
+                if (fabsf(k1) < K1_THRESH) {
+                    const float k = ep.k0;
+                    n_frac = sqrtf(fabsf(k * (k * dist_scaled + 1.0f)));
+                    robust = ESPC_ROBUST_LOW_K1;
+                } else if (fabsf(dist_scaled) < DIST_THRESH) {
+                    a = k1;
+                    b = k0;
+                    int0 = pow_1_5_signed(b);
+                    const float int1 = pow_1_5_signed(a + b);
+                    integral = int1 - int0;
+                    n_frac = (2.0f / 3.0f) * integral / a;
+                    robust = ESPC_ROBUST_LOW_DIST;
                 } else {
-                    t0_u = t0_u * 2u;
-                    dt *= 0.5f;
+                    a = -2.0f * dist_scaled * k1;
+                    b = -1.0f - 2.0f * dist_scaled * k0;
+                    int0 = espc_int_approx(b);
+                    const float int1 = espc_int_approx(a + b);
+                    integral = int1 - int0;
+                    const float k_peak = k0 - k1 * b / a;
+                    const float integrand_peak = sqrtf(fabsf(k_peak * (k_peak * dist_scaled + 1.0f)));
+                    n_frac = integral * integrand_peak / a;
+                }
+                const float n = clampf(ceilf(n_frac * scale_multiplier), 1.0f, 100.0f);
+                s_a[side] = a; s_b[side] = b; s_integral[side] = integral; s_int0[side] = int0; s_n[side] = n;
+                s_robust[side] = robust;
+                s_nu[side] = f2u(n);
+                s_line[side] = em.alloc(s_nu[side]);
+                flp_count(FLC_PIECES, 1u);
+                flp_count(FLC_EULER_LINES, s_nu[side]);
+            }
+            flp_mark(FLP_PIECE);
+            push = true;
+        };
+        if (lp_mode) {
+            if (lp_sp == 0u) break;  // the curve is done
+            // ---- one level-parallel turn: the range on top of the stack and its descendants down five levels ----
+            lp_sp -= 1u;
+            const uint32_t top = cl.lp_stack[lp_sp];  // (one address for the wave)
+            const uint32_t r_level = top >> 16, r_t0u = top & 0xffffu;
+            const uint32_t j = lane;  // node j of the tree (1 = the range itself; lane 0 has none)
+            const uint32_t d = j ? 31u - (uint32_t)__builtin_clz(j) : 0u, k = j ? j - (1u << d) : 0u;
+            const uint32_t lvl = r_level + d;
+            const bool node = j != 0u && lvl <= 16u;  // (a range of 2^-16 is accepted whatever it looks like: nothing below it)
+            float dt_j = 1.0f;
+            for (uint32_t q = 0; q < lvl; q++) dt_j *= 0.5f;  // (as the walk halves it: exact)
+            const uint32_t t0u_j = (r_t0u << d) + k;
+            const float ts = (float)t0u_j * dt_j;
+            const float te = ts + dt_j;
+            PointDeriv qa, qb = eval_cubic_and_deriv(p0, p1, p2, p3, te);
+            if (t0u_j == 0u) {
+                qa.point = p0;      // (the walk starts from p0 itself and from last_q as set up above, not from an evaluation at 0)
+                qa.deriv = last_q;
+            } else {
+                qa = eval_cubic_and_deriv(p0, p1, p2, p3, ts);
+            }
+            const bool tiny = node && ((t0u_j != 0u && dot(qa.deriv, qa.deriv) < DERIV_THRESH_SQUARED) || dot(qb.deriv, qb.deriv) < DERIV_THRESH_SQUARED);
+            if (FL_WAVE_ANY(tiny)) {
+                // a nudge somewhere under this range: the owner walks on from the range's start, alone, in lockstep's code
+                lp_mode = false;
+                active = lane == lp_owner;
+                t0_u = r_t0u;
+                dt = 1.0f;
+                for (uint32_t q = 0; q < r_level; q++) dt *= 0.5f;
+                last_t = (float)t0_u * dt;
+                if (t0_u == 0u) {
+                    last_p = p0;  // (last_q: as set up above)
+                } else {
+                    const PointDeriv st = eval_cubic_and_deriv(p0, p1, p2, p3, last_t);
+                    last_p = st.point;
+                    last_q = st.deriv;
+                }
+                continue;
+            }
+            const CubicParams cp = cubic_from_points_derivs(qa.point, qb.point, qa.deriv, qb.deriv, te - ts);
+            flp_mark(FLP_SUBDIV);
+            flp_count(FLC_ITERS, node ? 1u : 0u);
+            const bool pass = node && (cp.err * scale <= tol || dt_j <= SUBDIV_LIMIT);
+            const unsigned long long m_pass = __ballot(pass);
+            bool anc_pass = false;
+            for (uint32_t a = j >> 1; a >= 1u; a >>= 1) anc_pass = anc_pass || ((m_pass >> a) & 1ull) != 0ull;
+            const bool leaf = pass && !anc_pass;
+            const bool unres = node && d == 5u && !pass && !anc_pass;
+            const unsigned long long m_unres = __ballot(unres);  // (lanes 32 .. 63 are the level-5 ranges in t order)
+            const uint32_t u_lane = m_unres ? (uint32_t)__ffsll((long long)m_unres) - 1u : 64u;
+            const uint32_t limit = m_unres ? u_lane - 32u : 32u;  // in 32nds of the range: what lies before the first unresolved range
+            const uint32_t span32 = 32u >> d, start_pos = k * span32, end_pos = start_pos + span32;
+            const bool take = leaf && end_pos <= limit;
+            // who ends where (a leaf's first point is the last point of the leaf that ends where it begins)
+            wave_lds_sync();
+            if (take) cl.lp_end_at[end_pos] = lane;
+            wave_lds_sync();
+            if (take && start_pos != 0u) pred = cl.lp_end_at[start_pos];
+            if (limit != 0u) lp_last = cl.lp_end_at[limit];  // (all of [0, limit) is leaves: one of them ends at limit)
+            if (take) {
+                this_p0 = qa.point;
+                this_p1 = qb.point;
+                is_last = te == 1.0f;
+                accept(cp);
+            }
+            // the stack: the unresolved range on top, the blocks to its right below it, the leftmost of them uppermost
+            if (m_unres != 0ull) {
+                const uint32_t ku = u_lane - 32u;
+                if (lane == 0u) {
+                    uint32_t sp = lp_sp;
+                    for (uint32_t dd = 1u; dd <= 5u; dd++) {
+                        const uint32_t a = ku >> (5u - dd);  // the unresolved range's ancestor at depth dd (itself at 5)
+                        if ((a & 1u) == 0u) cl.lp_stack[sp++] = ((r_level + dd) << 16) | ((r_t0u << dd) + a + 1u);
+                    }
+                    cl.lp_stack[sp++] = ((r_level + 5u) << 16) | ((r_t0u << 5) + ku);
+                }
+                uint32_t n_push = 1u;
+                for (uint32_t dd = 1u; dd <= 5u; dd++) n_push += ((ku >> (5u - dd)) & 1u) == 0u ? 1u : 0u;
+                lp_sp += n_push;
+                wave_lds_sync();
+            }
+        } else {
+            if (!FL_WAVE_ANY(active)) break;
+            // ---- one turn of every active lane's walk (flatten.wgsl:395-446) ----
+            if (active) {
+                const float t0 = (float)t0_u * dt;
+                if (t0 == 1.0f) {
+                    active = false;
+                } else {
+                    float t1 = t0 + dt;
+                    PointDeriv this_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1);
+                    if (dot(this_pq1.deriv, this_pq1.deriv) < DERIV_THRESH_SQUARED) {
+                        PointDeriv new_pq1 = eval_cubic_and_deriv(p0, p1, p2, p3, t1 - DERIV_EPS);
+                        this_pq1.deriv = new_pq1.deriv;
+                        if (t1 < 1.0f) {
+                            this_pq1.point = new_pq1.point;
+                            t1 = t1 - DERIV_EPS;
+                        }
+                    }
+                    const float actual_dt = t1 - last_t;
+                    const CubicParams cp = cubic_from_points_derivs(last_p, this_pq1.point, last_q, this_pq1.deriv, actual_dt);
+                    flp_mark(FLP_SUBDIV);
+                    flp_count(FLC_ITERS, 1u);
+                    if (cp.err * scale <= tol || dt <= SUBDIV_LIMIT) {
+                        this_p0 = last_p;
+                        this_p1 = this_pq1.point;
+                        is_last = t1 == 1.0f;
+                        accept(cp);
+                        last_p = this_pq1.point;
+                        last_q = this_pq1.deriv;
+                        last_t = t1;
+                        t0_u += 1u;
+                        const uint32_t shift = (uint32_t)(__ffs((int)t0_u) - 1);
+                        t0_u >>= shift;
+                        dt *= (float)(1u << shift);
+                    } else {
+                        t0_u = t0_u * 2u;
+                        dt *= 0.5f;
+                    }
                 }
             }
         }
         unsigned long long pending = __ballot(push);
+        if (pending == 0ull) continue;
         // ---- the lines of the ranges accepted in this turn, a point per lane (flatten.wgsl:447-470): the owners leave their ranges in
         // LDS (EC_PIECES at a time, by rank among the accepting lanes), every lane takes points ----
+        const uint32_t box_lp = lp_mode ? lp_owner : 64u;  // (level-parallel: every range is the one curve's)
         while (pending != 0ull) {
             const uint32_t rank = mask_rank_below(pending, lane);
             const bool mine = push && ((pending >> lane) & 1ull) != 0ull && rank < EC_PIECES;
@@ -679,8 +810,8 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
                 const uint32_t robust = (e_flags >> (side * 2u)) & 3u;
                 const bool e_last = (e_flags & 16u) != 0u, fwd = ((e_flags >> (5u + side)) & 1u) != 0u;
                 const float normalized_offset = side ? -pc.noff : pc.noff;
-                // (what does not change from turn to turn stays in the owner's registers: the curve's end and start points, its
-                // transform and path; every lane takes part in a ds_bpermute, so they are fetched outside the branches)
+                // (what does not change from turn to turn stays in the owner's registers: the curve's end points, its transform and
+                // path; every lane takes part in a ds_bpermute, so they are fetched outside the branches)
                 const vec2 te0 = v2(shfl_f(t_end[0].x, owner), shfl_f(t_end[0].y, owner)), te1 = v2(shfl_f(t_end[1].x, owner), shfl_f(t_end[1].y, owner));
                 vec2 lp1;
                 if (i + 1u == n_u && e_last) {
@@ -701,10 +832,10 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
                 e_t.m0 = shfl_f(transform.m0, owner); e_t.m1 = shfl_f(transform.m1, owner); e_t.m2 = shfl_f(transform.m2, owner);
                 e_t.m3 = shfl_f(transform.m3, owner); e_t.t0 = shfl_f(transform.t0, owner); e_t.t1 = shfl_f(transform.t1, owner);
                 const uint32_t e_path = wave_shfl(path_ix, owner);
-                const vec2 ls0 = v2(shfl_f(lp0[0].x, owner), shfl_f(lp0[0].y, owner)), ls1 = v2(shfl_f(lp0[1].x, owner), shfl_f(lp0[1].y, owner));
                 if (on) {
                     // point i + 1: the far end of line i, the near end of line i + 1 (flatten.wgsl:463-468: the ends swap for a
-                    // negative offset); the range's first point (the previous range's last, or the curve's start) from the lane of i = 0
+                    // negative offset); the range's LAST point goes to LDS: the next range's first (and, below, its own line 0 waits
+                    // for its predecessor's)
                     const vec2 P = xf_apply(e_t, lp1);
                     em.write_end(line_ix + i, fwd ? 1u : 0u, P);
                     em.write_path(line_ix + i, e_path);
@@ -714,16 +845,11 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
                         cl.endpt[owner][side][0] = lp1.x;
                         cl.endpt[owner][side][1] = lp1.y;
                     }
-                    float bx0 = P.x, by0 = P.y, bx1 = P.x, by1 = P.y;
-                    if (i == 0u) {
-                        const vec2 S = xf_apply(e_t, side ? ls1 : ls0);
-                        em.write_end(line_ix, fwd ? 0u : 1u, S);
-                        bx0 = minf(bx0, S.x); by0 = minf(by0, S.y); bx1 = maxf(bx1, S.x); by1 = maxf(by1, S.y);
-                    }
-                    atomicMin(&cl.bbox[owner][0], f32_ordered(bx0));
-                    atomicMin(&cl.bbox[owner][1], f32_ordered(by0));
-                    atomicMax(&cl.bbox[owner][2], f32_ordered(bx1));
-                    atomicMax(&cl.bbox[owner][3], f32_ordered(by1));
+                    const uint32_t row = box_lp < 64u ? box_lp : owner;
+                    atomicMin(&cl.bbox[row][0], f32_ordered(P.x));
+                    atomicMin(&cl.bbox[row][1], f32_ordered(P.y));
+                    atomicMax(&cl.bbox[row][2], f32_ordered(P.x));
+                    atomicMax(&cl.bbox[row][3], f32_ordered(P.y));
                 }
                 flp_mark(FLP_EMIT);
             }
@@ -735,7 +861,30 @@ __device__ void flatten_euler_coop(Emitter &em, EulerCoopLds &cl, bool valid, co
             }
         }
         wave_lds_sync();
+        // every range's first point -- the near end of its line 0: the last point of the range before it (lockstep: this lane's own
+        // previous range, lp0; level-parallel: the leaf that ends where this one begins) -- by the lane that accepted the range
         if (push) {
+            const uint32_t row = box_lp < 64u ? box_lp : lane;
+#pragma unroll
+            for (int sd = 0; sd < 2; sd++) {
+                if (sd == 1 && !two_sided) break;
+                const vec2 st = pred < 64u ? v2(cl.endpt[pred][sd][0], cl.endpt[pred][sd][1]) : lp0[sd];
+                const vec2 S = xf_apply(transform, st);
+                const bool fwd = ((off_fwd >> sd) & 1u) != 0u;
+                em.write_end(s_line[sd], fwd ? 0u : 1u, S);
+                atomicMin(&cl.bbox[row][0], f32_ordered(S.x));
+                atomicMin(&cl.bbox[row][1], f32_ordered(S.y));
+                atomicMax(&cl.bbox[row][2], f32_ordered(S.x));
+                atomicMax(&cl.bbox[row][3], f32_ordered(S.y));
+            }
+        }
+        // ... and where the next range starts
+        if (lp_mode) {
+            if (lp_last < 64u) {
+                lp0[0] = v2(cl.endpt[lp_last][0][0], cl.endpt[lp_last][0][1]);
+                if (two_sided) lp0[1] = v2(cl.endpt[lp_last][1][0], cl.endpt[lp_last][1][1]);
+            }
+        } else if (push) {
             lp0[0] = v2(cl.endpt[lane][0][0], cl.endpt[lane][0][1]);
             if (two_sided) lp0[1] = v2(cl.endpt[lane][1][0], cl.endpt[lane][1][1]);
         }
