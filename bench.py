@@ -590,12 +590,13 @@ def main():
 
     # HBM traffic of the dominant kernel from the PMC passes (collected separately, as the pool requires, by
     # scripts/gpu_calib.sh; corrected with the factors calibrated in the same session; stamped with its commit)
-    traffic = traffic_commit = None
+    traffic = traffic_commit = traffic_sources = None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             tj = json.load(fh)
         traffic = tj.get("workloads", {}).get(head_key, tj).get("kernels", {}).get(head["dominant_kernel"], {}).get("traffic_bytes")
         traffic_commit = tj.get("commit")
+        traffic_sources = tj.get("kernel_sources")
         if second is not None:  # (the other workload's dominant kernel, same passes)
             second["roofline"]["traffic"] = (tj.get("workloads", {}).get("r1mix", {}).get("kernels", {})
                                              .get(second["dominant_kernel"], {}).get("traffic_bytes"))
@@ -606,8 +607,16 @@ def main():
     roof["peak_measured"] = round(peak_measured, 1) if peak_measured else None
     roof["peak_measured_how"] = "float4 device-to-device copy kernel (scripts/calib/copy_bw.hip) of 1 GiB on this GPU in this run, read + written bytes / best of 5"
     roof["traffic"] = traffic
+    # (the PMC passes are a session of their own; say so when the kernels have changed since.  Compared by a hash
+    # of the kernel sources -- a commit hash moves with every documentation commit and the GPU box has no .git)
+    from vello_amd._lib import kernel_sources_hash
+
+    sources_now = kernel_sources_hash()
+    stale = traffic is not None and traffic_sources != sources_now
+    roof["traffic_stale"] = bool(stale)
     roof["traffic_source"] = ("profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch, "
-                              f"collected at commit {traffic_commit})")
+                              f"collected at commit {traffic_commit}, kernel sources {traffic_sources}; this run's kernel sources {sources_now}: "
+                              + ("STALE -- the kernels have changed since the PMC passes)" if stale else "the same kernels)"))
     serial_med = head["serial_ms"]["median"]
     result = {
         "metric": "frames/sec paris-30k 1600x1600 MSAA16; scenes/sec at 1/2/4/8 GPU",

@@ -6,6 +6,9 @@ import os
 import re
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vello_amd._lib import kernel_sources_hash  # noqa: E402
+
 out_dir, tag = sys.argv[1], sys.argv[2]
 
 
@@ -45,6 +48,7 @@ doc = {
             "--steps 8 --warmup 2 --in-flight 1 --timed-only`; counters are in KiB, averaged per dispatch.  Corrections from the calibration "
             "kernels of the same session (scripts/calib/pmc_calib.hip, 512 MiB each): streamed 16 B/lane reads and writes.",
     "commit": commit,
+    "kernel_sources": kernel_sources_hash(),  # (bench.py compares it with the sources it runs: roofline.traffic_stale)
     "fetch_correction": fc,
     "write_correction": wc,
     "calibration": {k: {"FETCH_SIZE_KiB": cal_f.get(k, {}).get("FETCH_SIZE"), "WRITE_SIZE_KiB": cal_w.get(k, {}).get("WRITE_SIZE"), "known_bytes": KNOWN}

@@ -44,3 +44,8 @@ s, w, h = workloads.many_draw_objects_scene(); p, l = s.resolve()
 run("many_draw_objects (90k circles) 2000x1500 MSAA16", p, l, w, h, AaConfig.Msaa16)
 s, w, h = workloads.blend_grid_scene(); r = vello_amd.Resolver().resolve(s)
 run("blend_grid (16 mix modes, gradients) 900^2 MSAA16", r.packed, r.layout, w, h, AaConfig.Msaa16, resolved=r)
+# (the brush specialisation of fine at stated sizes; per-stage / per-kernel times and k_fine's phases: scripts/brush_prof.py)
+s, w, h = workloads.gradient_extend_scene(); r = vello_amd.Resolver().resolve(s)
+run("gradient_extend (linear / radial / sweep x extend modes) %dx%d MSAA16" % (w, h), r.packed, r.layout, w, h, AaConfig.Msaa16, resolved=r)
+s, w, h = workloads.image_sampling_scene(); r = vello_amd.Resolver().resolve(s)
+run("image_sampling (nearest / bilinear) %dx%d MSAA16" % (w, h), r.packed, r.layout, w, h, AaConfig.Msaa16, resolved=r)

@@ -157,3 +157,20 @@ def load_library():
     sig("vh_renderer_last_bump", None, [vp, c.POINTER(Bump)])
     _LIB = lib
     return lib
+
+
+def kernel_sources_hash():
+    """sha1 over the kernel sources (vello_amd/csrc/engine/*, csrc/Makefile): what a profile or a PMC pass says it measured.  A
+    commit hash moves with every documentation commit and does not exist on the GPU box; this says whether the KERNELS are the ones
+    the numbers came from (bench.py: roofline.traffic_stale)."""
+    import hashlib
+    import os
+
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha1()
+    files = [os.path.join(root, "Makefile")] + sorted(os.path.join(root, "engine", f) for f in os.listdir(os.path.join(root, "engine")))
+    for f in files:
+        if os.path.isfile(f) and not os.path.basename(f).startswith("_"):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
