@@ -8,6 +8,7 @@ test suites carry.  Prints the failing seeds only.
     FUZZ_GPU=1 ...             the product library on the GPU instead of the emulator build
     FUZZ_STROKE_KERNEL=1 ...   with flatten's stroked-line kernel forced on (VELLO_HIP_DEBUG_STROKE_KERNEL)
     FUZZ_FINE_SLICES=1 ...   every tile through the sliced path of fine (VELLO_HIP_DEBUG_FINE_SLICES)
+    FUZZ_FLATTEN=coop|alone ...  flatten's heavy list by the wave-cooperative walk / by every lane on its own, whatever the engine would pick
     FUZZ_IN_FLIGHT=n ...     vello_hip_set_frames_in_flight(n): from 2 on flatten runs its stroke workgroups as a kernel of their own
 
 Round 1 ran api 0-43500, sizes 0-6000, pools 0-4000, extreme 0-358 (some extreme seeds emit tens of millions of lines and take
@@ -26,6 +27,9 @@ ON_GPU = os.environ.get("FUZZ_GPU") == "1"              # the product library on
 STROKE_KERNEL = os.environ.get("FUZZ_STROKE_KERNEL") == "1"  # VELLO_HIP_DEBUG_STROKE_KERNEL: flatten's stroked-line kernel for every scene
 IN_FLIGHT = int(os.environ.get("FUZZ_IN_FLIGHT", "1"))
 FINE_SLICES = os.environ.get("FUZZ_FINE_SLICES") == "1"  # VELLO_HIP_DEBUG_FINE_SLICES: slices of 4 fills for every tile
+# round 5: which kernels take flatten's heavy list -- "coop" (VELLO_HIP_DEBUG_FLATTEN_COOP: the wave-cooperative walk), "alone"
+# (VELLO_HIP_DEBUG_FLATTEN_ALONE: every lane on its own); unset: the engine's own choice (small scenes: the cooperative walk)
+FLATTEN = os.environ.get("FUZZ_FLATTEN", "")
 if not ON_GPU:
     L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
 from oracle.oracle import Oracle  # noqa: E402
@@ -50,7 +54,7 @@ def one(mode, seed, eng):
         eng = vello_amd.Engine(capacities=TINY)
         eng.set_auto_grow(True)
         eng.set_frames_in_flight(IN_FLIGHT)
-        eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES)
+        eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES, flatten_coop=FLATTEN == "coop", flatten_alone=FLATTEN == "alone")
         w, h = [(128, 128), (300, 200), (64, 64)][seed % 3]
         scene = fuzz_scene(seed, size=max(w, h), n_ops=[40, 300][seed % 2])
         aa, base, kw = AAS[(seed // 2) % 3], 0xFF203040, {}
@@ -73,7 +77,7 @@ def main():
     eng = vello_amd.Engine()
     eng.set_auto_grow(True)
     eng.set_frames_in_flight(IN_FLIGHT)
-    eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES)
+    eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES, flatten_coop=FLATTEN == "coop", flatten_alone=FLATTEN == "alone")
     bad, t0 = [], time.time()
     for seed in range(lo, hi):
         try:
@@ -81,6 +85,8 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a campaign reports and carries on
             bad.append(seed)
             print("SEED", seed, type(e).__name__, str(e)[:300], flush=True)
+        if (seed - lo) % 500 == 499:
+            print("at", seed + 1, "bad", bad, round(time.time() - t0, 1), "s", flush=True)
     print("done", mode, hi - lo, "bad", bad, round(time.time() - t0, 1), "s")
 
 
