@@ -14,14 +14,14 @@ from vello_amd.renderer import Engine
 NAMES = ["interpreter", "batch: scan", "batch: segments", "batch: items", "fill: apply", "fill: prefix", "fill: sparse eval",
          "fill: restore", "fill: even-odd", "fill: unbatched", "blend", "rare: begin_clip", "rare: end_clip (blend)",
          "rare: gradients", "rare: image / blur"]
-NP = len(NAMES)  # phases; behind them: fills, batches, crossing records, command words, rare commands
-SLOTS = NP + 5
+NP = len(NAMES)  # phases; behind them: fills, batches, crossing records, command words, rare commands, fills through ms_fill_simple
+SLOTS = NP + 6
 
 
-def report(key, width=None, height=None, aa=2):
+def report(key, width=None, height=None, aa=None):
     wl = bench.Workload(key, 0)
-    width, height = width or bench.WIDTH, height or bench.HEIGHT
-    eng = Engine(0, 4, wl.caps)
+    width, height, aa = width or wl.width, height or wl.height, int(wl.aa) if aa is None else aa
+    eng = Engine(0, 1 << aa, wl.caps)
     eng.upload_scene(wl.packed, wl.layout)
     report_engine(key, eng, width, height, aa)
     del eng
@@ -35,12 +35,12 @@ def report_engine(key, eng, width, height, aa=2):
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
     cap = eng.capacities()["blend_spill"]
     raw = eng.read_buffer("blend_spill", np.uint32)[cap - n_tiles * SLOTS:cap].reshape(n_tiles, SLOTS).astype(np.float64)
-    cyc, fills, batches, items, words, rare = raw[:, :NP], raw[:, NP], raw[:, NP + 1], raw[:, NP + 2], raw[:, NP + 3], raw[:, NP + 4]
+    cyc, fills, batches, items, words, rare, simple = raw[:, :NP], raw[:, NP], raw[:, NP + 1], raw[:, NP + 2], raw[:, NP + 3], raw[:, NP + 4], raw[:, NP + 5]
     tot = cyc.sum(axis=1)
     order = np.argsort(tot)
     top = order[-max(1, n_tiles // 256):]  # the slowest 0.4 % of the tiles
     print(f"{key}: {n_tiles} tiles, {fills.sum():.0f} fills in {batches.sum():.0f} batches, {items.sum():.0f} crossing records, "
-          f"{words.sum():.0f} command words, {rare.sum():.0f} rare commands")
+          f"{words.sum():.0f} command words, {rare.sum():.0f} rare commands; {100 * simple.sum() / max(fills.sum(), 1):.0f} % of the fills through ms_fill_simple")
     print(f"  cycles per tile: mean {tot.mean():.0f}, max {tot.max():.0f} (= {tot.max() / 2400:.0f} us at 2.4 GHz); per fill: "
           f"{tot.sum() / max(fills.sum(), 1):.0f}; slowest tiles: {fills[top].mean():.0f} fills, {words[top].mean():.0f} words, "
           f"{tot[top].sum() / max(fills[top].sum(), 1):.0f} cycles per fill")

@@ -44,6 +44,7 @@ enum {
     FP_RARE_IMAGE,      // ... IMAGE, BLUR_RECT
     FP_N_FILLS, FP_N_BATCHES, FP_N_ITEMS, FP_N_WORDS,  // counts: fills, batches, crossing records, command words
     FP_N_RARE,          // count: rare commands
+    FP_N_SIMPLE,        // count: fills taken by ms_fill_simple
     FP_SLOTS
 };
 #ifdef VELLO_FINE_PROF
@@ -1891,6 +1892,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) k_fine(Config cfg, const 
                     const bool fast = fast_left != 0u;
                     for (;;) {
                         prof.count(FP_N_FILLS, 1u);
+                        if (samples_clean && ((simple_mask >> batch_pos) & 1u) != 0u) prof.count(FP_N_SIMPLE, 1u);
                         if (samples_clean && ((simple_mask >> batch_pos) & 1u) != 0u)
                             ms_fill_simple<AA>(sh, bt, sh_samples, batch_pos, slots, lane, area, rec_pre, rec_pre_begin, prof);
                         else
