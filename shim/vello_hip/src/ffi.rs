@@ -75,6 +75,8 @@ pub const VELLO_HIP_DEBUG_NO_CULL: u32 = 1;
 pub const VELLO_HIP_DEBUG_STROKE_KERNEL: u32 = 2;
 pub const VELLO_HIP_DEBUG_SEQ_CLIP: u32 = 4;
 pub const VELLO_HIP_DEBUG_FINE_SLICES: u32 = 8;
+pub const VELLO_HIP_DEBUG_FLATTEN_COOP: u32 = 16;
+pub const VELLO_HIP_DEBUG_FLATTEN_ALONE: u32 = 32;
 pub const VELLO_HIP_STAGE_COUNT: usize = 11;
 
 unsafe extern "C" {
