@@ -32,6 +32,8 @@ FINE_SLICES = os.environ.get("FUZZ_FINE_SLICES") == "1"  # VELLO_HIP_DEBUG_FINE_
 FLATTEN = os.environ.get("FUZZ_FLATTEN", "")
 if not ON_GPU:
     L._use_library(os.path.join(ROOT, "tests", "simt_emu", "libvello_emu.so"))
+elif os.environ.get("VELLO_AB_LIB"):  # another build of the product library: ab_tmp/libvello_hip_<X>.so (is a finding this round's?)
+    L._use_library(os.path.join(ROOT, "ab_tmp", "libvello_hip_%s.so" % os.environ["VELLO_AB_LIB"]))
 from oracle.oracle import Oracle  # noqa: E402
 from tests.parity import compare_frame  # noqa: E402
 from vello_amd import AaConfig  # noqa: E402
@@ -79,13 +81,15 @@ def main():
     eng.set_frames_in_flight(IN_FLIGHT)
     eng.set_debug_flags(stroke_kernel=STROKE_KERNEL, fine_slices=FINE_SLICES, flatten_coop=FLATTEN == "coop", flatten_alone=FLATTEN == "alone")
     bad, t0 = [], time.time()
+    t_said = t0
     for seed in range(lo, hi):
         try:
             one(mode, seed, eng)
         except Exception as e:  # noqa: BLE001 -- a campaign reports and carries on
             bad.append(seed)
             print("SEED", seed, type(e).__name__, str(e)[:300], flush=True)
-        if (seed - lo) % 500 == 499:
+        if (seed - lo) % 500 == 499 or time.time() - t_said > 30.0:  # (a run cut off by a timeout has said how far it came)
+            t_said = time.time()
             print("at", seed + 1, "bad", bad, round(time.time() - t0, 1), "s", flush=True)
     print("done", mode, hi - lo, "bad", bad, round(time.time() - t0, 1), "s")
 
