@@ -202,6 +202,9 @@ int vello_hip_set_auto_grow(vello_hip_ctx *ctx, int enabled);
  * vello_hip_render calls this itself when the scene is large against the current pools. */
 /* How many rounds the last blocking vello_hip_render took (1 unless robust mode had to grow pools and re-run). */
 uint32_t vello_hip_last_render_attempts(vello_hip_ctx *ctx);
+/* Launches in which the stages of a small scene shared a kernel (VELLO_HIP_DEBUG_NO_FUSION), counted since the context was
+ * created: lets a test see that the scene it renders took that path. */
+uint64_t vello_hip_fused_launches(vello_hip_ctx *ctx);
 int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                                   const vello_hip_render_params *params, vello_hip_capacities *out);
 
@@ -219,9 +222,11 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * VELLO_HIP_DEBUG_FLATTEN_COOP / _ALONE pick the kernels that flatten the scene's curves, stroked curves, joins and caps: the
  * wave-cooperative walk, or every lane on its own (normally the engine picks by what an earlier frame of the same scene put on
  * the list, and by the scene's size before there is one): same line soup as a multiset -- so that tests can hold both sets of
- * kernels to the oracle on the same scenes. */
+ * kernels to the oracle on the same scenes.
+ * VELLO_HIP_DEBUG_NO_FUSION launches every stage of a small scene as a kernel of its own (normally the workgroups of consecutive
+ * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers. */
 enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8,
-       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32 };
+       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -389,3 +389,48 @@ def clip_structures(big):
         yield "20 000 deep", [1] * 20000 + [-1] * 20000
         n = 300000  # > 1024 partitions: two per thread in k_clip_stack
         yield "300 000 clips", list(np.where(np.random.default_rng(5).random(n) < 0.5 + 0.2 * np.sin(np.arange(n) / 3001.0), 1, -1))
+
+
+def front_fusion_cases():
+    """Small scenes whose stages share launches (k_front, flatten.hip): (name, packed, layout, w, h, background, launches per frame)
+    -- 1: everything up to tile_alloc as one workgroup's work (a few dozen segments, no clips); 2: [zero fill | pathtag scan | light
+    pass + draw scan] and [binning | tile_alloc]."""
+    import workloads
+    from vello_amd import Layout, Scene
+
+    out = []
+    s = workloads.smoke_circle_scene()
+    out.append(("circle",) + tuple(s.resolve()) + (20, 20, 0xFF000000, 1))
+    s = workloads.circle_scene()
+    out.append(("circle256",) + tuple(s.resolve()) + (256, 256, 0xFF000000, 1))
+    out.append(("empty",) + tuple(Scene().resolve()) + (64, 64, 0xFF102030, 1))
+    out.append(("stroke_styles",) + tuple(workloads.stroke_styles_scene().resolve()) + (256, 256, 0xFFFFFFFF, 2))
+    out.append(("clip_blend",) + tuple(workloads.clip_blend_scene().resolve()) + (256, 256, 0xFF000000, 2))
+    out.append(("random_700",) + tuple(workloads.random_test_scene(3, n_paths=700, size=384.0, strokes=True, clips=True).resolve()) + (384, 384, 0xFF000000, 2))
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiger_scene.npz"))
+    out.append(("tiger", d["packed"], Layout(*[int(v) for v in d["layout"]]), 320, 320, 0xFFFFFFFF, 2))
+    return out
+
+
+def check_front_fusion(engine, case, in_flight=(1, 2)):
+    """One of front_fusion_cases(): the fused launches taken (vello_hip_fused_launches) and every stage and the image against the
+    oracle; then the same scene with every stage as a kernel of its own (VELLO_HIP_DEBUG_NO_FUSION)."""
+    from vello_amd import AaConfig
+
+    name, packed, layout, w, h, bg, per_frame = case
+    try:
+        for n in in_flight:
+            engine.set_frames_in_flight(n)
+            for aa in (AaConfig.Area, AaConfig.Msaa16):
+                before = engine.fused_launches()
+                engine.render(packed, layout, w, h, bg, aa)
+                assert engine.fused_launches() - before == per_frame, (name, n, engine.fused_launches() - before, per_frame)
+                compare_frame(engine, packed, layout, w, h, bg, aa, f"fusion_{name}_{n}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+        engine.set_frames_in_flight(1)
+        engine.set_debug_flags(no_fusion=True)
+        before = engine.fused_launches()
+        compare_frame(engine, packed, layout, w, h, bg, AaConfig.Msaa16, f"nofusion_{name}")
+        assert engine.fused_launches() == before
+    finally:
+        engine.set_frames_in_flight(1)
+        engine.set_debug_flags()

@@ -968,6 +968,15 @@ def test_emu_flatten_kernel_sets_curves(emu_engine):
         flatten_kernel_sets(emu_engine, "emu_flsets_" + name, packed, layout, w, h, in_flight=False)
 
 
+@pytest.mark.parametrize("case", range(7))
+def test_emu_front_fusion(emu_engine, case):
+    # small scenes: the workgroups of consecutive stages as turns of one launch (k_front) -- here of ONE workgroup, the emulator's
+    # launches run their workgroups one after the other; the grid barrier itself is the GPU suite's (test_gpu_front_fusion)
+    from tests.parity import check_front_fusion, front_fusion_cases
+
+    check_front_fusion(emu_engine, front_fusion_cases()[case])
+
+
 def test_emu_clip_stage_partitioned(emu_engine):
     # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip) and as the one-wave stack machine, against the oracle's stack
     from tests.parity import clip_structures, compare_clip_stage

@@ -724,6 +724,46 @@ def test_gpu_flatten_kernel_sets(gpu_engine, case):
         gpu_engine.set_auto_grow(False)
 
 
+@pytest.mark.parametrize("case", range(7))
+def test_gpu_front_fusion(gpu_engine, case):
+    # small scenes: the workgroups of consecutive stages as turns of one launch with a grid barrier between the stages (k_front);
+    # the launches counted, every stage and the image against the oracle, one frame in flight and two; then unfused
+    from tests.parity import check_front_fusion, front_fusion_cases
+
+    check_front_fusion(gpu_engine, front_fusion_cases()[case])
+
+
+def test_gpu_front_fusion_barrier_stress():
+    # k_front's grid barrier under load: the tiger (16 workgroups a launch, on different XCDs) 600 times with four frames in
+    # flight, and a scene whose every stage is one workgroup's -- each frame identical to the oracle's
+    import torch
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    d = np.load(os.path.join(GOLD, "tiger_scene.npz"))
+    layout = Layout(*[int(v) for v in d["layout"]])
+    for packed, lay, w, h, per_frame in ((d["packed"], layout, 512, 512, 2), tuple(workloads.circle_scene().resolve()) + (256, 256, 1)):
+        o = Oracle()
+        o.set_scene(packed, lay, w, h, WHITE, int(AaConfig.Msaa8))
+        ref = o.render()
+        eng = vello_amd.Engine()
+        eng.set_frames_in_flight(4)
+        eng.upload_scene(packed, lay)
+        targets = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+        torch.cuda.synchronize()
+        before = eng.fused_launches()
+        for rep in range(150):
+            for t in targets:
+                eng.render_resident(w, h, WHITE, AaConfig.Msaa8, out=t)
+            if rep % 50 == 49:
+                assert eng.sync() == 0
+                for t in targets:
+                    assert np.array_equal(ref, t.cpu().numpy()), rep
+                    t.zero_()
+                torch.cuda.synchronize()
+        assert eng.fused_launches() - before == 600 * per_frame
+
+
 def test_gpu_flatten_kernel_sets_baseline_configs(gpu_engine):
     # ... and on BASELINE's C2 (tiger: a wave per curve) and C4 (mmark-50k: a list of stroked curves), whichever set the engine
     # would pick for them by itself

@@ -16,7 +16,7 @@ HEADER = os.path.join(ROOT, "include", "vello_hip.h")
 FFI = os.path.join(ROOT, "shim", "vello_hip", "src", "ffi.rs")
 
 C_TO_RUST = {
-    "int": "c_int", "uint32_t": "u32", "size_t": "usize", "void": "()", "float": "f32", "uint8_t": "u8", "char": "c_char",
+    "int": "c_int", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "void": "()", "float": "f32", "uint8_t": "u8", "char": "c_char",
 }
 
 

@@ -177,6 +177,8 @@ struct Frame {
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;
     const uint32_t *mask_lut16;
+    uint32_t zero_bytes;     // the lane's zero region: Control + both look-back states (k_front clears it itself)
+    uint32_t *front_sync;    // k_front's grid-barrier counter (per lane; only ever grows)
     Bump *bump() const { return &control->bump; }
 };
 
@@ -184,7 +186,19 @@ void launch_pathtag_scan(const Frame &f, hipStream_t s);
 // (mid: when not null, an event is recorded behind every kernel of the stage but the last: per-KERNEL times of a stage of
 // several kernels, vello_hip_get_kernel_ms)
 // with_draw_scan: the draw stage's workgroups ride in k_flatten_light's launch (the caller then leaves launch_draw_scan out)
-void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr, bool with_draw_scan = false);
+// light_done: k_front has run the light pass (and the draw stage's workgroups) already
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr, bool with_draw_scan = false, bool light_done = false);
+// Small scenes: the workgroups of consecutive stages as ONE launch (k_front, flatten.hip).  `stages`: FRONT_* bits, consecutive stages;
+// returns what the launch adds to *f.front_sync (the caller keeps the counter's value: sync_base is the value before the launch).
+constexpr uint32_t FRONT_ZERO = 1u, FRONT_PATHTAG = 2u, FRONT_LIGHT = 4u, FRONT_HEAVY = 8u, FRONT_BINNING = 16u, FRONT_TILE_ALLOC = 32u;
+constexpr uint32_t FRONT_MAX_TAGS = 65536u, FRONT_MAX_DRAW_OBJECTS = 16384u;  // a scene beyond these has stages long enough to hide their launches
+constexpr uint32_t FRONT_TINY_SEGMENTS = 64u;  // up to here the heavy list joins the launch, which is then ONE workgroup
+uint32_t launch_front(const Frame &f, hipStream_t s, uint32_t stages, bool with_draw_scan, uint32_t sync_base);
+inline uint32_t flatten_n_seg_max(const Frame &f) {
+    // (a segment owns at least one word of path data, so the path-data stream bounds the segments even though the tag stream is padded)
+    const uint32_t n_tags = f.n_tag_words * 4u, n_data = f.cfg.layout.draw_tag_base - f.cfg.layout.path_data_base;
+    return n_tags < n_data ? n_tags : n_data;
+}
 void launch_draw_scan(const Frame &f, hipStream_t s);
 void launch_clip(const Frame &f, hipStream_t s);             // clip.hip
 void launch_clip_sequential(const Frame &f, hipStream_t s);  // draw.hip

@@ -68,6 +68,8 @@ struct Lane {
     DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
     DevBuf heavy_list;                // flatten: tag indices for the heavy code, 4 lists (one u32 per tag each, worst case)
     DevBuf arc_items;                 // flatten: arcs the stroke workgroups leave to the heavy code (64 B per segment, worst case)
+    DevBuf front_sync;                // k_front's grid-barrier counter (zeroed once, when allocated)
+    uint32_t front_sync_value = 0;    // ... and its value once every launch enqueued so far has run
     struct EvPair {
         int stage;
         hipEvent_t a, b;
@@ -117,6 +119,7 @@ struct vello_hip_ctx {
     uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
     bool force_brushes = false;  // pre-warm: run fine's brush specialisation on a scene without brushes
     uint32_t last_render_attempts = 0;  // rounds the last vello_hip_render needed (robust mode)
+    uint64_t fused_launches = 0;  // k_front launches so far (vello_hip_fused_launches)
     // last frame
     Config cfg{};
     bool have_cfg = false;
@@ -281,6 +284,12 @@ int alloc_lane_scene(vello_hip_ctx *c, Lane &l, const SceneSlot &sc) {
     const vello_hip_layout &L = sc.layout;
     int r;
     if ((r = ensure(c, l.zero_region, sc.zero_bytes))) return r;
+    if (!l.front_sync.ptr) {
+        if ((r = ensure(c, l.front_sync, 256))) return r;
+        HIP_TRY(c, hipMemset(l.front_sync.ptr, 0, 256));
+        HIP_TRY(c, hipStreamSynchronize(nullptr));  // (the lanes' streams do not wait for the null stream)
+        l.front_sync_value = 0;
+    }
     l.buf[VELLO_HIP_BUF_BUMP].ptr = l.zero_region.ptr;
     l.buf[VELLO_HIP_BUF_BUMP].size = sizeof(Control);  // (vello_hip_read_buffer: the bump allocators first, then the engine's own counters)
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TAG_MONOIDS], (size_t)(sc.n_tag_words + 4u) * sizeof(TagMonoid)))) return r;
@@ -399,6 +408,8 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.aa = p->aa;
     f.scene = (const uint32_t *)sc.scene.ptr;
     f.control = (Control *)l.zero_region.ptr;
+    f.zero_bytes = (uint32_t)sc.zero_bytes;
+    f.front_sync = (uint32_t *)l.front_sync.ptr;
     f.pathtag_state = (unsigned long long *)((char *)l.zero_region.ptr + sizeof(Control));
     f.draw_state = f.pathtag_state + (size_t)sc.n_pathtag_parts * 10u;
     f.tag_monoids = (TagMonoid *)l.buf[VELLO_HIP_BUF_TAG_MONOIDS].ptr;
@@ -500,6 +511,21 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         l.slice_cap_coarse = f.slice_cap;
         l.slice_fills_coarse = f.slice_fills;
     }
+    // Small scenes: consecutive stages as one launch (k_front, flatten.hip) -- A: [zero fill | pathtag scan | flatten's light pass
+    // + draw scan], B: [binning | tile_alloc]; a scene of a few dozen segments: everything up to tile_alloc.  Not for a stage that
+    // is being timed on its own.
+    bool fuse_a = false, fuse_b = false, fuse_all = false;
+    if ((c->debug_flags & VELLO_HIP_DEBUG_NO_FUSION) == 0u && f.n_tag_words * 4u <= FRONT_MAX_TAGS &&
+        f.cfg.layout.n_draw_objects <= FRONT_MAX_DRAW_OBJECTS && f.cfg.layout.n_paths <= FRONT_MAX_DRAW_OBJECTS) {
+        const uint32_t pm = c->prof_mask;
+        const uint32_t mask_a = (1u << VELLO_HIP_STAGE_PATHTAG_SCAN) | (1u << VELLO_HIP_STAGE_FLATTEN) | (1u << VELLO_HIP_STAGE_DRAW_SCAN);
+        const uint32_t mask_b = (1u << VELLO_HIP_STAGE_BINNING) | (1u << VELLO_HIP_STAGE_TILE_ALLOC);
+        fuse_a = first == VELLO_HIP_STAGE_PATHTAG_SCAN && last >= VELLO_HIP_STAGE_FLATTEN && (pm & mask_a) == 0u;
+        fuse_b = first <= VELLO_HIP_STAGE_BINNING && last >= VELLO_HIP_STAGE_TILE_ALLOC && (pm & mask_b) == 0u;
+        // (the heavy list aboard: the kernels of the cooperative walk, no stroke workgroups -- not when a debug flag asks for others)
+        fuse_all = fuse_a && fuse_b && (pm & (1u << VELLO_HIP_STAGE_CLIP)) == 0u && f.cfg.layout.n_clips == 0u &&
+                   flatten_n_seg_max(f) <= FRONT_TINY_SEGMENTS && f.flatten_coop && f.stroke_kernel_min_lines != 0u;
+    }
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
         Lane::EvPair ev{s, nullptr, nullptr, {nullptr, nullptr}};
@@ -513,21 +539,40 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         switch (s) {
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
-            HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, slot_of(c, l).zero_bytes, st));
             l.flatten_ran = false;
+            if (fuse_all) {
+                c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT | FRONT_HEAVY | FRONT_BINNING | FRONT_TILE_ALLOC, true,
+                                                   l.front_sync_value);
+                break;
+            }
+            if (fuse_a) break;  // (with FLATTEN's first launch)
+            HIP_TRY(c, hipMemsetAsync(l.zero_region.ptr, 0, slot_of(c, l).zero_bytes, st));
             launch_pathtag_scan(f, st);
             break;
         case VELLO_HIP_STAGE_FLATTEN:
-            // (a range that goes on to DRAW_SCAN: that stage's workgroups ride in flatten's first launch)
-            launch_flatten(f, st, prof ? ev.mid : nullptr, last >= VELLO_HIP_STAGE_DRAW_SCAN);
             l.flatten_ran = true;
+            if (fuse_all) break;
+            // (a range that goes on to DRAW_SCAN: that stage's workgroups ride in flatten's first launch)
+            if (fuse_a)
+                c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT, last >= VELLO_HIP_STAGE_DRAW_SCAN, l.front_sync_value);
+            launch_flatten(f, st, prof ? ev.mid : nullptr, last >= VELLO_HIP_STAGE_DRAW_SCAN, fuse_a);
             break;
         case VELLO_HIP_STAGE_DRAW_SCAN:
             if (first > VELLO_HIP_STAGE_FLATTEN) launch_draw_scan(f, st);  // (else: done beside k_flatten_light)
             break;
         case VELLO_HIP_STAGE_CLIP: launch_clip(f, st); break;
-        case VELLO_HIP_STAGE_BINNING: launch_binning(f, st); break;
-        case VELLO_HIP_STAGE_TILE_ALLOC: launch_tile_alloc(f, st); break;
+        case VELLO_HIP_STAGE_BINNING:
+            if (fuse_all) break;
+            if (fuse_b) {
+                if (f.cfg.layout.n_draw_objects != 0u || f.cfg.layout.n_paths != 0u)
+                    c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_BINNING | FRONT_TILE_ALLOC, false, l.front_sync_value);
+            } else {
+                launch_binning(f, st);
+            }
+            break;
+        case VELLO_HIP_STAGE_TILE_ALLOC:
+            if (!fuse_all && !fuse_b) launch_tile_alloc(f, st);
+            break;
         case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, st); break;
         case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, st); break;
         case VELLO_HIP_STAGE_COARSE: launch_coarse(f, st, prof ? ev.mid : nullptr); break;
@@ -719,6 +764,7 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         for (int i = 0; i < VELLO_HIP_BUF_COUNT; i++)
             if (l.buf[i].ptr && i != VELLO_HIP_BUF_BUMP) (void)hipFree(l.buf[i].ptr);
         if (l.zero_region.ptr) (void)hipFree(l.zero_region.ptr);
+        if (l.front_sync.ptr) (void)hipFree(l.front_sync.ptr);
         if (l.clip_stack.ptr) (void)hipFree(l.clip_stack.ptr);
         if (l.coarse_el.ptr) (void)hipFree(l.coarse_el.ptr);
         if (l.tile_bits.ptr) (void)hipFree(l.tile_bits.ptr);
@@ -1048,6 +1094,7 @@ int vello_hip_sync(vello_hip_ctx *c) {
 }
 
 uint32_t vello_hip_last_render_attempts(vello_hip_ctx *c) { return c ? c->last_render_attempts : 0u; }
+uint64_t vello_hip_fused_launches(vello_hip_ctx *c) { return c ? c->fused_launches : 0u; }
 
 void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
 

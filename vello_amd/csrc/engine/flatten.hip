@@ -12,6 +12,8 @@
 // in the reference (the line soup is an unordered set, flatten.wgsl:775-798).
 #include "engine.h"
 #include "draw_scan.h"
+#include "scan_body.h"     // (k_front runs the workgroups of the pathtag scan ...
+#include "binning_body.h"  //  ... and of binning and tile_alloc)
 
 namespace vk {
 
@@ -1044,20 +1046,9 @@ __device__ __forceinline__ uint32_t flatten_tag_light(Emitter &em, const Config 
     return 0u;
 }
 
-// The first n_draw_blocks workgroups are the draw stage's (draw_scan.h; first, so that their look-back chain is under way while
-// the flatten workgroups fill the chip): they need the scene and what
-// k_pathtag_scan stored at the PATH markers, nothing of flatten's, and the stage as a launch of its own is 6-10 us of launch
-// boundary and look-back latency on the frame's critical path.
-__global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
-                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
-                                                          Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t n_draw_blocks,
-                                                          unsigned long long *draw_state, DrawMonoid *__restrict__ draw_monoids,
-                                                          uint32_t *__restrict__ info, Clip *__restrict__ clip_inp) {
-    if (blockIdx.x < n_draw_blocks) {
-        draw_scan_workgroup(cfg, scene, control, draw_state, path_bboxes, draw_monoids, info, clip_inp);
-        return;
-    }
-    const uint32_t block = blockIdx.x - n_draw_blocks;
+// (one workgroup of flatten's light pass: FLATTEN_BLOCK_TAGS tags from tag `block` x FLATTEN_BLOCK_TAGS on)
+__device__ __forceinline__ void flatten_light_workgroup(const Config &cfg, uint32_t block, uint32_t n_tags, const uint32_t *scene, const TagMonoid *tag_monoids,
+                                                        PathBbox *path_bboxes, Control *control, LineSoup *lines, uint32_t *heavy_list) {
     __shared__ FlattenShared<FLATTEN_BLOCK_TAGS> sh;  // at most one line per tag: never overflows
     __shared__ uint32_t sh_heavy[FLATTEN_BLOCK_TAGS];  // curves from the front, strokes from the back
     __shared__ uint32_t sh_lines[FLATTEN_BLOCK_TAGS];  // stroked lines
@@ -1130,6 +1121,22 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     for (uint32_t i = tid; i < sh_n_heavy[0]; i += 256u) heavy_list[sh_heavy_base[0] + i] = sh_heavy[i];
     for (uint32_t i = tid; i < sh_n_heavy[1]; i += 256u) heavy_list[n_tags + sh_heavy_base[1] + i] = sh_heavy[FLATTEN_BLOCK_TAGS - 1u - i];
     for (uint32_t i = tid; i < sh_n_heavy[2]; i += 256u) heavy_list[2u * n_tags + sh_heavy_base[2] + i] = sh_lines[i];
+}
+
+// The first n_draw_blocks workgroups are the draw stage's (draw_scan.h; first, so that their look-back chain is under way while
+// the flatten workgroups fill the chip): they need the scene and what
+// k_pathtag_scan stored at the PATH markers, nothing of flatten's, and the stage as a launch of its own is 6-10 us of launch
+// boundary and look-back latency on the frame's critical path.
+__global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n_tags, const uint32_t *__restrict__ scene,
+                                                          const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
+                                                          Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t n_draw_blocks,
+                                                          unsigned long long *draw_state, DrawMonoid *__restrict__ draw_monoids,
+                                                          uint32_t *__restrict__ info, Clip *__restrict__ clip_inp) {
+    if (blockIdx.x < n_draw_blocks) {
+        draw_scan_workgroup(cfg, scene, control, draw_state, path_bboxes, draw_monoids, info, clip_inp);
+        return;
+    }
+    flatten_light_workgroup(cfg, blockIdx.x - n_draw_blocks, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list);
 }
 
 // ---- stroked lines: flatten_tag's stroke branch without the Euler-spiral flattener ------------------------------
@@ -1532,6 +1539,123 @@ __global__ void __launch_bounds__(256, 2) k_flatten_heavy(Config cfg, uint32_t n
                                                     stroke_kernel_min_lines, arc_items, arc_shard_cap);
 }
 
+// ---- small scenes: consecutive stages as ONE launch ------------------------------------------------------------------
+// A frame is a chain of a dozen dependent launches, and a launch boundary on this machine is ~4 us of nothing plus the ramp of
+// the next grid: for the 48-line circle that is the whole frame, for the Tiger a fifth of it.  k_front runs the workgroups of
+// several stages -- the same bodies, block by block -- as turns of a few persistent workgroups with a grid barrier between the
+// stages: [zero fill of the control block | pathtag scan | flatten's light pass + draw scan], and [binning | tile_alloc]; for
+// a scene of a few dozen segments the heavy list joins them and everything up to tile_alloc is one workgroup's work, the
+// barriers plain __syncthreads.  The barrier: one release-add per workgroup on a counter that only ever grows (the host
+// knows its value at the launch: `sync_base`), a spin until all have arrived, an acquire.  At most FRONT_MAX_WG workgroups,
+// so that every cooperative launch that can be in flight at once (frames in flight, other contexts) is resident as a whole.
+// Reference: vello/src/render.rs:250-436 (the dispatch chain these stages are).
+struct FrontArgs {
+    uint32_t stages;
+    uint32_t n_tag_words, n_scene_words, n_tags;
+    uint32_t n_pathtag_blocks, n_draw_blocks, n_light_blocks, n_binning_blocks, n_tile_alloc_blocks;
+    uint32_t arc_shard_cap;
+    uint32_t zero_vec16;  // 16-byte words of the lane's zero region (Control + look-back states)
+    uint32_t sync_base;   // *sync when the launch begins
+    uint32_t *sync;
+    const uint32_t *scene;
+    Control *control;
+    unsigned long long *pathtag_state, *draw_state;
+    TagMonoid *tag_monoids;
+    PathBbox *path_bboxes;
+    LineSoup *lines;
+    uint32_t *heavy_list, *arc_items;
+    DrawMonoid *draw_monoids;
+    uint32_t *info_bin_data;
+    Clip *clip_inp;
+    Bbox4 *clip_bboxes, *draw_bboxes;
+    BinHeader *bin_headers;
+    Path *paths;
+    Tile *tiles;
+};
+
+// All workgroups of the launch have finished the stage before / may start the next one.
+__device__ __forceinline__ void front_barrier(uint32_t *sync, uint32_t target, uint32_t *failed_flag) {
+    __syncthreads();  // (the workgroup's stores are out)
+#ifndef VELLO_SIMT_EMU  // (the emulator runs workgroups one after the other: a launch there is ONE workgroup)
+    if (gridDim.x != 1u) {
+        if (threadIdx.x == 0u) {
+            __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t spins = 0u;
+            while ((int32_t)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                // (as the look-back's: a launch that is not resident as a whole -- it always is, FRONT_MAX_WG -- must fail, not hang)
+                if (++spins > SPIN_LIMIT) {
+                    atomicOr(failed_flag, FAILED_INTERNAL);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+#endif
+}
+
+template <bool HEAVY>
+__global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
+    const uint32_t tid = threadIdx.x, wg = blockIdx.x, n_wg = gridDim.x;
+    uint32_t target = a.sync_base;
+    uint32_t todo = a.stages;
+    // (a barrier behind every stage but the launch's last)
+#define FRONT_STAGE_END(bit)                                   \
+    do {                                                       \
+        todo &= ~(bit);                                        \
+        if (todo != 0u) front_barrier(a.sync, target += n_wg, &a.control->bump.failed); \
+    } while (0)
+    if (a.stages & FRONT_ZERO) {  // render.rs:313 clears `bump`; here: Control and both look-back states
+        uint4 *z = reinterpret_cast<uint4 *>(a.control);
+        for (uint32_t i = wg * 256u + tid; i < a.zero_vec16; i += n_wg * 256u) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        FRONT_STAGE_END(FRONT_ZERO);
+    }
+    if (a.stages & FRONT_PATHTAG) {
+        for (uint32_t b = wg; b < a.n_pathtag_blocks; b += n_wg) {
+            pathtag_scan_workgroup(cfg, b, a.n_pathtag_blocks, a.n_tag_words, a.n_scene_words, a.scene, a.control, a.pathtag_state, a.tag_monoids,
+                                   a.path_bboxes);
+            __syncthreads();  // (the next turn writes the LDS this one read)
+        }
+        FRONT_STAGE_END(FRONT_PATHTAG);
+    }
+    if (a.stages & FRONT_LIGHT) {
+        for (uint32_t b = wg; b < a.n_draw_blocks + a.n_light_blocks; b += n_wg) {
+            if (b < a.n_draw_blocks)
+                draw_scan_workgroup(cfg, a.scene, a.control, a.draw_state, a.path_bboxes, a.draw_monoids, a.info_bin_data, a.clip_inp);
+            else
+                flatten_light_workgroup(cfg, b - a.n_draw_blocks, a.n_tags, a.scene, a.tag_monoids, a.path_bboxes, a.control, a.lines, a.heavy_list);
+            __syncthreads();
+        }
+        FRONT_STAGE_END(FRONT_LIGHT);
+    }
+    if constexpr (HEAVY) {
+        if (a.stages & FRONT_HEAVY) {
+            // (no stroke workgroups: every stroked line is the heavy list's; the workgroups stride over the list themselves)
+            __shared__ __attribute__((aligned(16))) unsigned char smem[FLATTEN_MAIN_LDS];
+            heavy_workgroups<HEAVY_FIRST, true>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem),
+                                                reinterpret_cast<EulerCoopLds *>(smem + FLATTEN_ARCS_AT), wg, n_wg, cfg, a.n_tags, a.scene, a.tag_monoids,
+                                                a.path_bboxes, a.control, a.lines, a.heavy_list, 0xffffffffu, a.arc_items, a.arc_shard_cap);
+            FRONT_STAGE_END(FRONT_HEAVY);
+        }
+    }
+    if (a.stages & FRONT_BINNING) {
+        for (uint32_t b = wg; b < a.n_binning_blocks; b += n_wg) {
+            binning_workgroup(cfg, b, a.draw_monoids, a.path_bboxes, a.clip_bboxes, a.draw_bboxes, &a.control->bump, a.info_bin_data, a.bin_headers);
+            __syncthreads();
+        }
+        FRONT_STAGE_END(FRONT_BINNING);
+    }
+    if (a.stages & FRONT_TILE_ALLOC) {
+        for (uint32_t b = wg; b < a.n_tile_alloc_blocks; b += n_wg) {
+            tile_alloc_workgroup(cfg, b, a.scene, a.draw_bboxes, &a.control->bump, a.paths, a.tiles);
+            __syncthreads();
+        }
+    }
+#undef FRONT_STAGE_END
+}
+
 #ifdef VELLO_FLATTEN_PROF
 }  // namespace vk
 // measurement build only: the counters of g_flatten_prof, read and cleared (scripts/flatten_prof.py binds it with ctypes)
@@ -1545,11 +1669,63 @@ extern "C" int vello_flatten_prof_read(unsigned long long *out) {
 namespace vk {
 #endif
 
-void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_draw_scan) {
+constexpr uint32_t FRONT_MAX_WG = 16u;
+uint32_t launch_front(const Frame &f, hipStream_t s, uint32_t stages, bool with_draw_scan, uint32_t sync_base) {
+    FrontArgs a{};
+    a.stages = stages;
+    a.n_tag_words = f.n_tag_words;
+    a.n_scene_words = f.n_scene_words;
+    a.n_tags = f.n_tag_words * 4u;
+    a.n_pathtag_blocks = (f.n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
+    if (a.n_pathtag_blocks == 0u) a.n_pathtag_blocks = 1u;
+    a.n_draw_blocks = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
+    a.n_light_blocks = (a.n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
+    a.n_binning_blocks = (f.cfg.layout.n_draw_objects + 255u) / 256u;
+    a.n_tile_alloc_blocks = (f.cfg.layout.n_paths + 255u) / 256u;
+    a.arc_shard_cap = flatten_arc_shard_cap(flatten_n_seg_max(f), true);
+    a.zero_vec16 = f.zero_bytes / 16u;
+    a.sync_base = sync_base;
+    a.sync = f.front_sync;
+    a.scene = f.scene;
+    a.control = f.control;
+    a.pathtag_state = f.pathtag_state;
+    a.draw_state = f.draw_state;
+    a.tag_monoids = f.tag_monoids;
+    a.path_bboxes = f.path_bboxes;
+    a.lines = f.lines;
+    a.heavy_list = f.heavy_list;
+    a.arc_items = f.arc_items;
+    a.draw_monoids = f.draw_monoids;
+    a.info_bin_data = f.info_bin_data;
+    a.clip_inp = f.clip_inp;
+    a.clip_bboxes = f.clip_bboxes;
+    a.draw_bboxes = f.draw_bboxes;
+    a.bin_headers = f.bin_headers;
+    a.paths = f.paths;
+    a.tiles = f.tiles;
+    // as many workgroups as the widest of the launch's stages has blocks, FRONT_MAX_WG at most; one when the heavy list is aboard
+    uint32_t n_wg = 1u;
+#ifndef VELLO_SIMT_EMU
+    if ((stages & FRONT_HEAVY) == 0u) {
+        if (stages & FRONT_PATHTAG) n_wg = n_wg > a.n_pathtag_blocks ? n_wg : a.n_pathtag_blocks;
+        if (stages & FRONT_LIGHT) n_wg = n_wg > a.n_draw_blocks + a.n_light_blocks ? n_wg : a.n_draw_blocks + a.n_light_blocks;
+        if (stages & FRONT_BINNING) n_wg = n_wg > a.n_binning_blocks ? n_wg : a.n_binning_blocks;
+        if (stages & FRONT_TILE_ALLOC) n_wg = n_wg > a.n_tile_alloc_blocks ? n_wg : a.n_tile_alloc_blocks;
+        if (n_wg > FRONT_MAX_WG) n_wg = FRONT_MAX_WG;
+    }
+#endif
+    if (stages & FRONT_HEAVY) hipLaunchKernelGGL(k_front<true>, dim3(n_wg), dim3(256), 0, s, f.cfg, a);
+    else hipLaunchKernelGGL(k_front<false>, dim3(n_wg), dim3(256), 0, s, f.cfg, a);
+    uint32_t n_stages = 0u;
+    for (uint32_t b = stages; b != 0u; b &= b - 1u) n_stages++;
+    return n_wg == 1u ? 0u : n_wg * (n_stages - 1u);
+}
+
+void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_draw_scan, bool light_done) {
     uint32_t n_tags = f.n_tag_words * 4u;
     uint32_t grid = (n_tags + FLATTEN_BLOCK_TAGS - 1u) / FLATTEN_BLOCK_TAGS;
     if (grid == 0) {
-        if (with_draw_scan) launch_draw_scan(f, s);
+        if (with_draw_scan && !light_done) launch_draw_scan(f, s);
         // (the stage's in-between events are recorded on every way out: vello_hip_get_kernel_ms reads all of them)
         if (mid) {
             (void)hipEventRecord(mid[0], s);
@@ -1558,15 +1734,15 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
         return;
     }
     const uint32_t grid_draw = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
-    hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                       f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp);
+    if (!light_done)
+        hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                           f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp);
     if (mid) (void)hipEventRecord(mid[0], s);
     // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
     // (workgroups beyond the list exit at once)
     // (a segment owns at least one word of path data, so the path-data stream bounds the list even though the tag stream
     // is padded to 4096 tags)
-    const uint32_t n_data = f.cfg.layout.draw_tag_base - f.cfg.layout.path_data_base;
-    const uint32_t n_seg_max = n_tags < n_data ? n_tags : n_data;
+    const uint32_t n_seg_max = flatten_n_seg_max(f);
     uint32_t grid_heavy = (n_seg_max + 3u) / 4u;
     if (grid_heavy > 2048u) grid_heavy = 2048u;
     if (grid_heavy < 4u) grid_heavy = 4u;
