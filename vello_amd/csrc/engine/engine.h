@@ -191,7 +191,10 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr, bo
 // Small scenes: the workgroups of consecutive stages as ONE launch (k_front, flatten.hip).  `stages`: FRONT_* bits, consecutive stages;
 // returns what the launch adds to *f.front_sync (the caller keeps the counter's value: sync_base is the value before the launch).
 constexpr uint32_t FRONT_ZERO = 1u, FRONT_PATHTAG = 2u, FRONT_LIGHT = 4u, FRONT_HEAVY = 8u, FRONT_BINNING = 16u, FRONT_TILE_ALLOC = 32u;
-constexpr uint32_t FRONT_MAX_TAGS = 65536u, FRONT_MAX_DRAW_OBJECTS = 16384u;  // a scene beyond these has stages long enough to hide their launches
+// (a turn per workgroup and stage at most -- FRONT_MAX_WG, flatten.hip: 16 light-pass blocks of 1 024 tags, 16 blocks of 256 draw objects; a
+// scene of 2 000 paths with twice these is 1 % slower one frame at a time and 4 % with four in flight when its stages share launches,
+// the scenes below gain 1-10 % and 3-50 %: profiles/r05_small_scene_latency.jsonl)
+constexpr uint32_t FRONT_MAX_TAGS = 16384u, FRONT_MAX_DRAW_OBJECTS = 4096u;
 constexpr uint32_t FRONT_TINY_SEGMENTS = 64u;  // up to here the heavy list joins the launch, which is then ONE workgroup
 uint32_t launch_front(const Frame &f, hipStream_t s, uint32_t stages, bool with_draw_scan, uint32_t sync_base);
 inline uint32_t flatten_n_seg_max(const Frame &f) {
