@@ -10,7 +10,24 @@ import bench
 from vello_amd.renderer import Engine
 
 
+def report_tiger():
+    """C2: the tiger at 1024 x 1024 -- a soup of 15 000 lines, k_path_count<1>: chunks of 256 lines, one per workgroup"""
+    import vello_amd
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "tiger_scene.npz"))
+    eng = Engine()
+    eng.upload_scene(d["packed"], vello_amd.Layout(*[int(v) for v in d["layout"]]))
+    for _ in range(3):
+        eng.render_resident(1024, 1024, 0xFFFFFFFF, 1)
+        eng.sync()
+    cap = eng.capacities()["seg_counts"]
+    n_chunks = (eng.bump()["lines"] + 255) // 256
+    raw = eng.read_buffer("seg_counts", np.uint32)[(cap - 4 * 8192) * 2:cap * 2].reshape(-1, 8).astype(np.int64)[:n_chunks]
+    report_chunks("tiger", raw, n_chunks)
+
+
 def report(key):
+    if key == "tiger":
+        return report_tiger()
     wl = bench.Workload(key, 0)
     eng = Engine(0, 4, wl.caps)
     eng.upload_scene(wl.packed, wl.layout)

@@ -237,20 +237,116 @@ __device__ __forceinline__ uint32_t pc_slot_more(PcShared &sh, uint32_t line) {
     return PC_NONE;
 }
 
-// The crossings of one line (path_count.wgsl:172-199), a thread per line; its crossing s is item `item0 + s` of the wave.
-// COUNT: the items below PC_STASH, into the table and the stash.  Otherwise: the items from PC_STASH on, straight to memory
-// and to the SegmentCount pool (the wave's records start at `seg_wave`).
-template <bool COUNT>
-__device__ __forceinline__ void pc_walk_line(PcShared &sh, const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, uint32_t lane, uint32_t wave,
-                                             const Config &cfg, Tile *tile, uint32_t seg_wave, uint32_t line_ix,
-                                             SegmentCount *__restrict__ seg_counts) {
+// The counting pass (path_count.wgsl:172-199): the first n_stash crossings of every line of the wave into the table and the stash;
+// the line's crossing s is item `item0 + s` of the wave.
+//
+// A thread per line, like the reference -- and then the pass lasts as long as the wave's LONGEST line: on a road map lines cross
+// 1.4 tiles, but a small scene's few workgroups wait for the one whose chunk holds the edges of a background rectangle (the tiger:
+// chunks take 5.8 us, one takes 30 -- a 20 us counting pass over 64-tile lines -- and that one is the launch;
+// scripts/pc_timeline.py tiger).  Crossings are independent of each other (z of crossing i is floor(a i + b), the z before it
+// floor(a (i - 1) + b): the same two roundings the loop carries along), so when a wave holds FEW long lines their crossings beyond
+// the first PC_COOP_FROM are spread over the lanes, 64 a round, line by line: the walk's nine words are read from the owner's lane
+// (v_readlane), the stash word names the owner as before.  "Few": the rounds that takes (twice over, for the reads) against the steps
+// the longest line would still walk alone -- a wave of mmark's lines, every one of them 80 tiles long, keeps a thread per line.
+#ifndef VK_PC_COOP_FROM
+#define VK_PC_COOP_FROM 8u
+#endif
+constexpr uint32_t PC_COOP_FROM = VK_PC_COOP_FROM;
+__device__ __forceinline__ void pc_count_lines(PcShared &sh, const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, uint32_t lane, uint32_t wave,
+                                               const Config &cfg, Tile *tile) {
+    // crossing i of the line with this walk, owned by lane `owner`, item `item` of the wave
+    auto crossing = [&](float a, float b, float x0, float y0, uint32_t base, uint32_t bbox02, uint32_t flags, uint32_t i, float last_z, float z,
+                        uint32_t item, uint32_t owner) {
+        (void)a; (void)b;
+        const int32_t bbox0 = (int32_t)(bbox02 & 0xffffu), bbox2 = (int32_t)(bbox02 >> 16);
+        const uint32_t stride = (uint32_t)(bbox2 - bbox0);
+        const float x_sign = (flags & 2u) ? -1.0f : 1.0f;
+        const int32_t delta = (flags & 1u) ? -1 : 1;
+        const int32_t y = f2i(y0 + (float)i - z);
+        const int32_t x = f2i(x0 + x_sign * z);
+        const uint32_t row = base + (uint32_t)y * stride;
+        const bool top_edge = i == 0u ? (flags & 4u) != 0u : last_z == z;  // (not folded into last_z: z is a NaN when a is not finite)
+        const uint32_t key = row + (uint32_t)x;
+        const int32_t x1 = (int32_t)((uint32_t)x + 1u);  // (x saturates at the ends of i32 for coordinates like 3e38: WGSL's i32 wraps)
+        const uint32_t bkey = row + (uint32_t)maxi(x1, bbox0);
+        const bool counted = key < cfg.tiles_size;
+        const bool bump = top_edge && x1 < bbox2 && bkey < cfg.tiles_size;
+        // the usual crossing: in the pool, its cache line in the first place the table gives it, its bump (if any) on the tile to
+        // its right -- a compare-and-swap, an add and the stash, no branch
+        const uint32_t line = key >> 4, h = pc_hash(line);
+        const uint32_t o = atomicCAS(&sh.keys[counted ? h : PC_TABLE + lane], PC_EMPTY, line);
+        const bool hit = o == PC_EMPTY || o == line;  // (a lane outside the pool reads PC_NOBODY)
+        const bool bump_right = bump && bkey == key + 1u;
+        const uint32_t at = h * 16u + (key & 15u);
+        const uint32_t one = 1u + (bump_right ? (uint32_t)delta << 16 : 0u);
+        atomicAdd(&sh.cnt[hit ? at : PC_CNT_WORDS + lane], one);
+        uint32_t word = hit ? at : PC_DONE;  // (a crossing outside the pool gets slot 0, as a robust access would give it)
+        // everything else, seldom: another place in the table, or none and straight to memory; a bump that is not on the right
+        const bool rest = (counted && !hit) || (bump && !(hit && bump_right));
+        if (PC_WAVE_ANY(rest)) {
+            if (rest) {
+                bool bumped = hit && bump_right;
+                if (counted && !hit) {
+                    const uint32_t slot = pc_slot_more(sh, line);
+                    if (slot != PC_NONE) {
+                        word = slot * 16u + (key & 15u);
+                        atomicAdd(&sh.cnt[word], one);
+                        bumped = bump_right;
+                    } else {
+                        word = PC_DONE | (atomicAdd(&tile[key].segment_count_or_ix, 1u) & 0xffffu);
+                    }
+                }
+                if (bump && !bumped) atomicAdd(&tile[bkey].backdrop, delta);
+            }
+        }
+        sh.stash[wave][item] = word | (owner << 16);
+    };
+    // few long lines in the wave?  (everything here is wave-uniform)
+    uint32_t n_own = n_stash;
+    const unsigned long long m_long = __ballot(n_stash > PC_COOP_FROM);
+    bool coop = false;
+    if (m_long != 0ull) {
+        const uint32_t longest = wave_read(wave_incl_scan_max_u32(n_stash, (int)lane), 63u);
+        const uint32_t rounds = n_stash > PC_COOP_FROM ? (n_stash - PC_COOP_FROM + 63u) / 64u : 0u;
+        const uint32_t all_rounds = wave_read(wave_incl_scan_u32(rounds, (int)lane), 63u);
+        coop = all_rounds * 2u + 2u < longest - PC_COOP_FROM;
+        if (coop) n_own = minu(n_stash, PC_COOP_FROM);
+    }
+    // a thread per line.  last_z: the z of the crossing before (path_count.wgsl:172-186 carries it through its loop)
+    float last_z = floorf(w.a * ((float)imin - 1.0f) + w.b);
+    for (uint32_t s = 0u; s < n_own; s++) {
+        const uint32_t i = imin + s;
+        const float z = floorf(w.a * (float)i + w.b);
+        crossing(w.a, w.b, w.x0, w.y0, w.base, w.bbox02, w.flags, i, last_z, z, item0 + s, lane);
+        last_z = z;
+    }
+    // the long lines' other crossings, a lane per crossing
+    if (coop) {
+        for (unsigned long long m = m_long; m != 0ull; m &= m - 1ull) {
+            const uint32_t owner = (uint32_t)__ffsll((long long)m) - 1u;
+            const float a = __uint_as_float(wave_read(__float_as_uint(w.a), owner)), b = __uint_as_float(wave_read(__float_as_uint(w.b), owner));
+            const float x0 = __uint_as_float(wave_read(__float_as_uint(w.x0), owner)), y0 = __uint_as_float(wave_read(__float_as_uint(w.y0), owner));
+            const uint32_t base = wave_read(w.base, owner), bbox02 = wave_read(w.bbox02, owner), flags = wave_read(w.flags, owner);
+            const uint32_t imin_o = wave_read(imin, owner), item_o = wave_read(item0, owner), n_o = wave_read(n_stash, owner);
+            for (uint32_t s = PC_COOP_FROM + lane; s < n_o; s += 64u) {
+                const uint32_t i = imin_o + s;
+                const float z = floorf(a * (float)i + b);
+                const float z_before = floorf(a * (float)(i - 1u) + b);
+                crossing(a, b, x0, y0, base, bbox02, flags, i, z_before, z, item_o + s, owner);
+            }
+        }
+    }
+}
+
+// The crossings of one line from its item `n_stash` on -- the ones without a place in the stash -- a thread per line, straight to
+// memory and to the SegmentCount pool (the wave's records start at `seg_wave`), as the reference does every crossing.
+__device__ __forceinline__ void pc_walk_line_direct(const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, const Config &cfg, Tile *tile,
+                                                    uint32_t seg_wave, uint32_t line_ix, SegmentCount *__restrict__ seg_counts) {
     const int32_t bbox0 = (int32_t)(w.bbox02 & 0xffffu), bbox2 = (int32_t)(w.bbox02 >> 16);
     const uint32_t stride = (uint32_t)(bbox2 - bbox0);
     const float x_sign = (w.flags & 2u) ? -1.0f : 1.0f;
     const int32_t delta = (w.flags & 1u) ? -1 : 1;
-    // the line's first n_stash crossings have places in the stash (COUNT) / the rest
-    const uint32_t s_begin = COUNT ? 0u : n_stash, s_end = COUNT ? n_stash : w.count;
-    // last_z: the z of the crossing before (path_count.wgsl:172-186 carries it through its loop)
+    const uint32_t s_begin = n_stash, s_end = w.count;
     const uint32_t i_begin = imin + s_begin;
     float last_z = floorf(w.a * (s_begin == 0u ? (float)imin - 1.0f : (float)(i_begin - 1u)) + w.b);
     const bool top_edge_0 = (w.flags & 4u) != 0u;
@@ -267,47 +363,15 @@ __device__ __forceinline__ void pc_walk_line(PcShared &sh, const PcWalk &w, uint
         const uint32_t bkey = row + (uint32_t)maxi(x1, bbox0);
         const bool counted = key < cfg.tiles_size;
         const bool bump = top_edge && x1 < bbox2 && bkey < cfg.tiles_size;
-        if (COUNT) {
-            // the usual crossing: in the pool, its cache line in the first place the table gives it, its bump (if any) on the tile to
-            // its right -- a compare-and-swap, an add and the stash, no branch
-            const uint32_t line = key >> 4, h = pc_hash(line);
-            const uint32_t o = atomicCAS(&sh.keys[counted ? h : PC_TABLE + lane], PC_EMPTY, line);
-            const bool hit = o == PC_EMPTY || o == line;  // (a lane outside the pool reads PC_NOBODY)
-            const bool bump_right = bump && bkey == key + 1u;
-            const uint32_t at = h * 16u + (key & 15u);
-            const uint32_t one = 1u + (bump_right ? (uint32_t)delta << 16 : 0u);
-            atomicAdd(&sh.cnt[hit ? at : PC_CNT_WORDS + lane], one);
-            uint32_t word = hit ? at : PC_DONE;  // (a crossing outside the pool gets slot 0, as a robust access would give it)
-            // everything else, seldom: another place in the table, or none and straight to memory; a bump that is not on the right
-            const bool rest = (counted && !hit) || (bump && !(hit && bump_right));
-            if (PC_WAVE_ANY(rest)) {
-                if (rest) {
-                    bool bumped = hit && bump_right;
-                    if (counted && !hit) {
-                        const uint32_t slot = pc_slot_more(sh, line);
-                        if (slot != PC_NONE) {
-                            word = slot * 16u + (key & 15u);
-                            atomicAdd(&sh.cnt[word], one);
-                            bumped = bump_right;
-                        } else {
-                            word = PC_DONE | (atomicAdd(&tile[key].segment_count_or_ix, 1u) & 0xffffu);
-                        }
-                    }
-                    if (bump && !bumped) atomicAdd(&tile[bkey].backdrop, delta);
-                }
-            }
-            sh.stash[wave][item0 + s] = word | (lane << 16);
-        } else {
-            uint32_t seg_within_slice = 0u;
-            if (counted) seg_within_slice = atomicAdd(&tile[key].segment_count_or_ix, 1u);
-            if (bump) atomicAdd(&tile[bkey].backdrop, delta);
-            const uint32_t seg_ix = seg_wave + item0 + s;
-            if (seg_ix < cfg.seg_counts_size) {
-                SegmentCount sc;
-                sc.line_ix = line_ix;
-                sc.counts = (seg_within_slice << 16) | i;
-                seg_counts[seg_ix] = sc;
-            }
+        uint32_t seg_within_slice = 0u;
+        if (counted) seg_within_slice = atomicAdd(&tile[key].segment_count_or_ix, 1u);
+        if (bump) atomicAdd(&tile[bkey].backdrop, delta);
+        const uint32_t seg_ix = seg_wave + item0 + s;
+        if (seg_ix < cfg.seg_counts_size) {
+            SegmentCount sc;
+            sc.line_ix = line_ix;
+            sc.counts = (seg_within_slice << 16) | i;
+            seg_counts[seg_ix] = sc;
         }
     }
 }
@@ -390,7 +454,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         uint32_t done = 0u;  // items of this wave before line group j (wave-uniform)
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) {
-            pc_walk_line<true>(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile, 0u, 0u, seg_counts);
+            pc_count_lines(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile);
             done += T[j];
         }
         if (tid == 0u) sh.base = reserved;
@@ -441,7 +505,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
                 }
             }
             if (PC_WAVE_ANY(n_stash[j] < w[j].count))  // crossings without a place in the stash: straight to memory
-                pc_walk_line<false>(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile, seg_wave, chunk + j * 256u + tid, seg_counts);
+                pc_walk_line_direct(w[j], w[j].ioff + p[j], done + p[j], n_stash[j], cfg, tile, seg_wave, chunk + j * 256u + tid, seg_counts);
             done += T[j];
         }
         __syncthreads();
