@@ -13,8 +13,9 @@
 //
 //  * k_coarse_prep (one launch, two jobs by block range): (a) per draw object, everything coarse needs from five
 //    buffers (tag, draw flags, first draw-data word, offsets, the Path record) gathered ONCE into a 32-byte record --
-//    the reference re-gathers it per (bin, draw object); (b) per 64 tiles of the pool, three bit planes by wave
-//    ballot: has segments / backdrop == 0 / backdrop even -- all the coverage test needs (coarse.wgsl:318-341).
+//    the reference re-gathers it per (bin, draw object); (b) per 64 tiles of the pool, three bits per tile by wave
+//    ballot: has segments / backdrop == 0 / backdrop even -- all the coverage test needs (coarse.wgsl:318-341) -- stored
+//    a word per 8 tiles with the three planes' bytes side by side (plane_window below).
 //  * k_coarse: one workgroup of four waves per 8x8-tile QUADRANT of a bin (4x the workgroups; a draw object is only
 //    considered by the quadrants its bbox touches).  Threads first act as draw objects: the bin's list is streamed
 //    256 entries at a time (entries prefetched one round ahead), survivors are queued in LDS and each gets its 64-bit
@@ -128,11 +129,18 @@ __device__ __forceinline__ uint32_t words_of(u64 m, u64 g, u64 k1, u64 k2, u64 k
     return 3u * popc64(g) + 3u * popc64(m & k1) + 4u * popc64(m & k2) + popc64(m & k3);
 }
 
-// 64 bits of a bit plane starting at bit `b` (one 8-byte load at a 4-byte aligned address; the planes carry two words of
-// slack behind the last tile).
-__device__ __forceinline__ unsigned long long plane_window(const uint32_t *__restrict__ plane, uint32_t b) {
-    const PtclWords2 w = *reinterpret_cast<const PtclWords2 *>(plane + (b >> 5));
-    return (((unsigned long long)w.b << 32) | (unsigned long long)w.a) >> (b & 31u);
+// The three tile bits coarse.wgsl:318-341 needs (segments present / backdrop zero / backdrop even), a WORD per 8 tiles:
+// byte 0 the eight tiles' "segments" bits, byte 1 "zero", byte 2 "even".  A quadrant is 8 tiles wide, so a row of an
+// object's rectangle inside it is at most 8 consecutive tiles: words b / 8 and b / 8 + 1 hold all three planes' bits of
+// the row -- ONE 8-byte load (4-byte aligned; two words of slack behind the last tile) where three separate planes took
+// one per plane.  k_coarse's stream rounds are bound by the number of scattered requests a CU's address unit takes
+// (512 threads x 8 rows x the planes read), not by their bytes.
+__device__ __forceinline__ PtclWords2 plane_window(const uint32_t *__restrict__ bits, uint32_t b) {
+    return *reinterpret_cast<const PtclWords2 *>(bits + (b >> 3));
+}
+// the 8-tile window of the plane whose bytes sit `byte_shift` bits up, starting at tile b (bits above the row: other tiles', masked by the caller)
+__device__ __forceinline__ uint32_t window_bits(PtclWords2 w, uint32_t byte_shift, uint32_t b) {
+    return (((w.a >> byte_shift) & 0xffu) | (((w.b >> byte_shift) & 0xffu) << 8)) >> (b & 7u);
 }
 
 }  // namespace
@@ -141,7 +149,7 @@ __device__ __forceinline__ unsigned long long plane_window(const uint32_t *__res
 __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_blocks, const uint32_t *__restrict__ scene,
                                                      const DrawMonoid *__restrict__ draw_monoids, const uint32_t *__restrict__ info_bin_data,
                                                      const Path *__restrict__ paths, const Tile *__restrict__ tiles, const Bump *__restrict__ bump,
-                                                     CoarseEl *__restrict__ coarse_el, uint32_t *__restrict__ tile_bits, uint32_t plane_words) {
+                                                     CoarseEl *__restrict__ coarse_el, uint32_t *__restrict__ tile_bits) {
     const uint32_t tid = threadIdx.x;
     if (blockIdx.x < n_el_blocks) {
         const uint32_t drawobj_ix = blockIdx.x * 256u + tid;
@@ -176,10 +184,9 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
         const unsigned long long ms = __ballot(t.segment_count_or_ix != 0u);
         const unsigned long long mz = __ballot(t.backdrop == 0);
         const unsigned long long mo = __ballot((t.backdrop & 1) == 0);
-        if (lane < 6u) {
-            const uint32_t p = lane >> 1, h = lane & 1u;
-            const unsigned long long m = p == 0u ? ms : (p == 1u ? mz : mo);
-            tile_bits[(size_t)p * plane_words + chunk * 2u + h] = (uint32_t)(m >> (32u * h));
+        if (lane < 8u) {  // word j of the chunk: tiles [8j, 8j + 8) of it
+            const uint32_t sh = 8u * lane;
+            tile_bits[(size_t)chunk * 8u + lane] = ((uint32_t)(ms >> sh) & 0xffu) | (((uint32_t)(mz >> sh) & 0xffu) << 8) | (((uint32_t)(mo >> sh) & 0xffu) << 16);
         }
     }
 }
@@ -189,7 +196,7 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
 // while a batch is emitted; wave 0's lanes are also the 64 tiles of the quadrant (write pointers, clip state).
 __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__restrict__ scene, const BinHeader *__restrict__ bin_headers,
                                                 const uint32_t *__restrict__ info_bin_data, const CoarseEl *__restrict__ coarse_el,
-                                                const uint32_t *__restrict__ tile_bits, uint32_t plane_words, Tile *tiles, Bump *bump,
+                                                const uint32_t *__restrict__ tile_bits, Tile *tiles, Bump *bump,
                                                 uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order,
                                                 SliceItem *slice_items, uint32_t *slice_counters, uint32_t slice_cap, uint32_t cov_cap,
                                                 uint32_t slice_fills, uint32_t slice_min_fills) {
@@ -222,9 +229,6 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     const uint32_t n_partitions = (cfg.layout.n_draw_objects + N_TILE - 1u) / N_TILE;
     const uint32_t sub_x0 = N_TILE_X * (bin_ix % width_in_bins) + SUB_W * (quad & 1u);
     const uint32_t sub_y0 = N_TILE_Y * (bin_ix / width_in_bins) + SUB_W * (quad >> 1);
-    const uint32_t *plane_s = tile_bits;
-    const uint32_t *plane_z = tile_bits + plane_words;
-    const uint32_t *plane_o = tile_bits + 2u * (size_t)plane_words;
     const bool has_clips = cfg.layout.n_clips != 0u;
     const bool cull = allow_cull && !has_clips;
     const uint32_t ptcl_dyn_start = cfg.width_in_tiles * cfg.height_in_tiles * PTCL_INITIAL_ALLOC;
@@ -346,9 +350,9 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             const uint32_t base = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
             u64 inc = 0ull, kil = 0ull, seg = 0ull, clr = 0ull;
             {
-                // BRANCH-FREE on purpose: with each row's two loads under `if (r < h)` the compiler ends every one of the
-                // 16 conditional blocks with s_waitcnt vmcnt(0) -- sixteen memory round trips in a row, 8 300 of a
-                // round's 13 000 cycles.  Rows an object does not have (and objects that miss the quadrant) load the
+                // BRANCH-FREE on purpose: with each row's load under `if (r < h)` the compiler ends every one of the
+                // conditional blocks with s_waitcnt vmcnt(0) -- a memory round trip per row, one after the other (round 2,
+                // when a row was two loads: 8 300 of a round's 13 000 cycles).  Rows an object does not have (and objects that miss the quadrant) load the
                 // first words of the plane instead and get an empty row mask.
                 const uint32_t rx0 = (uint32_t)x0, ry0 = (uint32_t)y0;
                 const uint32_t w = meets ? (uint32_t)(x1 - x0) : 0u, h = meets ? (uint32_t)(y1 - y0) : 0u;
@@ -356,21 +360,18 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
                 const uint32_t BLEND_CLIP = (128u << 8) | 3u;
                 const bool is_blend = is_clip && el.w0 != BLEND_CLIP;
                 const bool even_odd = (el.flags & DRAW_INFO_FLAGS_FILL_RULE_BIT) != 0u;
-                const uint32_t *plane_c = even_odd ? plane_o : plane_z;
+                const uint32_t clear_byte = even_odd ? 16u : 8u;  // which plane says "backdrop clear" under the object's fill rule
                 const uint32_t wmask = (1u << w) - 1u;
                 const uint32_t b0 = base + stride * ry0 + rx0;
-                u64 ws[SUB_W], wc[SUB_W];
+                PtclWords2 win[SUB_W];
 #pragma unroll
-                for (uint32_t r = 0; r < SUB_W; r++) {
-                    const uint32_t b = r < h ? b0 + stride * r : 0u;
-                    ws[r] = plane_window(plane_s, b);
-                    wc[r] = plane_window(plane_c, b);
-                }
+                for (uint32_t r = 0; r < SUB_W; r++) win[r] = plane_window(tile_bits, r < h ? b0 + stride * r : 0u);
 #pragma unroll
                 for (uint32_t r = 0; r < SUB_W; r++) {
                     const uint32_t rmask = r < h ? wmask : 0u;
-                    const uint32_t sg = (uint32_t)ws[r] & rmask;
-                    const uint32_t clear = (uint32_t)wc[r] & rmask;  // backdrop_clear per tile of the row
+                    const uint32_t b = b0 + stride * r;  // (only its low three bits are used: rows the object does not have are masked)
+                    const uint32_t sg = window_bits(win[r], 0u, b) & rmask;
+                    const uint32_t clear = window_bits(win[r], clear_byte, b) & rmask;  // backdrop_clear per tile of the row
                     // include_tile = n_segs != 0 || (backdrop_clear == is_clip) || is_blend
                     const uint32_t in = is_blend ? rmask : (sg | ((is_clip ? clear : ~clear) & rmask));
                     const uint32_t shift = ((ry0 + r) * SUB_W + rx0) & 63u;
@@ -813,11 +814,11 @@ void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     if (n_bit_blocks > 2048u) n_bit_blocks = 2048u;
     if (n_bit_blocks < 1u) n_bit_blocks = 1u;
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
-                       f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.tile_bits_plane_words);
+                       f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits);
     if (mid) (void)hipEventRecord(mid[0], s);
     const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
-                       f.tile_bits_plane_words, f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,
+                       f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,
                        f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills);
 }
 

@@ -63,7 +63,7 @@ struct Lane {
     DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
     DevBuf clip_stack;
     DevBuf coarse_el;                 // coarse: CoarseEl per draw object
-    DevBuf tile_bits;                 // coarse: 3 bit planes over the tile pool
+    DevBuf tile_bits;                 // coarse: 3 bits per tile of the pool, a word per 8 tiles
     DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
     DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
     DevBuf heavy_list;                // flatten: tag indices for the heavy code, 4 lists (one u32 per tag each, worst case)
@@ -229,8 +229,9 @@ uint32_t cov_cap_words(const vello_hip_capacities &d, uint32_t aa_mask) {
     return d.ptcl >= COV_CAP_MAX_WORDS / 2u ? COV_CAP_MAX_WORDS : d.ptcl * 2u;
 }
 
-// words of one coarse bit plane: 2 per 64 tiles + 2 of slack for the 64-bit windows read at the last tiles
-uint32_t tile_bits_plane_words(uint32_t tiles) { return (tiles + 63u) / 64u * 2u + 2u; }
+// words of coarse's tile bits: one per 8 tiles (three planes' bytes side by side, coarse.hip plane_window) + 2 of slack for
+// the two-word windows read at the last tiles
+uint32_t tile_bits_words(uint32_t tiles) { return (tiles + 63u) / 64u * 8u + 2u; }
 
 // pool-capacity buffers of one lane (reference sizes: config.rs:398-408)
 int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
@@ -244,7 +245,7 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_SEGMENTS], (size_t)d.segments * sizeof(Segment)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BLEND_SPILL], (size_t)d.blend_spill * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_PTCL], (size_t)d.ptcl * 4u))) return r;
-    if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_plane_words(d.tiles) * 3u * 4u))) return r;
+    if ((r = ensure(c, l.tile_bits, (size_t)tile_bits_words(d.tiles) * 4u))) return r;
     if ((r = ensure(c, l.cov, (size_t)cov_cap_words(d, c->aa_mask) * 4u))) return r;
     return 0;
 }
@@ -253,7 +254,7 @@ int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
 size_t pool_bytes(const vello_hip_capacities &d, uint32_t aa_mask) {
     return (size_t)d.lines * sizeof(LineSoup) + (size_t)d.bin_data * 4u + (size_t)d.tiles * sizeof(Tile) +
            (size_t)d.seg_counts * sizeof(SegmentCount) + (size_t)d.segments * sizeof(Segment) + (size_t)d.blend_spill * 4u +
-           (size_t)d.ptcl * 4u + (size_t)tile_bits_plane_words(d.tiles) * 12u + (size_t)cov_cap_words(d, aa_mask) * 4u;
+           (size_t)d.ptcl * 4u + (size_t)tile_bits_words(d.tiles) * 4u + (size_t)cov_cap_words(d, aa_mask) * 4u;
 }
 
 // Makes `d` the context's capacities, or leaves the context as it was: ensure() frees a buffer before it allocates the
@@ -430,7 +431,6 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.clip_stack = (uint32_t *)l.clip_stack.ptr;
     f.coarse_el = (CoarseEl *)l.coarse_el.ptr;
     f.tile_bits = (uint32_t *)l.tile_bits.ptr;
-    f.tile_bits_plane_words = tile_bits_plane_words(c->caps.tiles);
     f.tile_order = (uint32_t *)l.tile_order.ptr;
     f.slice_items = (SliceItem *)l.slice_items.ptr;
     f.slice_counters = (uint32_t *)l.slice_counters.ptr;
