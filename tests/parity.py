@@ -472,6 +472,11 @@ def check_prezeroed_tiles(make_engine, exact_tiles=True):
                 bump = e.bump()
                 assert bump["failed"] == 0, bump
                 tiles = e.read_buffer("tiles", np.uint32, 8 * bump["tile"]).reshape(-1, 2).copy()
+                if not exact_tiles:
+                    # (on a GPU tile_alloc's workgroups draw their ranges from bump.tile in whatever order they arrive: the pool
+                    # path by path, in path order)
+                    paths = e.read_buffer("paths", np.uint32, 32 * layout.n_draw_objects).reshape(-1, 8)
+                    tiles = np.concatenate([tiles[p[4]:p[4] + (p[2] - p[0]) * (p[3] - p[1])] for p in paths] + [np.zeros((0, 2), np.uint32)])
                 got.append((img, bump, tiles))
             seen.append(got[0][1]["tile"])
             assert got[0][1] == got[1][1], (i, got[0][1], got[1][1])
