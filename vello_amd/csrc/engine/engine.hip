@@ -569,6 +569,10 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     // The tiles a finished frame of the scene took, zeroed beside k_flatten_light instead of by tile_alloc (Frame::prezero_tiles): only
     // when both launches are this call's, and for pools worth the trouble (2 MB of tiles).
     f.prezero_tiles = 0u;
+    {   // MEASUREMENT SEAM: VELLO_HIP_PREZERO_AT=light in the environment keeps the zero fill in k_flatten_light's launch
+        const char *at = std::getenv("VELLO_HIP_PREZERO_AT");
+        f.prezero_in_scan = first == VELLO_HIP_STAGE_PATHTAG_SCAN && !(at && at[0] == 'l');
+    }
     if (!fuse_a && first <= VELLO_HIP_STAGE_FLATTEN && last >= VELLO_HIP_STAGE_TILE_ALLOC && f.n_tag_words != 0u &&
         (c->debug_flags & VELLO_HIP_DEBUG_NO_PREZERO) == 0u) {
         const int64_t t = slot_of(c, l).tiles_used;

@@ -1137,15 +1137,10 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
         draw_scan_workgroup(cfg, scene, control, draw_state, path_bboxes, draw_monoids, info, clip_inp);
         return;
     }
-    // Behind them, the workgroups that zero tiles [0, prezero_tiles) of the pool for this frame's tile_alloc (Frame::prezero_tiles:
-    // nothing of the frame has touched the pool yet, the lane's previous frame is behind us on the stream): 16-byte stores, a
-    // contiguous piece per workgroup, under the flatten workgroups' dependent loads.  prezero_tiles is even (16-byte aligned end).
+    // Behind them, when the frame's pathtag scan was not this call's (Frame::prezero_in_scan), the workgroups that zero tiles
+    // [0, prezero_tiles) of the pool for this frame's tile_alloc (scan_body.h prezero_workgroup)
     if (blockIdx.x < n_draw_blocks + n_zero_blocks) {
-        const uint32_t zb = blockIdx.x - n_draw_blocks, pairs = prezero_tiles / 2u;
-        const uint32_t per = (pairs + n_zero_blocks - 1u) / n_zero_blocks;
-        const uint32_t lo = minu(zb * per, pairs), hi = minu(lo + per, pairs);
-        uint4 *t128 = reinterpret_cast<uint4 *>(tiles);
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) t128[i] = make_uint4(0u, 0u, 0u, 0u);
+        prezero_workgroup(tiles, prezero_tiles, blockIdx.x - n_draw_blocks, n_zero_blocks);
         return;
     }
     flatten_light_workgroup(cfg, blockIdx.x - n_draw_blocks - n_zero_blocks, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list);
@@ -1746,9 +1741,7 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
         return;
     }
     const uint32_t grid_draw = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
-    // (Frame::prezero_tiles: a piece of 64 KB or more per workgroup, 1 024 workgroups at most)
-    uint32_t grid_zero = (f.prezero_tiles + 8191u) / 8192u;
-    if (grid_zero > 1024u) grid_zero = 1024u;
+    const uint32_t grid_zero = f.prezero_in_scan ? 0u : prezero_grid(f.prezero_tiles);
     if (!light_done)
         hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw + grid_zero), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
                            f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp, f.tiles, f.prezero_tiles, grid_zero);
