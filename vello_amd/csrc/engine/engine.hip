@@ -572,6 +572,8 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     {   // MEASUREMENT SEAM: VELLO_HIP_PREZERO_AT=light in the environment keeps the zero fill in k_flatten_light's launch
         const char *at = std::getenv("VELLO_HIP_PREZERO_AT");
         f.prezero_in_scan = first == VELLO_HIP_STAGE_PATHTAG_SCAN && !(at && at[0] == 'l');
+        const char *pm = std::getenv("VELLO_HIP_PREZERO_MODE");
+        f.prezero_mode = pm ? (uint32_t)std::strtoul(pm, nullptr, 10) : 0u;
     }
     if (!fuse_a && first <= VELLO_HIP_STAGE_FLATTEN && last >= VELLO_HIP_STAGE_TILE_ALLOC && f.n_tag_words != 0u &&
         (c->debug_flags & VELLO_HIP_DEBUG_NO_PREZERO) == 0u) {

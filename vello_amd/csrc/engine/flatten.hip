@@ -1140,7 +1140,7 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
     // Behind them, when the frame's pathtag scan was not this call's (Frame::prezero_in_scan), the workgroups that zero tiles
     // [0, prezero_tiles) of the pool for this frame's tile_alloc (scan_body.h prezero_workgroup)
     if (blockIdx.x < n_draw_blocks + n_zero_blocks) {
-        prezero_workgroup(tiles, prezero_tiles, blockIdx.x - n_draw_blocks, n_zero_blocks);
+        prezero_workgroup(tiles, prezero_tiles, blockIdx.x - n_draw_blocks, n_zero_blocks, 0u);
         return;
     }
     flatten_light_workgroup(cfg, blockIdx.x - n_draw_blocks - n_zero_blocks, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list);
