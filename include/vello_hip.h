@@ -205,9 +205,6 @@ uint32_t vello_hip_last_render_attempts(vello_hip_ctx *ctx);
 /* Launches in which the stages of a small scene shared a kernel (VELLO_HIP_DEBUG_NO_FUSION), counted since the context was
  * created: lets a test see that the scene it renders took that path. */
 uint64_t vello_hip_fused_launches(vello_hip_ctx *ctx);
-/* Tiles of the pool that the latest frame enqueued had zeroed beside flatten's first launch instead of by tile_alloc
- * (VELLO_HIP_DEBUG_NO_PREZERO; 0 until a finished frame of the scene has shown how many it takes): lets a test see the path taken. */
-uint32_t vello_hip_last_prezero_tiles(vello_hip_ctx *ctx);
 int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const vello_hip_layout *layout,
                                   const vello_hip_render_params *params, vello_hip_capacities *out);
 
@@ -227,13 +224,9 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * the list, and by the scene's size before there is one): same line soup as a multiset -- so that tests can hold both sets of
  * kernels to the oracle on the same scenes.
  * VELLO_HIP_DEBUG_NO_FUSION launches every stage of a small scene as a kernel of its own (normally the workgroups of consecutive
- * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers.
- * VELLO_HIP_DEBUG_NO_PREZERO makes tile_alloc zero every tile it hands out, as tile_alloc.wgsl:104-122 does (normally, once a
- * finished frame of the scene has shown how many tiles it takes, that many are zeroed by workgroups riding in flatten's first
- * launch and tile_alloc zeroes only what lies beyond them): same tiles. */
+ * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers. */
 enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8,
-       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64,
-       VELLO_HIP_DEBUG_NO_PREZERO = 128 };
+       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -17,7 +17,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

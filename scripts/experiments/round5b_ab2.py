@@ -9,13 +9,13 @@ import os
 import sys
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.argv = [sys.argv[0]] + sys.argv[1:]
 order = sys.argv[1] if len(sys.argv) > 1 else "APAP"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 sys.argv = [sys.argv[0], str(reps)]
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "scripts", "experiments"))
 import round5b_ab as R  # noqa: E402
 
 wl = R.make_workload("d2")

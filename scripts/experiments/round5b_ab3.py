@@ -7,10 +7,10 @@ import statistics
 import sys
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 sys.argv = [sys.argv[0], str(reps)]
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "scripts", "experiments"))
 import round5b_ab as R  # noqa: E402
 
 for key in R.SCENES:

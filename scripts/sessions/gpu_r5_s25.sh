@@ -6,4 +6,4 @@ O=gpurun_out/r5s25
 mkdir -p $O
 cp .commit_stamp $O/commit.txt 2>/dev/null || true
 (timeout 200 python -m pytest tests/test_gpu_parity.py -x -q -k "tiles_zeroed" 2>&1 | tail -8) > $O/new_tests.log; tail -3 $O/new_tests.log
-timeout 300 python scripts/round5b_ab3.py 3 > $O/ab3.jsonl 2> $O/ab3.txt; grep -v amdgpu.ids $O/ab3.txt
+timeout 300 python scripts/experiments/round5b_ab3.py 3 > $O/ab3.jsonl 2> $O/ab3.txt; grep -v amdgpu.ids $O/ab3.txt

@@ -6,4 +6,4 @@ O=gpurun_out/r5s26
 mkdir -p $O
 cp .commit_stamp $O/commit.txt 2>/dev/null || true
 for m in 1 2 3; do (VELLO_HIP_PREZERO_MODE=$m timeout 100 python -m pytest tests/test_gpu_parity.py -x -q -k "tiles_zeroed" 2>&1 | tail -2) ; done > $O/new_tests.log; cat $O/new_tests.log
-timeout 300 python scripts/round5b_ab4.py 3 > $O/ab4.jsonl 2> $O/ab4.txt; grep -v amdgpu.ids $O/ab4.txt
+timeout 300 python scripts/experiments/round5b_ab4.py 3 > $O/ab4.jsonl 2> $O/ab4.txt; grep -v amdgpu.ids $O/ab4.txt

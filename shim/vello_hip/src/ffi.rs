@@ -78,7 +78,6 @@ pub const VELLO_HIP_DEBUG_FINE_SLICES: u32 = 8;
 pub const VELLO_HIP_DEBUG_FLATTEN_COOP: u32 = 16;
 pub const VELLO_HIP_DEBUG_FLATTEN_ALONE: u32 = 32;
 pub const VELLO_HIP_DEBUG_NO_FUSION: u32 = 64;
-pub const VELLO_HIP_DEBUG_NO_PREZERO: u32 = 128;
 pub const VELLO_HIP_STAGE_COUNT: usize = 11;
 
 unsafe extern "C" {
@@ -94,7 +93,6 @@ unsafe extern "C" {
     pub fn vello_hip_grow_pools(ctx: *mut vello_hip_ctx, demand: *const vello_hip_bump, new_caps: *mut vello_hip_capacities) -> c_int;
     pub fn vello_hip_last_render_attempts(ctx: *mut vello_hip_ctx) -> u32;
     pub fn vello_hip_fused_launches(ctx: *mut vello_hip_ctx) -> u64;
-    pub fn vello_hip_last_prezero_tiles(ctx: *mut vello_hip_ctx) -> u32;
     pub fn vello_hip_estimate_capacities(scene: *const u8, scene_len: usize, layout: *const vello_hip_layout, params: *const vello_hip_render_params, out: *mut vello_hip_capacities) -> c_int;
     pub fn vello_hip_set_auto_grow(ctx: *mut vello_hip_ctx, enabled: c_int) -> c_int;
     pub fn vello_hip_set_debug_flags(ctx: *mut vello_hip_ctx, flags: u32) -> c_int;

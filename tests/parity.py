@@ -434,60 +434,3 @@ def check_front_fusion(engine, case, in_flight=(1, 2)):
     finally:
         engine.set_frames_in_flight(1)
         engine.set_debug_flags()
-
-
-def check_prezeroed_tiles(make_engine, exact_tiles=True):
-    """Frame::prezero_tiles (engine.h): from the frame after the first finished one of an uploaded scene, the tiles that frame took
-    are zeroed by workgroups riding in k_flatten_light's launch and tile_alloc zeroes only what lies beyond them.  The hint is the
-    tile count of an EARLIER frame: exact (same target), too large (a smaller target next) and too small (a larger one next) --
-    image, bump counters and the whole tile pool against a context that never pre-zeroes (VELLO_HIP_DEBUG_NO_PREZERO), and the
-    image against the oracle.  make_engine() must create its context with VELLO_HIP_PREZERO_MIN_TILES=1 in the environment."""
-    import workloads
-    from vello_amd import AaConfig
-
-    packed, layout = workloads.random_test_scene(5, n_paths=300, size=384.0, strokes=True, clips=True).resolve()
-    eng, plain = make_engine(), make_engine()
-    # (a scene this small would have its front stages share launches -- k_front zeroes nothing ahead of tile_alloc: every stage on its own)
-    eng.set_debug_flags(no_fusion=True)
-    plain.set_debug_flags(no_fusion=True, no_prezero=True)
-    oracle = Oracle()
-    # (the hint is learnt ONCE per uploaded scene -- the control block of a finished frame is read back only while something about the
-    # scene is unknown: first a small target, so that the larger ones after it find the hint too small; then, the scene uploaded
-    # again, a large one first, so that the smaller one finds it too large)
-    phases = [(1, [(200, 136), (384, 384), (384, 384), (200, 136)]), (2, [(384, 384), (200, 136), (384, 384), (384, 384)])]
-    for n_in_flight, sizes in phases:
-        seen = []  # bump.tile of this phase's frames
-        for e in (eng, plain):
-            e.upload_scene(packed, layout)
-            e.set_frames_in_flight(n_in_flight)
-        for i, (w, h) in enumerate(sizes):
-            aa = AaConfig.Msaa16 if i % 2 == 0 else AaConfig.Area
-            got = []
-            for e in (eng, plain):
-                e.render_resident(w, h, 0xFF000000, aa)
-                want = 0 if (e is plain or len(seen) == 0) else (seen[0] + 1) & ~1
-                assert e.last_prezero_tiles() == want, (n_in_flight, i, e.last_prezero_tiles(), want)
-                e.sync_frame(0)
-                img = e.read_buffer("output", np.uint8, w * h * 4).reshape(h, w, 4).copy()
-                bump = e.bump()
-                assert bump["failed"] == 0, bump
-                tiles = e.read_buffer("tiles", np.uint32, 8 * bump["tile"]).reshape(-1, 2).copy()
-                if not exact_tiles:
-                    # (on a GPU tile_alloc's workgroups draw their ranges from bump.tile in whatever order they arrive: the pool
-                    # path by path, in path order)
-                    paths = e.read_buffer("paths", np.uint32, 32 * layout.n_draw_objects).reshape(-1, 8)
-                    tiles = np.concatenate([tiles[p[4]:p[4] + (p[2] - p[0]) * (p[3] - p[1])] for p in paths] + [np.zeros((0, 2), np.uint32)])
-                got.append((img, bump, tiles))
-            seen.append(got[0][1]["tile"])
-            assert got[0][1] == got[1][1], (i, got[0][1], got[1][1])
-            # (a tile's second word is the segment slice coarse gave it: which slice is the order of its atomics on a GPU)
-            assert np.array_equal(got[0][2][:, 0], got[1][2][:, 0]), f"frame {i}: backdrops differ"
-            if exact_tiles:
-                assert np.array_equal(got[0][2], got[1][2]), f"frame {i}: tile pools differ"
-            assert np.array_equal(got[0][0], got[1][0]), f"frame {i}: images differ"
-            oracle.set_scene(packed, layout, w, h, 0xFF000000, int(aa))
-            ref = oracle.render()
-            d = np.abs(got[0][0].astype(np.int32) - ref.astype(np.int32)).max()
-            assert d <= (1 if aa == AaConfig.Area else 0), (i, d)
-        assert eng.sync() == 0 and plain.sync() == 0
-        assert seen[1] != seen[0]

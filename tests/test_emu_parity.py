@@ -977,20 +977,6 @@ def test_emu_front_fusion(emu_engine, case):
     check_front_fusion(emu_engine, front_fusion_cases()[case])
 
 
-def test_emu_tiles_zeroed_beside_flatten(built, monkeypatch):
-    # Frame::prezero_tiles: the zero fill of the tiles an earlier frame of the scene took, in k_flatten_light's launch
-    import vello_amd
-    import vello_amd._lib as L
-    from tests.parity import check_prezeroed_tiles
-
-    monkeypatch.setenv("VELLO_HIP_PREZERO_MIN_TILES", "1")
-    L._use_library(emu_library_path())
-    try:
-        check_prezeroed_tiles(lambda: vello_amd.Engine())
-    finally:
-        L._use_library(None)
-
-
 def test_emu_clip_stage_partitioned(emu_engine):
     # a5: clip_reduce / clip_leaf as partitioned kernels (clip.hip) and as the one-wave stack machine, against the oracle's stack
     from tests.parity import clip_structures, compare_clip_stage

@@ -733,43 +733,6 @@ def test_gpu_front_fusion(gpu_engine, case):
     check_front_fusion(gpu_engine, front_fusion_cases()[case])
 
 
-def test_gpu_tiles_zeroed_beside_flatten(built, monkeypatch):
-    # Frame::prezero_tiles: the tiles an earlier frame of the scene took are zeroed in k_flatten_light's launch, tile_alloc zeroes the
-    # rest -- hint exact, too small, too large; one lane and two; against a context that never does it and against the oracle
-    import vello_amd
-    from tests.parity import check_prezeroed_tiles
-
-    monkeypatch.setenv("VELLO_HIP_PREZERO_MIN_TILES", "1")
-    check_prezeroed_tiles(lambda: vello_amd.Engine(), exact_tiles=False)
-
-
-def test_gpu_tiles_zeroed_beside_flatten_road_map(built):
-    # ... and at the size it is for, with the threshold as shipped: the road map's 10 M tiles.  Frame 0 finds no hint (tile_alloc zeroes
-    # everything); the later ones, on four lanes, must show the same image and counters
-    import torch
-    import vello_amd
-    import bench
-
-    packed, layout = workloads.paris_like_scene_d2().resolve()
-    eng = vello_amd.Engine(capacities=bench.D2_CAPS)
-    eng.upload_scene(packed, layout)
-    out = [torch.zeros((1600, 1600, 4), dtype=torch.uint8, device="cuda:0") for _ in range(5)]
-    torch.cuda.synchronize()
-    eng.render_resident(1600, 1600, WHITE, AaConfig.Msaa16, out=out[0])
-    assert eng.last_prezero_tiles() == 0
-    eng.sync_frame(0)
-    first = eng.bump()
-    assert first["failed"] == 0 and first["tile"] > 262144
-    eng.set_frames_in_flight(4)
-    for t in out[1:]:
-        eng.render_resident(1600, 1600, WHITE, AaConfig.Msaa16, out=t)
-        assert eng.last_prezero_tiles() == (first["tile"] + 1) & ~1
-    assert eng.sync() == 0
-    assert eng.bump() == first
-    for t in out[1:]:
-        assert torch.equal(t, out[0])
-
-
 def test_gpu_front_fusion_barrier_stress():
     # k_front's grid barrier under load: the tiger (16 workgroups a launch, on different XCDs) 600 times with four frames in
     # flight, and a scene whose every stage is one workgroup's -- each frame identical to the oracle's

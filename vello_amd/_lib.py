@@ -91,7 +91,6 @@ def load_library():
     sig("vello_hip_set_debug_flags", i32, [vp, u32])
     sig("vello_hip_last_render_attempts", u32, [vp])
     sig("vello_hip_fused_launches", ctypes.c_uint64, [vp])
-    sig("vello_hip_last_prezero_tiles", u32, [vp])
     sig("vello_hip_estimate_capacities", i32, [vp, sz, c.POINTER(LayoutStruct), c.POINTER(RenderParamsStruct), c.POINTER(Capacities)])
     sig("vello_hip_gather_frames", i32, [c.POINTER(vp), u32, i32, c.POINTER(vp), c.POINTER(vp), sz])
     sig("vello_hip_gather_wait", i32, [c.POINTER(vp), u32])

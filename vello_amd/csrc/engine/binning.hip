@@ -13,8 +13,8 @@ __global__ void __launch_bounds__(256) k_binning(Config cfg, const DrawMonoid *_
 }
 
 __global__ void __launch_bounds__(256) k_tile_alloc(Config cfg, const uint32_t *__restrict__ scene, const Bbox4 *__restrict__ draw_bboxes,
-                                                    Bump *bump, Path *__restrict__ paths, Tile *__restrict__ tiles, uint32_t prezero) {
-    tile_alloc_workgroup(cfg, blockIdx.x, scene, draw_bboxes, bump, paths, tiles, prezero);
+                                                    Bump *bump, Path *__restrict__ paths, Tile *__restrict__ tiles) {
+    tile_alloc_workgroup(cfg, blockIdx.x, scene, draw_bboxes, bump, paths, tiles);
 }
 
 void launch_binning(const Frame &f, hipStream_t s) {
@@ -27,7 +27,7 @@ void launch_binning(const Frame &f, hipStream_t s) {
 void launch_tile_alloc(const Frame &f, hipStream_t s) {
     uint32_t n_wg = (f.cfg.layout.n_paths + 255u) / 256u;
     if (n_wg == 0) return;
-    hipLaunchKernelGGL(k_tile_alloc, dim3(n_wg), dim3(256), 0, s, f.cfg, f.scene, f.draw_bboxes, f.bump(), f.paths, f.tiles, f.prezero_tiles);
+    hipLaunchKernelGGL(k_tile_alloc, dim3(n_wg), dim3(256), 0, s, f.cfg, f.scene, f.draw_bboxes, f.bump(), f.paths, f.tiles);
 }
 
 }  // namespace vk

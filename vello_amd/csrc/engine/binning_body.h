@@ -126,9 +126,8 @@ __device__ __forceinline__ void binning_workgroup(const Config &cfg, uint32_t bl
 }
 
 // tile_alloc.wgsl:35-123: per-path tile rectangles, one bump allocation per workgroup, zero fill.
-// Tiles [0, prezero) are zero already (Frame::prezero_tiles: an earlier launch of the same frame filled them).
 __device__ __forceinline__ void tile_alloc_workgroup(const Config &cfg, uint32_t block, const uint32_t *scene, const Bbox4 *draw_bboxes, Bump *bump,
-                                                     Path *paths, Tile *tiles, uint32_t prezero) {
+                                                     Path *paths, Tile *tiles) {
     __shared__ uint32_t sh_scan[4];
     __shared__ uint32_t sh_offset;
     __shared__ uint32_t sh_fill;
@@ -167,6 +166,7 @@ __device__ __forceinline__ void tile_alloc_workgroup(const Config &cfg, uint32_t
     }
     __syncthreads();
     const uint32_t tile_offset = sh_offset;
+    const uint32_t fill = sh_fill;
     if (drawobj_ix < cfg.layout.n_draw_objects) {
         Path p;
         p.bbox[0] = ux0; p.bbox[1] = uy0; p.bbox[2] = ux1; p.bbox[3] = uy1;
@@ -176,13 +176,11 @@ __device__ __forceinline__ void tile_alloc_workgroup(const Config &cfg, uint32_t
     }
     // 16-byte stores over the 16-byte aligned middle of the range, single tiles at its ends
     {
-        // the workgroup's range [tile_offset, tile_offset + sh_fill) less what is zero already
-        const uint32_t end = tile_offset + sh_fill, zero_from = minu(maxu(tile_offset, prezero), end), fill = end - zero_from;
-        const uint32_t head = minu(fill, zero_from & 1u);  // (a Tile is 8 bytes: the pool is 16-byte aligned at even tiles)
-        unsigned long long *t64 = reinterpret_cast<unsigned long long *>(tiles + zero_from);
+        const uint32_t head = minu(fill, tile_offset & 1u);  // (a Tile is 8 bytes: the pool is 16-byte aligned at even tiles)
+        unsigned long long *t64 = reinterpret_cast<unsigned long long *>(tiles + tile_offset);
         if (tid < head) t64[tid] = 0ull;
         const uint32_t pairs = (fill - head) / 2u;
-        uint4 *t128 = reinterpret_cast<uint4 *>(tiles + zero_from + head);
+        uint4 *t128 = reinterpret_cast<uint4 *>(tiles + tile_offset + head);
         for (uint32_t i = tid; i < pairs; i += 256u) t128[i] = make_uint4(0u, 0u, 0u, 0u);
         if (tid == 0u && head + 2u * pairs < fill) t64[fill - 1u] = 0ull;
     }

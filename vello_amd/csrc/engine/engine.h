@@ -177,13 +177,6 @@ struct Frame {
     const uint32_t *mask_lut8;
     const uint32_t *mask_lut16;
     uint32_t zero_bytes;     // the lane's zero region: Control + both look-back states (k_front clears it itself)
-    // Tiles [0, prezero_tiles) of the pool are zeroed by workgroups that ride in k_flatten_light's launch, and tile_alloc leaves
-    // them out of its zero fill: the 80 MB a road map's tile rectangles take are written under the latency-bound front of the
-    // frame instead of as 16 us of their own.  A HINT (the tiles a finished frame of the scene allocated): whatever it is,
-    // tile_alloc zeroes the rest of what it hands out.  0: tile_alloc zeroes everything, as tile_alloc.wgsl:104-122 does.
-    uint32_t prezero_tiles;
-    uint32_t prezero_mode;  // EXPERIMENT: VELLO_HIP_PREZERO_MODE (scan_body.h prezero_workgroup)
-    bool prezero_in_scan;  // ... in k_pathtag_scan's launch (the scan is this call's: the usual case) instead of k_flatten_light's
     uint32_t *front_sync;    // k_front's grid-barrier counter (per lane; only ever grows)
     Bump *bump() const { return &control->bump; }
 };

@@ -5,9 +5,7 @@
 // buffers owned by the context and reused across frames.
 #include "../../../include/vello_hip.h"
 
-#include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,10 +25,6 @@ struct DevBuf {
     void *ptr = nullptr;
     size_t size = 0;
 };
-
-// Frame::prezero_tiles: below this many tiles (2 MB) tile_alloc zeroes them itself.  (TEST SEAM: VELLO_HIP_PREZERO_MIN_TILES in the
-// environment when the context is created -- the suites' scenes take a few thousand tiles.)
-constexpr int64_t PREZERO_MIN_TILES = 262144;
 
 uint32_t align_up(uint32_t len, uint32_t alignment) { return len + ((0u - len) & (alignment - 1u)); }
 
@@ -58,9 +52,6 @@ struct SceneSlot {
     // what k_flatten_light put on flatten's heavy list in a finished frame of this scene: fills' curves, stroked curves (+ the cap
     // markers of open subpaths), stroked lines (-1: not known yet): picks the kernels that take the list (Frame::flatten_coop)
     int64_t heavy_curves = -1, heavy_strokes = -1;
-    // tiles a finished frame of this scene allocated (bump.tile; -1: not known yet): zeroed beside flatten's first launch instead of
-    // by tile_alloc (Frame::prezero_tiles).  Depends on the target's size too -- a hint: tile_alloc zeroes whatever lies beyond it.
-    int64_t tiles_used = -1;
     uint64_t generation = 0;  // bumped by every upload into the slot: a lane's finished frame speaks for the scene it rendered only
 };
 
@@ -68,7 +59,6 @@ struct Lane {
     hipStream_t stream = nullptr;
     SceneSlot own;          // vello_hip_render_frame: the scene of the frame this lane is rendering
     bool use_own = false;   // else the context's shared scene (vello_hip_upload_scene)
-    bool tile_alloc_ran = false;  // the lane's latest frame got as far as tile_alloc (its bump.tile speaks for the scene)
     DevBuf buf[VELLO_HIP_BUF_COUNT];  // SCENE / CONFIG entries unused (shared, see ctx)
     DevBuf zero_region;               // Control + look-back states (BUF_BUMP aliases its head)
     DevBuf clip_stack;
@@ -106,7 +96,6 @@ struct Staging {
 
 struct vello_hip_ctx {
     int device = 0;
-    int64_t prezero_min_tiles = PREZERO_MIN_TILES;
     uint32_t aa_mask = 0;
     vello_hip_capacities caps{};
     DevBuf config;
@@ -131,7 +120,6 @@ struct vello_hip_ctx {
     bool force_brushes = false;  // pre-warm: run fine's brush specialisation on a scene without brushes
     uint32_t last_render_attempts = 0;  // rounds the last vello_hip_render needed (robust mode)
     uint64_t fused_launches = 0;  // k_front launches so far (vello_hip_fused_launches)
-    uint32_t last_prezero_tiles = 0;  // Frame::prezero_tiles of the latest stage range that held tile_alloc (vello_hip_last_prezero_tiles)
     // last frame
     Config cfg{};
     bool have_cfg = false;
@@ -245,39 +233,11 @@ uint32_t cov_cap_words(const vello_hip_capacities &d, uint32_t aa_mask) {
 // the two-word windows read at the last tiles
 uint32_t tile_bits_words(uint32_t tiles) { return (tiles + 63u) / 64u * 8u + 2u; }
 
-// A lane's stream.  MEASUREMENT SEAM (round 5): VELLO_HIP_LANE_CU_SPLIT=<k>[i] in the environment gives lane j a
-// stream restricted to partition j mod k of the device's CUs (hipExtStreamCreateWithCUMask) -- contiguous runs of mask bits, or with
-// the `i` suffix every k-th bit -- so that frames in flight share the chip by CUs instead of by whichever kernel's workgroups
-// fit the holes the others leave.  Unset (the default, and what every number in profiles/ was measured with unless its file
-// says otherwise): an ordinary non-blocking stream on all CUs.
-int create_lane_stream(vello_hip_ctx *c, hipStream_t *out, uint32_t lane_ix) {
-#ifndef VELLO_SIMT_EMU
-    const char *env = std::getenv("VELLO_HIP_LANE_CU_SPLIT");
-    const uint32_t k = env ? (uint32_t)std::strtoul(env, nullptr, 10) : 0u;
-    if (k < 2u || k > 8u) {
-#endif
-        (void)lane_ix;
-        HIP_TRY(c, hipStreamCreateWithFlags(out, hipStreamNonBlocking));
-        return 0;
-#ifndef VELLO_SIMT_EMU
-    }
-    const bool interleaved = std::strchr(env, 'i') != nullptr;
-    int n_cu = 0;
-    HIP_TRY(c, hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device));
-    const uint32_t n = (uint32_t)n_cu, part = lane_ix % k, per = (n + k - 1u) / k;
-    std::vector<uint32_t> mask((n + 31u) / 32u, 0u);
-    for (uint32_t b = 0; b < n; b++)
-        if ((interleaved ? b % k : b / per) == part) mask[b >> 5] |= 1u << (b & 31u);
-    HIP_TRY(c, hipExtStreamCreateWithCUMask(out, (uint32_t)mask.size(), mask.data()));
-    return 0;
-#endif
-}
-
 // pool-capacity buffers of one lane (reference sizes: config.rs:398-408)
 int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     const vello_hip_capacities &d = c->caps;
     int r;
-    if (!l.stream && (r = create_lane_stream(c, &l.stream, (uint32_t)(&l - c->lanes.data())))) return r;
+    if (!l.stream) HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile)))) return r;
@@ -566,21 +526,6 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         fuse_all = fuse_a && fuse_b && (pm & (1u << VELLO_HIP_STAGE_CLIP)) == 0u && f.cfg.layout.n_clips == 0u &&
                    flatten_n_seg_max(f) <= FRONT_TINY_SEGMENTS && f.flatten_coop && f.stroke_kernel_min_lines != 0u;
     }
-    // The tiles a finished frame of the scene took, zeroed beside k_flatten_light instead of by tile_alloc (Frame::prezero_tiles): only
-    // when both launches are this call's, and for pools worth the trouble (2 MB of tiles).
-    f.prezero_tiles = 0u;
-    {   // MEASUREMENT SEAM: VELLO_HIP_PREZERO_AT=light in the environment keeps the zero fill in k_flatten_light's launch
-        const char *at = std::getenv("VELLO_HIP_PREZERO_AT");
-        f.prezero_in_scan = first == VELLO_HIP_STAGE_PATHTAG_SCAN && !(at && at[0] == 'l');
-        const char *pm = std::getenv("VELLO_HIP_PREZERO_MODE");
-        f.prezero_mode = pm ? (uint32_t)std::strtoul(pm, nullptr, 10) : 0u;
-    }
-    if (!fuse_a && first <= VELLO_HIP_STAGE_FLATTEN && last >= VELLO_HIP_STAGE_TILE_ALLOC && f.n_tag_words != 0u &&
-        (c->debug_flags & VELLO_HIP_DEBUG_NO_PREZERO) == 0u) {
-        const int64_t t = slot_of(c, l).tiles_used;
-        if (t >= c->prezero_min_tiles) f.prezero_tiles = (uint32_t)std::min<int64_t>((t + 1) & ~(int64_t)1, (int64_t)(c->caps.tiles & ~1u));
-    }
-    if (last >= VELLO_HIP_STAGE_TILE_ALLOC && first <= VELLO_HIP_STAGE_TILE_ALLOC) c->last_prezero_tiles = f.prezero_tiles;
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
         Lane::EvPair ev{s, nullptr, nullptr, {nullptr, nullptr}};
@@ -595,7 +540,6 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
             l.flatten_ran = false;
-            l.tile_alloc_ran = false;
             if (fuse_all) {
                 c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT | FRONT_HEAVY | FRONT_BINNING | FRONT_TILE_ALLOC, true,
                                                    l.front_sync_value);
@@ -627,7 +571,6 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             }
             break;
         case VELLO_HIP_STAGE_TILE_ALLOC:
-            l.tile_alloc_ran = true;
             if (!fuse_all && !fuse_b) launch_tile_alloc(f, st);
             break;
         case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, st); break;
@@ -745,7 +688,6 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
     vello_hip_ctx *c = new vello_hip_ctx();
     c->device = device;
     c->aa_mask = aa_mask ? (aa_mask & VELLO_HIP_AA_MASK_ALL) : VELLO_HIP_AA_MASK_ALL;
-    if (const char *env = std::getenv("VELLO_HIP_PREZERO_MIN_TILES")) c->prezero_min_tiles = (int64_t)std::strtoll(env, nullptr, 10);
     // reference pool sizes, vello_encoding/src/config.rs:398-408
     vello_hip_capacities d{1u << 21, 1u << 18, 1u << 21, 1u << 21, 1u << 21, 1u << 20, 1u << 23};
     if (caps) {
@@ -908,7 +850,6 @@ static int load_slot(vello_hip_ctx *c, SceneSlot &sc, hipStream_t st, const uint
     sc.heavy_curves = sc.heavy_strokes = -1;
     sc.soup_lines = -1;
     sc.slice_demand = -1;
-    sc.tiles_used = -1;
     sc.generation += 1u;
     {
         // The same pass checks what draw_leaf / clip_leaf will index with (shared/drawtag.wgsl:47-54: bit 0 = clip,
@@ -1091,7 +1032,7 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
     HIP_TRY(c, hipStreamSynchronize(l.stream));
     // (once per scene: what flatten counted, so that later frames can leave out a launch that would exit at once)
     SceneSlot &sc = slot_of(c, l);
-    if (l.used && l.flatten_ran && l.zero_region.ptr && l.frame_generation == sc.generation && (sc.stroke_lines < 0 || (l.slices_on && sc.slice_demand < 0) || (l.tile_alloc_ran && sc.tiles_used < 0))) {
+    if (l.used && l.flatten_ran && l.zero_region.ptr && l.frame_generation == sc.generation && (sc.stroke_lines < 0 || (l.slices_on && sc.slice_demand < 0))) {
         Control ctl;
         HIP_TRY(c, hipMemcpy(&ctl, l.zero_region.ptr, sizeof ctl, hipMemcpyDeviceToHost));
         if (ctl.bump.failed == 0u) {
@@ -1099,7 +1040,6 @@ int vello_hip_sync_frame(vello_hip_ctx *c, uint32_t age) {
             sc.heavy_curves = (int64_t)ctl.heavy_count[0];
             sc.heavy_strokes = (int64_t)ctl.heavy_count[1];
             sc.soup_lines = (int64_t)ctl.bump.lines;
-            if (l.tile_alloc_ran) sc.tiles_used = (int64_t)ctl.bump.tile;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }
     }
@@ -1122,7 +1062,6 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
             sc.heavy_curves = (int64_t)ctl.heavy_count[0];
             sc.heavy_strokes = (int64_t)ctl.heavy_count[1];
             sc.soup_lines = (int64_t)ctl.bump.lines;
-            if (l.tile_alloc_ran) sc.tiles_used = (int64_t)ctl.bump.tile;
             if (l.slices_on && (int64_t)ctl.slice_items > sc.slice_demand) sc.slice_demand = (int64_t)ctl.slice_items;
         }
         return VELLO_HIP_OK;
@@ -1156,7 +1095,6 @@ int vello_hip_sync(vello_hip_ctx *c) {
 
 uint32_t vello_hip_last_render_attempts(vello_hip_ctx *c) { return c ? c->last_render_attempts : 0u; }
 uint64_t vello_hip_fused_launches(vello_hip_ctx *c) { return c ? c->fused_launches : 0u; }
-uint32_t vello_hip_last_prezero_tiles(vello_hip_ctx *c) { return c ? c->last_prezero_tiles : 0u; }
 
 void *vello_hip_get_stream(vello_hip_ctx *c) { return c ? (void *)c->lanes[c->last_lane].stream : nullptr; }
 

@@ -1131,19 +1131,12 @@ __global__ void __launch_bounds__(256, 4) k_flatten_light(Config cfg, uint32_t n
                                                           const TagMonoid *__restrict__ tag_monoids, PathBbox *path_bboxes,
                                                           Control *control, LineSoup *lines, uint32_t *heavy_list, uint32_t n_draw_blocks,
                                                           unsigned long long *draw_state, DrawMonoid *__restrict__ draw_monoids,
-                                                          uint32_t *__restrict__ info, Clip *__restrict__ clip_inp, Tile *__restrict__ tiles,
-                                                          uint32_t prezero_tiles, uint32_t n_zero_blocks) {
+                                                          uint32_t *__restrict__ info, Clip *__restrict__ clip_inp) {
     if (blockIdx.x < n_draw_blocks) {
         draw_scan_workgroup(cfg, scene, control, draw_state, path_bboxes, draw_monoids, info, clip_inp);
         return;
     }
-    // Behind them, when the frame's pathtag scan was not this call's (Frame::prezero_in_scan), the workgroups that zero tiles
-    // [0, prezero_tiles) of the pool for this frame's tile_alloc (scan_body.h prezero_workgroup)
-    if (blockIdx.x < n_draw_blocks + n_zero_blocks) {
-        prezero_workgroup(tiles, prezero_tiles, blockIdx.x - n_draw_blocks, n_zero_blocks, 0u);
-        return;
-    }
-    flatten_light_workgroup(cfg, blockIdx.x - n_draw_blocks - n_zero_blocks, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list);
+    flatten_light_workgroup(cfg, blockIdx.x - n_draw_blocks, n_tags, scene, tag_monoids, path_bboxes, control, lines, heavy_list);
 }
 
 // ---- stroked lines: flatten_tag's stroke branch without the Euler-spiral flattener ------------------------------
@@ -1656,7 +1649,7 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
     }
     if (a.stages & FRONT_TILE_ALLOC) {
         for (uint32_t b = wg; b < a.n_tile_alloc_blocks; b += n_wg) {
-            tile_alloc_workgroup(cfg, b, a.scene, a.draw_bboxes, &a.control->bump, a.paths, a.tiles, 0u);
+            tile_alloc_workgroup(cfg, b, a.scene, a.draw_bboxes, &a.control->bump, a.paths, a.tiles);
             __syncthreads();
         }
     }
@@ -1741,10 +1734,9 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
         return;
     }
     const uint32_t grid_draw = with_draw_scan ? (f.cfg.layout.n_draw_objects + DRAW_PART - 1u) / DRAW_PART : 0u;
-    const uint32_t grid_zero = f.prezero_in_scan ? 0u : prezero_grid(f.prezero_tiles);
     if (!light_done)
-        hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw + grid_zero), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
-                           f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp, f.tiles, f.prezero_tiles, grid_zero);
+        hipLaunchKernelGGL(k_flatten_light, dim3(grid + grid_draw), dim3(256), 0, s, f.cfg, n_tags, f.scene, f.tag_monoids, f.path_bboxes, f.control,
+                           f.lines, f.heavy_list, grid_draw, f.draw_state, f.draw_monoids, f.info_bin_data, f.clip_inp);
     if (mid) (void)hipEventRecord(mid[0], s);
     // enough workgroups for a wave per list entry on small scenes and for one round per workgroup on large ones
     // (workgroups beyond the list exit at once)

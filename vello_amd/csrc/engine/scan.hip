@@ -11,22 +11,15 @@ namespace vk {
 
 __global__ void __launch_bounds__(256) k_pathtag_scan(Config cfg, uint32_t n_tag_words, uint32_t n_scene_words, const uint32_t *__restrict__ scene,
                                                       Control *control, unsigned long long *state,
-                                                      TagMonoid *__restrict__ tag_monoids, PathBbox *__restrict__ path_bboxes, uint32_t n_parts,
-                                                      Tile *__restrict__ tiles, uint32_t prezero_tiles, uint32_t prezero_mode) {
-    // (behind the scan's partitions: the workgroups of Frame::prezero_tiles, scan_body.h prezero_workgroup)
-    if (blockIdx.x >= n_parts) {
-        prezero_workgroup(tiles, prezero_tiles, blockIdx.x - n_parts, gridDim.x - n_parts, prezero_mode);
-        return;
-    }
-    pathtag_scan_workgroup(cfg, blockIdx.x, n_parts, n_tag_words, n_scene_words, scene, control, state, tag_monoids, path_bboxes);
+                                                      TagMonoid *__restrict__ tag_monoids, PathBbox *__restrict__ path_bboxes) {
+    pathtag_scan_workgroup(cfg, blockIdx.x, gridDim.x, n_tag_words, n_scene_words, scene, control, state, tag_monoids, path_bboxes);
 }
 
 void launch_pathtag_scan(const Frame &f, hipStream_t s) {
     uint32_t n_parts = (f.n_tag_words + PATHTAG_PART_WORDS - 1u) / PATHTAG_PART_WORDS;
     if (n_parts == 0) n_parts = 1;
-    const uint32_t grid_zero = f.prezero_in_scan ? prezero_grid(f.prezero_tiles) : 0u;
-    hipLaunchKernelGGL(k_pathtag_scan, dim3(n_parts + grid_zero), dim3(256), 0, s, f.cfg, f.n_tag_words, f.n_scene_words, f.scene, f.control,
-                       f.pathtag_state, f.tag_monoids, f.path_bboxes, n_parts, f.tiles, f.prezero_tiles, f.prezero_mode);
+    hipLaunchKernelGGL(k_pathtag_scan, dim3(n_parts), dim3(256), 0, s, f.cfg, f.n_tag_words, f.n_scene_words, f.scene, f.control,
+                       f.pathtag_state, f.tag_monoids, f.path_bboxes);
 }
 
 }  // namespace vk

@@ -20,42 +20,6 @@ __device__ __forceinline__ TagMonoid reduce_tag(uint32_t tag_word) {
     return c;
 }
 
-// Frame::prezero_tiles: workgroup `zb` of `n_zero_blocks` zeroes its contiguous piece of tiles [0, prezero_tiles) of the pool for
-// this frame's tile_alloc (nothing of the frame has touched the pool yet, the lane's previous frame is behind us on the stream):
-// 16-byte stores.  prezero_tiles is even (a Tile is 8 bytes: a 16-byte aligned end).  Rides in k_pathtag_scan's launch, whose
-// partitions keep a fraction of the chip busy with a chain of dependent round trips, or in k_flatten_light's.
-// EXPERIMENT (round 5, session 26; `mode` from VELLO_HIP_PREZERO_MODE): what is left dirty in the L2s is written back when the launch
-// ends, whoever wrote it -- 0: plain stores; 1: + a release fence per workgroup (buffer_wbl2 while the scan still runs);
-// 2: agent-scope (written-through) 8-byte stores; 3: nontemporal 16-byte stores.
-__device__ __forceinline__ void prezero_workgroup(Tile *tiles, uint32_t prezero_tiles, uint32_t zb, uint32_t n_zero_blocks, uint32_t mode) {
-    const uint32_t pairs = prezero_tiles / 2u;
-    const uint32_t per = (pairs + n_zero_blocks - 1u) / n_zero_blocks;
-    const uint32_t lo = minu(zb * per, pairs), hi = minu(lo + per, pairs);
-    uint4 *t128 = reinterpret_cast<uint4 *>(tiles);
-#ifndef VELLO_SIMT_EMU
-    if (mode == 2u) {
-        unsigned long long *t64 = reinterpret_cast<unsigned long long *>(tiles);
-        for (uint32_t i = 2u * lo + threadIdx.x; i < 2u * hi; i += 256u) __hip_atomic_store(&t64[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    if (mode == 3u) {
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 *v128 = reinterpret_cast<u32x4 *>(tiles);
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) __builtin_nontemporal_store(z, &v128[i]);
-        return;
-    }
-#endif
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256u) t128[i] = make_uint4(0u, 0u, 0u, 0u);
-#ifndef VELLO_SIMT_EMU
-    if (mode == 1u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
-}
-inline uint32_t prezero_grid(uint32_t prezero_tiles) {  // a piece of 64 KB or more per workgroup, 1 024 workgroups at most
-    const uint32_t g = (prezero_tiles + 8191u) / 8192u;
-    return g > 1024u ? 1024u : g;
-}
-
 // One partition of the scan (the partition is handed out by ticket; `block` of `n_blocks` only strides bbox_clear).  A workgroup of
 // k_pathtag_scan, or one turn of a workgroup of k_front (flatten.hip: the stages up to tile_alloc as one launch for small scenes).
 __device__ __forceinline__ void pathtag_scan_workgroup(const Config &cfg, uint32_t block, uint32_t n_blocks, uint32_t n_tag_words, uint32_t n_scene_words,

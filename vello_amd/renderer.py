@@ -209,21 +209,20 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_slices=False, flatten_coop=False, flatten_alone=False, no_fusion=False, no_prezero=False):
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_slices=False, flatten_coop=False, flatten_alone=False, no_fusion=False):
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
         runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
         stack machine instead of the partitioned kernels; fine_slices cuts every tile's command list into slices of
         4 fills for fine's MSAA modes (normally only lists of >= 96 fills are cut, engine.h FINE_SLICE_MIN_FILLS); flatten_coop /
         flatten_alone pick the kernels of flatten's heavy list (the wave-cooperative walk / every lane on its own) instead of leaving
         the choice to the engine; no_fusion launches every stage of a small scene as a kernel of its own (normally consecutive stages
-        up to tile_alloc share launches there); no_prezero makes tile_alloc zero every tile itself (normally the tiles a finished
-        frame of the scene took are zeroed beside flatten's first launch).  Flags not named are cleared (update_debug_flags keeps them)."""
+        up to tile_alloc share launches there).  Flags not named are cleared (update_debug_flags keeps them)."""
         self._debug = {"no_cull": bool(no_cull), "stroke_kernel": bool(stroke_kernel), "seq_clip": bool(seq_clip),
                        "fine_slices": bool(fine_slices), "flatten_coop": bool(flatten_coop), "flatten_alone": bool(flatten_alone),
-                       "no_fusion": bool(no_fusion), "no_prezero": bool(no_prezero)}
+                       "no_fusion": bool(no_fusion)}
         d = self._debug
         flags = ((1 if d["no_cull"] else 0) | (2 if d["stroke_kernel"] else 0) | (4 if d["seq_clip"] else 0) | (8 if d["fine_slices"] else 0) |
-                 (16 if d["flatten_coop"] else 0) | (32 if d["flatten_alone"] else 0) | (64 if d["no_fusion"] else 0) | (128 if d["no_prezero"] else 0))
+                 (16 if d["flatten_coop"] else 0) | (32 if d["flatten_alone"] else 0) | (64 if d["no_fusion"] else 0))
         self._check(self._lib.vello_hip_set_debug_flags(self._h, flags), "set_debug_flags")
 
     def update_debug_flags(self, **changes):
@@ -234,10 +233,6 @@ class Engine:
 
     def last_render_attempts(self):
         return int(self._lib.vello_hip_last_render_attempts(self._h))
-
-    def last_prezero_tiles(self):
-        """vello_hip_last_prezero_tiles: tiles the latest frame had zeroed beside flatten's first launch instead of by tile_alloc."""
-        return int(self._lib.vello_hip_last_prezero_tiles(self._h))
 
     def fused_launches(self):
         """vello_hip_fused_launches: launches in which stages of a small scene shared a kernel, since the engine was created."""
