@@ -49,6 +49,10 @@ constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
 constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u - 1u;  // a tile's fixed block minus the blend word, the tail and the work word
 constexpr uint32_t REGION_SLACK = 62u;  // words a new region holds beyond the batch that asked for it
+#ifndef VK_COARSE_SPLIT_MIN
+#define VK_COARSE_SPLIT_MIN 1536u
+#endif
+constexpr uint32_t COARSE_SPLIT_MIN = VK_COARSE_SPLIT_MIN;  // a bin's list is split over two workgroups per quadrant from 3 stream rounds on (if long against the average)
 // what a draw object emits per tile: a path command (CMD_FILL 4 words / CMD_SOLID 1) + a draw command of 2 or 3 words,
 // or CMD_BEGIN_CLIP alone (coarse.wgsl:377-450)
 constexpr uint32_t KIND_NONE = 0u, KIND_PATH2 = 1u, KIND_PATH3 = 2u, KIND_BEGIN = 3u;
@@ -199,7 +203,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
                                                 const uint32_t *__restrict__ tile_bits, Tile *tiles, Bump *bump,
                                                 uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order,
                                                 SliceItem *slice_items, uint32_t *slice_counters, uint32_t slice_cap, uint32_t cov_cap,
-                                                uint32_t slice_fills, uint32_t slice_min_fills) {
+                                                uint32_t slice_fills, uint32_t slice_min_fills, bool split_all) {
 #ifdef VELLO_SIMT_EMU
     __shared__ CoarseLds sh;
 #else
@@ -220,10 +224,12 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     const uint32_t width_in_bins = (cfg.width_in_tiles + N_TILE_X - 1u) / N_TILE_X;
     const uint32_t height_in_bins = (cfg.height_in_tiles + N_TILE_Y - 1u) / N_TILE_Y;
     const uint32_t n_bins = width_in_bins * height_in_bins;
-    // workgroup -> (bin, quadrant): consecutive workgroup ids go to different XCDs (id mod 8), so the four quadrants
-    // of a bin, which read the same bin lists and records, get ids that are equal mod 8 and share one L2
-    const uint32_t bin_ix = ((blockIdx.x >> 3) >> 2) * 8u + (blockIdx.x & 7u);
-    const uint32_t quad = (blockIdx.x >> 3) & 3u;
+    // workgroup -> (bin, quadrant, half): consecutive workgroup ids go to different XCDs (id mod 8), so the eight workgroups
+    // of a bin, which read the same bin lists and records, get ids that are equal mod 8 and share one L2.  A quadrant is ONE
+    // workgroup's (half 0) unless the bin's list is long against the frame's average (below): then half h takes tile rows
+    // [4h, 4h + 4) of it.
+    const uint32_t bin_ix = (blockIdx.x >> 6) * 8u + (blockIdx.x & 7u);
+    const uint32_t quad = (blockIdx.x >> 4) & 3u, half = (blockIdx.x >> 3) & 1u;
     if (bin_ix >= n_bins) return;
     const uint32_t aligned_n_bins = (n_bins + N_TILE - 1u) & ~(N_TILE - 1u);
     const uint32_t n_partitions = (cfg.layout.n_draw_objects + N_TILE - 1u) / N_TILE;
@@ -321,8 +327,28 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
         }
         return e;
     };
+    // LONG LISTS ARE SPLIT.  The launch is as long as its slowest workgroup -- the quadrants of the densest bins (the road map: 165 000
+    // cycles against a mean of 103 000, on 196 of 256 CUs) -- so a bin whose list is long against the frame's average gives each of
+    // its quadrants to TWO workgroups, the upper and the lower four tile rows: both stream the whole list, each keeps, transposes and
+    // emits only what touches its rows.  The eight workgroups of a bin see the same headers and the same bump.binning: one decision.
+    uint32_t bin_total = 0u;
+    if (n_partitions > PART_CHUNK) {  // (beyond 65 536 draw objects the first merged chunk is not the whole list: a pass of its own)
+        uint32_t mine = 0u;
+        for (uint32_t p = tid; p < n_partitions; p += WG) mine += bin_headers[(size_t)p * aligned_n_bins + bin_ix].element_count;
+        mine = wave_incl_scan_u32(mine, (int)lane);
+        if (lane == 63u) sh.wave_cnt[wave] = mine;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t w = 0; w < NW; w++) bin_total += sh.wave_cnt[w];
+        __syncthreads();
+    }
     uint32_t d_next;
     bool cur_valid = fetch_index(d_next);  // round 0
+    if (n_partitions <= PART_CHUNK) bin_total = chunk_total;
+    const uint32_t list_mean = minu(bump->binning, cfg.binning_size) / n_bins;
+    const bool split = split_all || bin_total >= maxu(COARSE_SPLIT_MIN, list_mean + list_mean / 4u);  // (split_all: VELLO_HIP_DEBUG_COARSE_SPLIT)
+    if (half != 0u && !split) return;
+    const int32_t row_lo = split ? (int32_t)(4u * half) : 0, row_hi = split ? row_lo + 4 : (int32_t)SUB_W;
     CoarseEl el_next = load_el(d_next);
     bool next_valid = cur_valid ? fetch_index(d_next) : false;  // entries of round 1
     bool more = cur_valid;
@@ -343,8 +369,8 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             const int32_t bx0 = (int32_t)(el.bbox_x & 0xffffu), bx1 = (int32_t)(el.bbox_x >> 16);
             const int32_t by0 = (int32_t)(el.bbox_y & 0xffffu), by1 = (int32_t)(el.bbox_y >> 16);
             const int32_t dx = bx0 - (int32_t)sub_x0, dy = by0 - (int32_t)sub_y0;
-            const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, 0, (int32_t)SUB_W);
-            const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, 0, (int32_t)SUB_W);
+            const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, row_lo, row_hi);
+            const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, row_lo, row_hi);
             const bool meets = el.tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
             const uint32_t stride = (uint32_t)(bx1 - bx0);
             const uint32_t base = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
@@ -726,7 +752,8 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
         }
     }
     if (wave == 0u) {
-        const bool in_target = sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles;
+        const bool in_target = sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles &&
+                               (int32_t)(lane / SUB_W) >= row_lo && (int32_t)(lane / SUB_W) < row_hi;  // (a split quadrant: this half's rows)
         if (in_target) {
             if (!dead) ptcl[cur] = CMD_END;
             uint32_t blend_ix = 0u;
@@ -816,10 +843,10 @@ void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
                        f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits);
     if (mid) (void)hipEventRecord(mid[0], s);
-    const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
+    const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 8u;  // (bin, quadrant, half)
     hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,
-                       f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills);
+                       f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills, f.coarse_split_all);
 }
 
 }  // namespace vk

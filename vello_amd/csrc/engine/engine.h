@@ -172,6 +172,7 @@ struct Frame {
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that stroke workgroups would exit at once
     bool flatten_coop;          // flatten's heavy list by the kernels of the wave-cooperative walk (flatten_walk.inc) instead of round 4's
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
+    bool coarse_split_all;  // VELLO_HIP_DEBUG_COARSE_SPLIT: every quadrant of every bin as two workgroups (coarse.hip: normally only long lists)
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;

@@ -456,6 +456,7 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.n_ramps = sc.n_ramps;
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
+    f.coarse_split_all = (c->debug_flags & VELLO_HIP_DEBUG_COARSE_SPLIT) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
     f.path_count_small = sc.soup_lines >= 0 && sc.soup_lines < PATH_COUNT_SMALL_MAX_LINES;
