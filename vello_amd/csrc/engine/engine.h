@@ -153,6 +153,7 @@ struct Frame {
     uint32_t *blend_spill;
     CoarseEl *coarse_el;     // coarse: one record per draw object (k_coarse_prep)
     uint32_t *tile_bits;     // coarse: three bits per tile of the pool (segments present / backdrop zero / backdrop even), a word per 8 tiles
+    uint32_t *coarse_split;  // coarse: [0, n_bins) bin is split; [n_bins] number of split bins; then their indices (coarse.hip COARSE_SPLIT_*)
     uint32_t *tile_order;    // coarse -> fine: [bucket][n_tiles] tile indices, filled up to control->work_count[bucket]
     SliceItem *slice_items;  // coarse -> fine: the slices of the long tiles (MSAA modes), slice_cap entries
     uint32_t *slice_counters;  // per first item: slices of the tile that have finished
