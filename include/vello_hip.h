@@ -224,13 +224,9 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * the list, and by the scene's size before there is one): same line soup as a multiset -- so that tests can hold both sets of
  * kernels to the oracle on the same scenes.
  * VELLO_HIP_DEBUG_NO_FUSION launches every stage of a small scene as a kernel of its own (normally the workgroups of consecutive
- * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers.
- * VELLO_HIP_DEBUG_COARSE_SPLIT gives every 8 x 8-tile quadrant of every bin to two workgroups of coarse, four tile rows each
- * (normally only the quadrants of a bin whose list is long against the frame's average, from 1 536 entries on): same command
- * lists -- so that small test scenes exercise the split. */
+ * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers. */
 enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8,
-       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64,
-       VELLO_HIP_DEBUG_COARSE_SPLIT = 128 };
+       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -78,7 +78,6 @@ pub const VELLO_HIP_DEBUG_FINE_SLICES: u32 = 8;
 pub const VELLO_HIP_DEBUG_FLATTEN_COOP: u32 = 16;
 pub const VELLO_HIP_DEBUG_FLATTEN_ALONE: u32 = 32;
 pub const VELLO_HIP_DEBUG_NO_FUSION: u32 = 64;
-pub const VELLO_HIP_DEBUG_COARSE_SPLIT: u32 = 128;
 pub const VELLO_HIP_STAGE_COUNT: usize = 11;
 
 unsafe extern "C" {

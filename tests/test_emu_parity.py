@@ -1042,18 +1042,6 @@ def test_emu_fine_slices(emu_engine, name, body):
         emu_engine.set_debug_flags()
 
 
-@pytest.mark.parametrize("name,body", _pipeline_cases(), ids=[c[0] for c in _pipeline_cases()])
-def test_emu_coarse_split_quadrants(emu_engine, name, body):
-    # coarse's split (VELLO_HIP_DEBUG_COARSE_SPLIT: every 8 x 8-tile quadrant as two workgroups of four tile rows; normally only the
-    # quadrants of bins with long lists) through the same oracle comparisons: PTCL word for word, segment slices, the clip machine,
-    # occlusion culling, fine's work buckets and slices
-    emu_engine.set_debug_flags(coarse_split=True)
-    try:
-        body(emu_engine)
-    finally:
-        emu_engine.set_debug_flags()
-
-
 def test_emu_fine_slices_survive_split_stage_ranges(emu_engine):
     # vello_hip_run_stages seam: COARSE in one call, FINE in a later one.  Coarse cuts tiles into slices according to the
     # number of slice blocks fine is going to launch; between the two calls the engine learns the scene's demand (sync reads

@@ -891,18 +891,6 @@ def _slice_cases():
 
 
 @pytest.mark.parametrize("name,body", _slice_cases(), ids=[c[0] for c in _slice_cases()])
-def test_coarse_split_quadrants_forced(gpu_engine, name, body):
-    # coarse with EVERY quadrant as two workgroups of four tile rows (VELLO_HIP_DEBUG_COARSE_SPLIT; normally only the quadrants of
-    # bins whose lists are long against the frame's average -- the road map's dense bins, test_config_c3_d2_scene_full_size):
-    # PTCL word for word, segment slices, bump counters, images through the same comparisons as the unsplit launch
-    gpu_engine.set_debug_flags(coarse_split=True)
-    try:
-        body(gpu_engine)
-    finally:
-        gpu_engine.set_debug_flags()
-
-
-@pytest.mark.parametrize("name,body", _slice_cases(), ids=[c[0] for c in _slice_cases()])
 def test_fine_slices_forced(gpu_engine, name, body):
     # fine's sliced path on the MI355X with EVERY tile cut into slices of 4 fills (VELLO_HIP_DEBUG_FINE_SLICES): the slices of a
     # tile run on whatever CUs / XCDs the dispatcher picks, the last one to finish composites from the coverage scratch --

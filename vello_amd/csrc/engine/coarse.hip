@@ -49,21 +49,6 @@ constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
 constexpr uint32_t INITIAL_ROOM = PTCL_INITIAL_ALLOC - 1u - 2u - 1u;  // a tile's fixed block minus the blend word, the tail and the work word
 constexpr uint32_t REGION_SLACK = 62u;  // words a new region holds beyond the batch that asked for it
-// LONG LISTS ARE SPLIT.  k_coarse is as long as its slowest workgroup -- the quadrants of the densest bins (the road map: 165 000 cycles
-// against a mean of 103 000, on 196 of 256 CUs) -- so the bins with the longest lists give each of their quadrants to TWO workgroups,
-// the upper and the lower four tile rows: both stream the whole list, each keeps, transposes and emits only what touches its rows.
-// Which bins: k_coarse_prep's last block ranks the bins by the length of their lists; the COARSE_SPLIT_BINS longest are split if they
-// hold at least COARSE_SPLIT_MIN entries (three stream rounds) and a quarter more than the average bin.  Their lower halves are the work
-// of 4 x COARSE_SPLIT_BINS HELPER workgroups behind the launch's others (the ones without a bin leave after one load): the launch grows
-// by the CUs it left idle, not by a workgroup per quadrant (a grid of twice the workgroups, half of which only find out that they are
-// not wanted, cost the road map 22 us and every other scene 10-17: profiles/r05_ab_coarse_split.txt).
-#ifndef VK_COARSE_SPLIT_MIN
-#define VK_COARSE_SPLIT_MIN 1536u
-#endif
-constexpr uint32_t COARSE_SPLIT_MIN = VK_COARSE_SPLIT_MIN;
-constexpr uint32_t COARSE_SPLIT_BINS = 16u;        // bins split at most (VELLO_HIP_DEBUG_COARSE_SPLIT: all of them)
-constexpr uint32_t COARSE_SPLIT_RANK_MAX = 1024u;  // the ranking is one block's work, quadratic in the bins: targets of more bins are not split
-// coarse_split[]: [0, n_bins) 1 if the bin is split; [n_bins] the number of split bins; [n_bins + 1 ...) their indices
 // what a draw object emits per tile: a path command (CMD_FILL 4 words / CMD_SOLID 1) + a draw command of 2 or 3 words,
 // or CMD_BEGIN_CLIP alone (coarse.wgsl:377-450)
 constexpr uint32_t KIND_NONE = 0u, KIND_PATH2 = 1u, KIND_PATH3 = 2u, KIND_BEGIN = 3u;
@@ -164,50 +149,8 @@ __device__ __forceinline__ uint32_t window_bits(PtclWords2 w, uint32_t byte_shif
 __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_blocks, const uint32_t *__restrict__ scene,
                                                      const DrawMonoid *__restrict__ draw_monoids, const uint32_t *__restrict__ info_bin_data,
                                                      const Path *__restrict__ paths, const Tile *__restrict__ tiles, const Bump *__restrict__ bump,
-                                                     CoarseEl *__restrict__ coarse_el, uint32_t *__restrict__ tile_bits,
-                                                     const BinHeader *__restrict__ bin_headers, uint32_t *__restrict__ coarse_split, bool split_all) {
+                                                     CoarseEl *__restrict__ coarse_el, uint32_t *__restrict__ tile_bits) {
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x == gridDim.x - 1u) {
-        // Job (c), the last block: which bins' quadrants get two workgroups (COARSE_SPLIT_* above)
-        __shared__ uint32_t sh_total[COARSE_SPLIT_RANK_MAX];
-        __shared__ uint32_t sh_n;
-        const uint32_t n_bins = ((cfg.width_in_tiles + N_TILE_X - 1u) / N_TILE_X) * ((cfg.height_in_tiles + N_TILE_Y - 1u) / N_TILE_Y);
-        const uint32_t aligned_n_bins = (n_bins + N_TILE - 1u) & ~(N_TILE - 1u);
-        const uint32_t n_partitions = (cfg.layout.n_draw_objects + N_TILE - 1u) / N_TILE;
-        if (tid == 0u) sh_n = 0u;
-        if (split_all) {
-            for (uint32_t b = tid; b < n_bins; b += 256u) {
-                coarse_split[b] = 1u;
-                coarse_split[n_bins + 1u + b] = b;
-            }
-            if (tid == 0u) coarse_split[n_bins] = n_bins;
-            return;
-        }
-        const bool rank_them = n_bins <= COARSE_SPLIT_RANK_MAX && (bump->failed & (STAGE_BINNING | STAGE_FLATTEN | FAILED_SCENE)) == 0u;
-        if (rank_them) {
-            for (uint32_t b = tid; b < n_bins; b += 256u) {
-                uint32_t total = 0u;
-                for (uint32_t p = 0; p < n_partitions; p++) total += bin_headers[(size_t)p * aligned_n_bins + b].element_count;
-                sh_total[b] = total;
-            }
-        }
-        __syncthreads();
-        const uint32_t mean = minu(bump->binning, cfg.binning_size) / maxu(n_bins, 1u);
-        const uint32_t least = maxu(COARSE_SPLIT_MIN, mean + mean / 4u);
-        for (uint32_t b = tid; b < n_bins; b += 256u) {
-            bool split = false;
-            if (rank_them && sh_total[b] >= least) {
-                uint32_t longer = 0u;  // bins with a longer list (ties: the lower index first)
-                for (uint32_t o = 0; o < n_bins; o++) longer += (sh_total[o] > sh_total[b] || (sh_total[o] == sh_total[b] && o < b)) ? 1u : 0u;
-                split = longer < COARSE_SPLIT_BINS;
-            }
-            coarse_split[b] = split ? 1u : 0u;
-            if (split) coarse_split[n_bins + 1u + atomicAdd(&sh_n, 1u)] = b;
-        }
-        __syncthreads();
-        if (tid == 0u) coarse_split[n_bins] = sh_n;
-        return;
-    }
     if (blockIdx.x < n_el_blocks) {
         const uint32_t drawobj_ix = blockIdx.x * 256u + tid;
         if (drawobj_ix >= cfg.layout.n_draw_objects) return;
@@ -233,7 +176,7 @@ __global__ void __launch_bounds__(256) k_coarse_prep(Config cfg, uint32_t n_el_b
     const uint32_t n_tiles = minu(bump->tile, cfg.tiles_size);
     const uint32_t lane = tid & 63u;
     const uint32_t wave = (blockIdx.x - n_el_blocks) * 4u + (tid >> 6);
-    const uint32_t n_waves = (gridDim.x - 1u - n_el_blocks) * 4u;
+    const uint32_t n_waves = (gridDim.x - n_el_blocks) * 4u;
     for (uint32_t chunk = wave; chunk * 64u < n_tiles; chunk += n_waves) {
         const uint32_t i = chunk * 64u + lane;
         Tile t{1, 0u};
@@ -256,7 +199,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
                                                 const uint32_t *__restrict__ tile_bits, Tile *tiles, Bump *bump,
                                                 uint32_t *ptcl, bool allow_cull, uint32_t *work_count, uint32_t *tile_order,
                                                 SliceItem *slice_items, uint32_t *slice_counters, uint32_t slice_cap, uint32_t cov_cap,
-                                                uint32_t slice_fills, uint32_t slice_min_fills, const uint32_t *__restrict__ coarse_split) {
+                                                uint32_t slice_fills, uint32_t slice_min_fills) {
 #ifdef VELLO_SIMT_EMU
     __shared__ CoarseLds sh;
 #else
@@ -278,18 +221,9 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     const uint32_t height_in_bins = (cfg.height_in_tiles + N_TILE_Y - 1u) / N_TILE_Y;
     const uint32_t n_bins = width_in_bins * height_in_bins;
     // workgroup -> (bin, quadrant): consecutive workgroup ids go to different XCDs (id mod 8), so the four quadrants
-    // of a bin, which read the same bin lists and records, get ids that are equal mod 8 and share one L2.  Behind them the helper
-    // workgroups: helper j takes the lower four tile rows of quadrant j mod 4 of the j / 4-th split bin (COARSE_SPLIT_* above).
-    const uint32_t n_main = ((n_bins + 7u) / 8u) * 8u * 4u;
-    const bool helper = blockIdx.x >= n_main;
-    uint32_t bin_ix = ((blockIdx.x >> 3) >> 2) * 8u + (blockIdx.x & 7u);
-    uint32_t quad = (blockIdx.x >> 3) & 3u;
-    if (helper) {
-        const uint32_t j = blockIdx.x - n_main;
-        if (j / 4u >= coarse_split[n_bins]) return;
-        bin_ix = coarse_split[n_bins + 1u + j / 4u];
-        quad = j & 3u;
-    }
+    // of a bin, which read the same bin lists and records, get ids that are equal mod 8 and share one L2
+    const uint32_t bin_ix = ((blockIdx.x >> 3) >> 2) * 8u + (blockIdx.x & 7u);
+    const uint32_t quad = (blockIdx.x >> 3) & 3u;
     if (bin_ix >= n_bins) return;
     const uint32_t aligned_n_bins = (n_bins + N_TILE - 1u) & ~(N_TILE - 1u);
     const uint32_t n_partitions = (cfg.layout.n_draw_objects + N_TILE - 1u) / N_TILE;
@@ -389,9 +323,6 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
     };
     uint32_t d_next;
     bool cur_valid = fetch_index(d_next);  // round 0
-    // (a split bin: the upper four tile rows of the quadrant are this workgroup's, the lower four a helper's)
-    const bool split = helper || coarse_split[bin_ix] != 0u;
-    const int32_t row_lo = helper ? 4 : 0, row_hi = split ? row_lo + 4 : (int32_t)SUB_W;
     CoarseEl el_next = load_el(d_next);
     bool next_valid = cur_valid ? fetch_index(d_next) : false;  // entries of round 1
     bool more = cur_valid;
@@ -412,8 +343,8 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
             const int32_t bx0 = (int32_t)(el.bbox_x & 0xffffu), bx1 = (int32_t)(el.bbox_x >> 16);
             const int32_t by0 = (int32_t)(el.bbox_y & 0xffffu), by1 = (int32_t)(el.bbox_y >> 16);
             const int32_t dx = bx0 - (int32_t)sub_x0, dy = by0 - (int32_t)sub_y0;
-            const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, row_lo, row_hi);
-            const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, row_lo, row_hi);
+            const int32_t x0 = clampi(dx, 0, (int32_t)SUB_W), y0 = clampi(dy, 0, (int32_t)SUB_W);
+            const int32_t x1 = clampi(bx1 - (int32_t)sub_x0, 0, (int32_t)SUB_W), y1 = clampi(by1 - (int32_t)sub_y0, 0, (int32_t)SUB_W);
             const bool meets = el.tag != DRAWTAG_NOP && x1 > x0 && y1 > y0;
             const uint32_t stride = (uint32_t)(bx1 - bx0);
             const uint32_t base = el.tiles - (uint32_t)(dy * (int32_t)stride + dx);
@@ -795,8 +726,7 @@ __global__ void __launch_bounds__(WG) k_coarse(Config cfg, const uint32_t *__res
         }
     }
     if (wave == 0u) {
-        const bool in_target = sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles &&
-                               (int32_t)(lane / SUB_W) >= row_lo && (int32_t)(lane / SUB_W) < row_hi;  // (a split quadrant: this half's rows)
+        const bool in_target = sub_x0 + lane % SUB_W < cfg.width_in_tiles && sub_y0 + lane / SUB_W < cfg.height_in_tiles;
         if (in_target) {
             if (!dead) ptcl[cur] = CMD_END;
             uint32_t blend_ix = 0u;
@@ -883,15 +813,13 @@ void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid) {
     uint32_t n_bit_blocks = (uint32_t)(((uint64_t)f.cfg.tiles_size + 256u * 8u - 1u) / (256u * 8u));
     if (n_bit_blocks > 2048u) n_bit_blocks = 2048u;
     if (n_bit_blocks < 1u) n_bit_blocks = 1u;
-    // (+ 1: the block that picks the bins whose quadrants get two workgroups)
-    hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks + 1u), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
-                       f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits, f.bin_headers, f.coarse_split, f.coarse_split_all);
+    hipLaunchKernelGGL(k_coarse_prep, dim3(n_el_blocks + n_bit_blocks), dim3(256), 0, s, f.cfg, n_el_blocks, f.scene, f.draw_monoids,
+                       f.info_bin_data, f.paths, f.tiles, f.bump(), f.coarse_el, f.tile_bits);
     if (mid) (void)hipEventRecord(mid[0], s);
-    const uint32_t n_main = ((wb * hb + 7u) / 8u) * 8u * 4u;
-    const uint32_t n_helpers = 4u * (f.coarse_split_all ? wb * hb : (wb * hb <= COARSE_SPLIT_RANK_MAX ? COARSE_SPLIT_BINS : 0u));
-    hipLaunchKernelGGL(k_coarse, dim3(n_main + n_helpers), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
+    const uint32_t n_wg = ((wb * hb + 7u) / 8u) * 8u * 4u;
+    hipLaunchKernelGGL(k_coarse, dim3(n_wg), dim3(WG), sizeof(CoarseLds), s, f.cfg, f.scene, f.bin_headers, f.info_bin_data, f.coarse_el, f.tile_bits,
                        f.tiles, f.bump(), f.ptcl, !f.no_cull, f.control->work_count, f.tile_order,
-                       f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills, f.coarse_split);
+                       f.slice_items, f.slice_counters, f.slice_cap, f.cov_cap, f.slice_fills, f.slice_min_fills);
 }
 
 }  // namespace vk

@@ -153,7 +153,6 @@ struct Frame {
     uint32_t *blend_spill;
     CoarseEl *coarse_el;     // coarse: one record per draw object (k_coarse_prep)
     uint32_t *tile_bits;     // coarse: three bits per tile of the pool (segments present / backdrop zero / backdrop even), a word per 8 tiles
-    uint32_t *coarse_split;  // coarse: [0, n_bins) bin is split; [n_bins] number of split bins; then their indices (coarse.hip COARSE_SPLIT_*)
     uint32_t *tile_order;    // coarse -> fine: [bucket][n_tiles] tile indices, filled up to control->work_count[bucket]
     SliceItem *slice_items;  // coarse -> fine: the slices of the long tiles (MSAA modes), slice_cap entries
     uint32_t *slice_counters;  // per first item: slices of the tile that have finished
@@ -173,7 +172,6 @@ struct Frame {
     bool launch_stroke_kernel;  // false when an earlier frame of the same scene showed that stroke workgroups would exit at once
     bool flatten_coop;          // flatten's heavy list by the kernels of the wave-cooperative walk (flatten_walk.inc) instead of round 4's
     bool sequential_clip;  // VELLO_HIP_DEBUG_SEQ_CLIP: the one-wave stack machine whatever the clip count
-    bool coarse_split_all;  // VELLO_HIP_DEBUG_COARSE_SPLIT: every quadrant of every bin as two workgroups (coarse.hip: normally only long lists)
     bool no_cull;  // VELLO_HIP_DEBUG_NO_CULL: coarse emits every draw, as the reference does (exact PTCL / segment diffs)
     bool brushes;  // the scene has gradient / image / blurred-rect draw objects (selects fine's specialisation)
     const uint32_t *mask_lut8;

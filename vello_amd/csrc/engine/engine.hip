@@ -65,7 +65,6 @@ struct Lane {
     DevBuf coarse_el;                 // coarse: CoarseEl per draw object
     DevBuf tile_bits;                 // coarse: 3 bits per tile of the pool, a word per 8 tiles
     DevBuf tile_order;                // coarse -> fine: tiles bucketed by command-list length
-    DevBuf coarse_split;              // coarse: which bins' quadrants get two workgroups (coarse.hip COARSE_SPLIT_*)
     DevBuf slice_items, slice_counters, cov;  // coarse -> fine: slices of long tiles, their arrival counters, coverage scratch
     DevBuf heavy_list;                // flatten: tag indices for the heavy code, 4 lists (one u32 per tag each, worst case)
     DevBuf arc_items;                 // flatten: arcs the stroke workgroups leave to the heavy code (64 B per segment, worst case)
@@ -392,10 +391,6 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_BIN_HEADERS], (size_t)(binning_wgs * aligned_n_bins + 1u) * sizeof(BinHeader)))) return r;
     if (!out_device && (r = ensure(c, l.buf[VELLO_HIP_BUF_OUTPUT], (size_t)p->width * p->height * 4u))) return r;
     if ((r = ensure(c, l.tile_order, (size_t)f.cfg.width_in_tiles * f.cfg.height_in_tiles * FINE_WORK_BUCKETS * 4u))) return r;
-    {
-        const size_t n_bins = (size_t)((f.cfg.width_in_tiles + 15u) / 16u) * ((f.cfg.height_in_tiles + 15u) / 16u);
-        if ((r = ensure(c, l.coarse_split, (2u * n_bins + 1u) * 4u))) return r;
-    }
     // fine launches one (at once exiting) workgroup per slice item it MIGHT be given in front of the tiles' workgroups:
     // as many as the scene asked for in an earlier frame (+ 1/8), a quarter of the tiles while that is unknown.  Coarse
     // cuts a tile into slices only if its items fit (the rest are rendered unsliced), so any number is correct.
@@ -437,7 +432,6 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.coarse_el = (CoarseEl *)l.coarse_el.ptr;
     f.tile_bits = (uint32_t *)l.tile_bits.ptr;
     f.tile_order = (uint32_t *)l.tile_order.ptr;
-    f.coarse_split = (uint32_t *)l.coarse_split.ptr;
     f.slice_items = (SliceItem *)l.slice_items.ptr;
     f.slice_counters = (uint32_t *)l.slice_counters.ptr;
     f.cov = (uint32_t *)l.cov.ptr;
@@ -462,7 +456,6 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     f.n_ramps = sc.n_ramps;
     f.brushes = sc.brushes || c->force_brushes;
     f.no_cull = (c->debug_flags & VELLO_HIP_DEBUG_NO_CULL) != 0u;
-    f.coarse_split_all = (c->debug_flags & VELLO_HIP_DEBUG_COARSE_SPLIT) != 0u;
     f.sequential_clip = (c->debug_flags & VELLO_HIP_DEBUG_SEQ_CLIP) != 0u;
     f.stroke_kernel_min_lines = (c->debug_flags & VELLO_HIP_DEBUG_STROKE_KERNEL) != 0u ? 0u : FLATTEN_STROKE_KERNEL_MIN_LINES;
     f.path_count_small = sc.soup_lines >= 0 && sc.soup_lines < PATH_COUNT_SMALL_MAX_LINES;
@@ -776,7 +769,6 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         if (l.coarse_el.ptr) (void)hipFree(l.coarse_el.ptr);
         if (l.tile_bits.ptr) (void)hipFree(l.tile_bits.ptr);
         if (l.tile_order.ptr) (void)hipFree(l.tile_order.ptr);
-        if (l.coarse_split.ptr) (void)hipFree(l.coarse_split.ptr);
         for (DevBuf *b : {&l.slice_items, &l.slice_counters, &l.cov})
             if (b->ptr) (void)hipFree(b->ptr);
         if (l.heavy_list.ptr) (void)hipFree(l.heavy_list.ptr);

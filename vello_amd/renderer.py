@@ -209,21 +209,20 @@ class Engine:
     def set_auto_grow(self, enabled=True):
         self._check(self._lib.vello_hip_set_auto_grow(self._h, 1 if enabled else 0), "set_auto_grow")
 
-    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_slices=False, flatten_coop=False, flatten_alone=False, no_fusion=False, coarse_split=False):
+    def set_debug_flags(self, no_cull=False, stroke_kernel=False, seq_clip=False, fine_slices=False, flatten_coop=False, flatten_alone=False, no_fusion=False):
         """vello_hip_set_debug_flags: no_cull makes coarse emit every draw (reference-exact PTCL / segments); stroke_kernel
         runs flatten's stroked-line kernel whatever the number of stroked lines; seq_clip matches clips with the one-wave
         stack machine instead of the partitioned kernels; fine_slices cuts every tile's command list into slices of
         4 fills for fine's MSAA modes (normally only lists of >= 96 fills are cut, engine.h FINE_SLICE_MIN_FILLS); flatten_coop /
         flatten_alone pick the kernels of flatten's heavy list (the wave-cooperative walk / every lane on its own) instead of leaving
         the choice to the engine; no_fusion launches every stage of a small scene as a kernel of its own (normally consecutive stages
-        up to tile_alloc share launches there); coarse_split gives every quadrant of every bin to two workgroups of coarse (normally
-        only the quadrants of bins with long lists).  Flags not named are cleared (update_debug_flags keeps them)."""
+        up to tile_alloc share launches there).  Flags not named are cleared (update_debug_flags keeps them)."""
         self._debug = {"no_cull": bool(no_cull), "stroke_kernel": bool(stroke_kernel), "seq_clip": bool(seq_clip),
                        "fine_slices": bool(fine_slices), "flatten_coop": bool(flatten_coop), "flatten_alone": bool(flatten_alone),
-                       "no_fusion": bool(no_fusion), "coarse_split": bool(coarse_split)}
+                       "no_fusion": bool(no_fusion)}
         d = self._debug
         flags = ((1 if d["no_cull"] else 0) | (2 if d["stroke_kernel"] else 0) | (4 if d["seq_clip"] else 0) | (8 if d["fine_slices"] else 0) |
-                 (16 if d["flatten_coop"] else 0) | (32 if d["flatten_alone"] else 0) | (64 if d["no_fusion"] else 0) | (128 if d["coarse_split"] else 0))
+                 (16 if d["flatten_coop"] else 0) | (32 if d["flatten_alone"] else 0) | (64 if d["no_fusion"] else 0))
         self._check(self._lib.vello_hip_set_debug_flags(self._h, flags), "set_debug_flags")
 
     def update_debug_flags(self, **changes):
