@@ -11,14 +11,7 @@ namespace vk {
 // (write-through), so it is never torn and needs no separate flag or fence
 // (cdna_hip_programming.md guideline 16, form R2).
 constexpr uint32_t SCAN_STATUS_AGG = 1, SCAN_STATUS_PREFIX = 2;
-// tag words per thread of the pathtag scan: a partition is 256 x this many words.  The scan is as long as its chain of look-backs, a hop per
-// partition (the road map: 233 partitions of 1 024 words, 16 us), so a thread takes 8 words (two 16-byte loads) and the chain is half as long
-// (profiles/r05_ab_pathtag_wpt.txt).
-#ifndef VK_PATHTAG_WPT
-#define VK_PATHTAG_WPT 8
-#endif
-constexpr uint32_t PATHTAG_WPT = VK_PATHTAG_WPT;
-constexpr uint32_t PATHTAG_PART_WORDS = 256u * PATHTAG_WPT;
+constexpr uint32_t PATHTAG_PART_WORDS = 1024;  // 256 threads x 4 tag words (= 4096 tags)
 constexpr uint32_t DRAW_PART = 256;            // draw objects per partition
 #ifndef VK_FLATTEN_TPT
 #define VK_FLATTEN_TPT 4

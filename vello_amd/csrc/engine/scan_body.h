@@ -43,19 +43,18 @@ __device__ __forceinline__ void pathtag_scan_workgroup(const Config &cfg, uint32
     if (tid == 0) sh_part = atomicAdd(&control->ticket_pathtag, 1u);
     __syncthreads();
     const uint32_t part = sh_part;
-    constexpr int WPT = (int)PATHTAG_WPT;
-    const uint32_t word0 = part * PATHTAG_PART_WORDS + (uint32_t)tid * PATHTAG_WPT;
+    const uint32_t word0 = part * PATHTAG_PART_WORDS + (uint32_t)tid * 4u;
     const uint32_t *tags = scene + cfg.layout.path_tag_base;
 
-    uint32_t tw[WPT];
+    uint32_t tw[4];
 #pragma unroll
-    for (int k = 0; k < WPT; k++) tw[k] = (word0 + k < n_tag_words) ? tags[word0 + k] : 0u;
+    for (int k = 0; k < 4; k++) tw[k] = (word0 + k < n_tag_words) ? tags[word0 + k] : 0u;
 
     // thread-local exclusive prefixes
-    uint32_t ex[WPT][5];
+    uint32_t ex[4][5];
     uint32_t acc[5] = {0u, 0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < WPT; k++) {
+    for (int k = 0; k < 4; k++) {
         TagMonoid m = reduce_tag(tw[k]);
         ex[k][0] = acc[0]; ex[k][1] = acc[1]; ex[k][2] = acc[2]; ex[k][3] = acc[3]; ex[k][4] = acc[4];
         acc[0] += m.trans_ix; acc[1] += m.pathseg_ix; acc[2] += m.pathseg_offset; acc[3] += m.style_ix; acc[4] += m.path_ix;
@@ -102,7 +101,7 @@ __device__ __forceinline__ void pathtag_scan_workgroup(const Config &cfg, uint32
 #pragma unroll
     for (int f = 0; f < 5; f++) base[f] = sh_excl[f] + wave_excl[f] + (inc[f] - acc[f]);
 #pragma unroll
-    for (int k = 0; k < WPT; k++) {
+    for (int k = 0; k < 4; k++) {
         if (word0 + k < n_tag_words) {
             TagMonoid o;
             o.trans_ix = base[0] + ex[k][0];
