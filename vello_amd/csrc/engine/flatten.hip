@@ -318,20 +318,6 @@ __device__ __forceinline__ TagMonoid reduce_tag_f(uint32_t tag_word) {
 }
 
 // flatten.wgsl:684-701
-// (the two loads of compute_tag_monoid apart from its arithmetic: the stroke workgroups request a round's tag words and monoids while the
-// round before it is still being flattened)
-__device__ __forceinline__ PathTagData tag_monoid_of(uint32_t tag_word, const TagMonoid &pre, uint32_t ix) {
-    uint32_t shift = (ix & 3u) * 8u;
-    TagMonoid tm = reduce_tag_f(tag_word & ((1u << shift) - 1u));
-    PathTagData r;
-    r.tag_byte = (tag_word >> shift) & 0xffu;
-    r.monoid.trans_ix = pre.trans_ix + tm.trans_ix - 1u;
-    r.monoid.pathseg_ix = pre.pathseg_ix + tm.pathseg_ix;
-    r.monoid.pathseg_offset = pre.pathseg_offset + tm.pathseg_offset;
-    r.monoid.style_ix = pre.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS;
-    r.monoid.path_ix = pre.path_ix + tm.path_ix;
-    return r;
-}
 __device__ PathTagData compute_tag_monoid(const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix) {
     uint32_t tag_word = scene[cfg.layout.path_tag_base + (ix >> 2)];
     uint32_t shift = (ix & 3u) * 8u;
@@ -1199,11 +1185,10 @@ __device__ __forceinline__ bool stroke_arc_one_line(Emitter &em, uint32_t path_i
 
 // One stroked LINETO (flatten_tag's stroke branch with flatten_euler reduced to its straight-segment shortcut).  Returns
 // false when the segment is not straight (the heavy kernel takes it).  Arcs that need the exact path are pushed to `q`.
-// tag_word / pre: the tag word ix >> 2 and its monoid, loaded by the caller (a round ahead).
 __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
-                                     uint32_t ix, uint32_t tag_word, const TagMonoid &pre, uint32_t &path_ix_out) {
+                                     uint32_t ix, uint32_t &path_ix_out) {
     using namespace inl;  // (tangents, joins and caps without arcs: no transcendentals either way)
-    PathTagData tag = tag_monoid_of(tag_word, pre, ix);
+    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
     const uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
@@ -1218,8 +1203,8 @@ __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg
                                 length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
     // (false for a degenerate segment too: its chord is shorter than the test's lower bound)
     if (!cubic_is_straight(pts.p0, pts.p1, pts.p2, pts.p3, scale, offset)) return false;
-    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822 (three times out of four in the word at hand)
-    PathTagData ntag = ((ix + 1u) >> 2) == (ix >> 2) ? tag_monoid_of(tag_word, pre, ix + 1u) : compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
+    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
+    PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
     CubicPoints npts = read_path_segment(pd, ntag, true);
     bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
     bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
@@ -1318,22 +1303,8 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
     __syncthreads();
     Bump *bump = &control->bump;
     const uint32_t lane = tid & 63u;
-    // A round is a chain of dependent loads -- list entry, tag word + monoid, points / style / transform, the neighbour's -- and a
-    // workgroup walks 5 of them on a road map: the list entries are requested TWO rounds ahead, the tag words and monoids ONE, from
-    // clamped addresses (a load under a branch would wait for everything in flight: DESIGN.md 3.1), so a round starts with its data's
-    // addresses in registers.
-    const uint32_t stride = n_blocks * 256u, last = n_lines_q - 1u;
-    const uint32_t *const list = heavy_list + 2u * (size_t)n_tags;
-    uint32_t tag_ix_cur = list[minu(block * 256u + tid, last)];
-    uint32_t tag_ix_next = list[minu(block * 256u + tid + stride, last)];
-    uint32_t word_cur = scene[cfg.layout.path_tag_base + (tag_ix_cur >> 2)];
-    TagMonoid pre_cur = tag_monoids[tag_ix_cur >> 2];
 #pragma unroll 1
-    for (uint32_t base = block * 256u; base < n_lines_q; base += stride) {
-        // (what the rounds after this one will want; beyond the list: its last entry again)
-        const uint32_t tag_ix_after = list[minu(base + tid + 2u * stride, last)];
-        const uint32_t word_next = scene[cfg.layout.path_tag_base + (tag_ix_next >> 2)];
-        const TagMonoid pre_next = tag_monoids[tag_ix_next >> 2];
+    for (uint32_t base = block * 256u; base < n_lines_q; base += n_blocks * 256u) {
         Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
@@ -1343,9 +1314,10 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
         const uint32_t e = base + tid;
         bool hand_on = false;
-        const uint32_t tag_ix = tag_ix_cur;
+        uint32_t tag_ix = 0u;
         if (e < n_lines_q) {
-            hand_on = !flatten_stroked_line(em, arcs, cfg, scene, tag_monoids, tag_ix, word_cur, pre_cur, key);
+            tag_ix = heavy_list[2u * n_tags + e];
+            hand_on = !flatten_stroked_line(em, arcs, cfg, scene, tag_monoids, tag_ix, key);
             if (hand_on) key = 0xffffffffu;
             else if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
@@ -1386,10 +1358,6 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
             }
             __syncthreads();  // (the next round appends to both)
         }
-        tag_ix_cur = tag_ix_next;
-        tag_ix_next = tag_ix_after;
-        word_cur = word_next;
-        pre_cur = pre_next;
     }
 }
 
