@@ -282,6 +282,23 @@ def test_emu_reference_catalogue_second_batch(emu_engine, which):
                       resolved=r)
 
 
+def test_emu_reference_catalogue_third_batch(emu_engine):
+    # test_scenes.rs:2291-2349 (an IMAGE under a luminance-mask layer; the JPEG asset replaced by a synthetic image of the same role,
+    # the whole scene at a quarter of its size for the emulator) and :1693-1706 (a translucent square over the base colour, which the
+    # reference animates through the hues: four base colours, one of them translucent)
+    import vello_amd
+
+    scene, w, h = workloads.image_luminance_mask_scene(scale=4)
+    r = vello_amd.Resolver().resolve(scene)
+    for aa in (AaConfig.Area, AaConfig.Msaa16):
+        compare_frame(emu_engine, r.packed, r.layout, w, h, WHITE, aa, f"emu_image_luminance_mask_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                      resolved=r)
+    scene, w, h = workloads.base_color_test_scene()
+    r = vello_amd.Resolver().resolve(scene)
+    for base in (0xFF3C8CE6, 0xFF20C040, 0xFFFFFFFF, 0x80402010):
+        compare_frame(emu_engine, r.packed, r.layout, 160, 160, base, AaConfig.Msaa8, f"emu_base_color_{base:08x}", resolved=r)
+
+
 def test_emu_image_atlas_residency_sequence(emu_engine):
     # resolve.rs:507-541 / image_cache.rs end to end: a 32-texel atlas that has to evict, repack and grow while frames keep
     # sampling it; after every resolve the frame must equal the oracle's rendering of the same atlas state

@@ -434,6 +434,24 @@ def test_reference_catalogue_second_batch(gpu_engine, which, aa):
                   resolved=r)
 
 
+def test_reference_catalogue_third_batch(gpu_engine):
+    # test_scenes.rs:2291-2349 at full size (a 640 x 480 image under a luminance-mask layer; the JPEG asset replaced by a synthetic image
+    # of the same role) and :1693-1706 (a translucent square over the base colour, which the reference animates through the hues)
+    import vello_amd
+
+    scene, w, h = workloads.image_luminance_mask_scene()
+    r = vello_amd.Resolver().resolve(scene)
+    for aa in (AaConfig.Area, AaConfig.Msaa16):
+        compare_frame(gpu_engine, r.packed, r.layout, w, h, WHITE, aa, f"gpu_image_luminance_mask_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                      resolved=r)
+    scene, w, h = workloads.base_color_test_scene()
+    r = vello_amd.Resolver().resolve(scene)
+    for base in (0xFF3C8CE6, 0xFF20C040, 0xFFFFFFFF, 0x80402010):
+        for aa in (AaConfig.Area, AaConfig.Msaa16):
+            compare_frame(gpu_engine, r.packed, r.layout, w, h, base, aa, f"gpu_base_color_{base:08x}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0,
+                          resolved=r)
+
+
 def test_image_atlas_residency_sequence(gpu_engine):
     # resolve.rs:507-541 / image_cache.rs end to end: a 32-texel atlas that has to evict, repack and grow while frames keep
     # sampling it; after every resolve the frame must equal the oracle's rendering of the same atlas state

@@ -14,5 +14,5 @@ from .ref_scenes import (tricky_strokes_scene, fill_types_scene, robust_paths_sc
                          deep_blend_scene, many_clips_scene, blurred_rounded_rect_scene, image_sampling_scene,
                          image_sampling_bicubic_scene, funky_paths_scene, cardioid_scene, many_draw_objects_scene,
                          ref_stroke_styles_scene, two_point_radial_scene, conflation_artifacts_scene, labyrinth_scene,
-                         clip_test_scene, luminance_mask_scene, image_extend_modes_scene, brush_transform_scene,
+                         clip_test_scene, luminance_mask_scene, image_luminance_mask_scene, base_color_test_scene, image_extend_modes_scene, brush_transform_scene,
                          clip_blends_scene, regression_stroke_scenes)

@@ -557,6 +557,42 @@ def luminance_mask_scene():
     return s, 55, 55
 
 
+def image_luminance_mask_scene(scale=1):
+    """test_scenes.rs:2291-2349: a 640 x 480 image under a luminance-mask layer, over beige and aquamarine rectangles, inside a
+    src-over layer; 700 x 500.  The reference's image is a JPEG asset (assets/splash-flower.jpg: no decoder here, and what the scene
+    tests is the mask, not the flower): a SYNTHETIC opaque image of the same size stands in -- a radial luminance ramp crossed by
+    hue stripes, so that the mask takes every value.  scale > 1 shrinks image, geometry and target alike (the emulator's cases)."""
+    from vello_amd import BlendMode, Compose, ImageData, Mix
+    iw, ih = 640 // scale, 480 // scale
+    yy, xx = np.mgrid[0:ih, 0:iw].astype(np.float64)
+    r = np.hypot((xx - iw / 2.0) / (iw / 2.0), (yy - ih / 2.0) / (ih / 2.0))
+    lum = np.clip(1.0 - r, 0.0, 1.0)
+    stripe = ((xx + 2.0 * yy) // max(1, 40 // scale)).astype(np.int64) % 3
+    px = np.zeros((ih, iw, 4), dtype=np.uint8)
+    for c in range(3):
+        px[..., c] = np.round(255.0 * lum * np.where(stripe == c, 1.0, 0.55))
+    px[..., 3] = 255
+    image = ImageData(px)
+    k = 1.0 / scale
+    s = Scene()
+    s.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.SrcOver), 1.0, Affine.IDENTITY, Rect(0., 0., 700. * k, 500. * k))
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(245, 245, 220), None, Rect(0., 0., 640. * k, 240. * k))    # css BEIGE
+    s.fill(Fill.EvenOdd, Affine.IDENTITY, Color.from_rgb8(127, 255, 212), None, Rect(0., 240. * k, 320. * k, 480. * k))  # css AQUAMARINE
+    s.push_luminance_mask_layer(Fill.NonZero, 1.0, Affine.IDENTITY, Rect(0., 0., 640. * k, 480. * k))
+    s.draw_image(image, Affine.IDENTITY)
+    s.pop_layer()
+    s.pop_layer()
+    return s, 700 // scale, 500 // scale
+
+
+def base_color_test_scene():
+    """test_scenes.rs:1693-1706: a half-transparent white square over the BASE colour (which the scene animates through the hues: the
+    tests render it over several).  550 x 550."""
+    s = Scene()
+    s.fill(Fill.NonZero, Affine.IDENTITY, Color(1.0, 1.0, 1.0, 0.5), None, Rect(50.0, 50.0, 500.0, 500.0))
+    return s, 550, 550
+
+
 def image_extend_modes_scene(quality=None):
     """test_scenes.rs:2168-2212: the 2x2 sample image as the brush of a 6x6 rect magnified 100x, brush offset (2, 2),
     under Pad, Reflect, Repeat and mixed x-Repeat / y-Reflect; bilinear or nearest.  1500 x 1500 on white."""
