@@ -574,7 +574,8 @@ def test_inconsistent_scenes_are_refused(gpu_engine):
 
 def test_reference_regression_scenes(gpu_engine):
     # the reference's own regression tests that need no fonts: known_issues.rs:54-90 (clip_blends, issue #1198),
-    # regression.rs:18-31 (rounded_rectangle_watertight, issue #616), :107-121 (stroke_width_zero, issue #662)
+    # regression.rs:18-31 (rounded_rectangle_watertight, issue #616), :107-121 (stroke_width_zero, issue #662), known_issues.rs:20-52
+    # (layer_size, issue #1061, `should_panic` upstream: an EMPTY Compose::Clear layer over a red square -- held to the restated shaders' frame)
     import vello_amd
 
     cases = [workloads.clip_blends_scene() + ("clip_blends",)] + workloads.regression_stroke_scenes()
@@ -587,6 +588,8 @@ def test_reference_regression_scenes(gpu_engine):
             assert (img[:, :, :3] == 0).all()
         if name == "clip_blends":
             assert tuple(img[5, 5]) == (0, 0, 255, 255) and tuple(img[90, 50]) == (0, 0, 212, 255)   # blue x aquamarine, multiplied
+        if name == "layer_size":  # (the Clear layer's rectangle comes out transparent -- over black: 0 -- the green around it stays)
+            assert tuple(img[5, 5]) == (0, 255, 0, 255) and tuple(img[30, 30]) == (0, 0, 0, 0)
 
 
 def test_zero_width_stroke_clip_before_any_transform(gpu_engine):

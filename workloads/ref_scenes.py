@@ -645,10 +645,19 @@ def clip_blends_scene():
 
 def regression_stroke_scenes():
     """vello_tests/tests/regression.rs:18-31 (issue #616: the 2 px stroke of a rounded rectangle must be watertight) and
-    :107-121 (issue #662: a zero-width stroke draws nothing).  Returns [(scene, w, h, name)]."""
+    :107-121 (issue #662: a zero-width stroke draws nothing); known_issues.rs:20-52 (below).  Returns [(scene, w, h, name)]."""
     from vello_amd import RoundedRect
     a = Scene()
     a.stroke(Stroke(2.0), Affine.IDENTITY, Color.from_rgb8(255, 255, 255), None, RoundedRect(60.0, 10.0, 80.0, 30.0, 10.0))
     b = Scene()
     b.stroke(Stroke(0.0), Affine.IDENTITY, Color.from_rgb8(255, 218, 185), None, Rect(10.0, 10.0, 40.0, 40.0))
-    return [(a, 70, 30, "rounded_rectangle_watertight"), (b, 50, 50, "stroke_width_zero")]
+    # known_issues.rs:20-52 (issue #1061, `should_panic` upstream: the snapshot and the pipeline disagree about it): a Compose::Clear
+    # layer WITHOUT content over a red square.  Whatever the reference's shaders make of it, the engine must make the same (the
+    # oracle restates them: the layer's rectangle comes out cleared).
+    from vello_amd import BlendMode, Compose, Mix
+    c = Scene()
+    c.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(0, 255, 0), None, Rect(0.0, 0.0, 60.0, 60.0))
+    c.fill(Fill.NonZero, Affine.IDENTITY, Color.from_rgb8(255, 0, 0), None, Rect(20.0, 20.0, 40.0, 40.0))
+    c.push_layer(Fill.NonZero, BlendMode(Mix.Normal, Compose.Clear), 1.0, Affine.IDENTITY, Rect(20.0, 20.0, 40.0, 40.0))
+    c.pop_layer()
+    return [(a, 70, 30, "rounded_rectangle_watertight"), (b, 50, 50, "stroke_width_zero"), (c, 60, 60, "layer_size")]
