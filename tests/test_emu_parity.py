@@ -65,6 +65,31 @@ def test_emu_capacity_overflow_leaves_target_untouched(built):
         L._use_library(None)
 
 
+@pytest.mark.parametrize("spare", [0, 1, 7])
+def test_emu_pools_exactly_full(built, spare):
+    # every pool sized to what the frame takes (+ spare elements): the last tile, line, segment and PTCL word sit at the END of their
+    # buffers -- coarse's two-word tile-bit windows, the 16-byte zero fill of an odd tile range, path_count's and path_tiling's gathers read
+    # right up to it.  (The AddressSanitizer sweep, scripts/asan_check.sh, runs this suite: a read one element too far fails there.)
+    import vello_amd
+    import vello_amd._lib as L
+
+    packed, layout = workloads.random_test_scene(9, n_paths=260, size=300.0, strokes=True, clips=True).resolve()
+    L._use_library(emu_library_path())
+    try:
+        probe = vello_amd.Engine()
+        _, need = probe.render(packed, layout, 300, 300, BLACK, AaConfig.Msaa16)
+        assert need["failed"] == 0
+        caps = {"lines": need["lines"] + spare, "tiles": need["tile"] + spare, "seg_counts": need["seg_counts"] + spare,
+                "segments": need["segments"] + spare, "bin_data": need["binning"] + layout.bin_data_start + spare}
+        eng = vello_amd.Engine(capacities=caps)
+        got = eng.capacities()
+        assert got["tiles"] == need["tile"] + spare and got["lines"] == need["lines"] + spare
+        for aa in (AaConfig.Msaa16, AaConfig.Area):
+            compare_frame(eng, packed, layout, 300, 300, BLACK, aa, f"emu_exact_pools_{spare}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+    finally:
+        L._use_library(None)
+
+
 def test_emu_frames_in_flight_rotate_lanes(built):
     # host logic of vello_hip_set_frames_in_flight: the ring of private buffer sets, sync_frame ages,
     # read_buffer following the newest lane
