@@ -333,8 +333,27 @@ def test_tricky_strokes_round_joins_and_caps(gpu_engine):
     compare_frame(gpu_engine, packed, layout, w, h, WHITE, AaConfig.Msaa8, "gpu_tricky_round")
 
 
-def test_config_c5_all_eight_seeds(gpu_engine):
-    # BASELINE config C5: the eight per-GPU scenes (seeds 0x5EED0001..8), images against the oracle (tile-parallel)
+def test_config_c5_all_eight_seeds(built):
+    # BASELINE config C5 as bench.py --gpus 8 renders it (bench.py Workload: rank k draws paris_like_scene_d2(SEED0 + k) on a
+    # context created with D2_CAPS): the seven scenes of ranks 1..7, images bit-exact against the oracle (tile-parallel);
+    # seeds ...0004 and ...0007 with every intermediate as well.  Seed ...0001 (rank 0) is test_config_c3_d2_scene_full_size.
+    import bench
+    import vello_amd
+    from oracle.oracle import Oracle
+
+    eng = vello_amd.Engine(device=0, capacities=bench.D2_CAPS)
+    o = Oracle(capacity_scale=8)
+    o.set_threads(32)
+    for k in range(1, 8):
+        packed, layout = workloads.paris_like_scene_d2(bench.SEED0 + k).resolve()
+        img, ref, bump = compare_frame(eng, packed, layout, 1600, 1600, WHITE, AaConfig.Msaa16, f"gpu_paris_d2_seed{k}",
+                                       check_stages=(k in (3, 6)), oracle=o)
+        assert bump["failed"] == 0 and bump["lines"] > (1 << 21)
+        assert np.array_equal(img, ref), k
+
+
+def test_config_c5_r1mix_seeds(gpu_engine):
+    # round 1's stroke-light mix (bench.py --workload r1mix) at the same eight seeds, images against the oracle
     from oracle.oracle import Oracle
 
     o = Oracle()
