@@ -90,7 +90,10 @@ enum {
                                  * robust buffer access absorbs such scenes upstream; HIP has none, so they are refused. */
     VELLO_HIP_E_HIP = -2,       /* HIP runtime error; see vello_hip_last_error */
     VELLO_HIP_E_NO_DEVICE = -3, /* no gfx950 device / kernels missing: never falls back to a CPU path */
-    VELLO_HIP_E_CAPACITY = -4   /* bump.failed != 0 */
+    VELLO_HIP_E_CAPACITY = -4,  /* bump.failed != 0: a pool overflowed (the robust path grows the pools and renders again) */
+    VELLO_HIP_E_INTERNAL = -5   /* a spin bound of the engine tripped (a look-back or k_front's grid barrier waited for a workgroup
+                                 * that never arrived): the frame is discarded, the lane's counters are reset; NOT a pool overflow --
+                                 * auto-grow does not treat it as one */
 };
 
 /* Stage ids (launch order; render.rs:250-502, :560-629).  Several reference dispatches are fused:

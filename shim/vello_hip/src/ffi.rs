@@ -71,6 +71,7 @@ pub const VELLO_HIP_E_INVALID: c_int = -1;
 pub const VELLO_HIP_E_HIP: c_int = -2;
 pub const VELLO_HIP_E_NO_DEVICE: c_int = -3;
 pub const VELLO_HIP_E_CAPACITY: c_int = -4;
+pub const VELLO_HIP_E_INTERNAL: c_int = -5;
 pub const VELLO_HIP_DEBUG_NO_CULL: u32 = 1;
 pub const VELLO_HIP_DEBUG_STROKE_KERNEL: u32 = 2;
 pub const VELLO_HIP_DEBUG_SEQ_CLIP: u32 = 4;

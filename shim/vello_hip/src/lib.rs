@@ -25,6 +25,8 @@ pub enum Error {
     /// A bump-allocated pool overflowed and auto-grow is off: the target is untouched (fine.wgsl:1070-1074); the
     /// counters say what the frame needs (`HipRenderer::grow_pools`).
     Capacity(vello_hip_bump),
+    /// An engine-internal wait gave up (a look-back or grid barrier whose partner never arrived): the frame is discarded.
+    Internal(String),
 }
 
 pub struct HipRenderer {
@@ -79,6 +81,7 @@ impl HipRenderer {
             VELLO_HIP_E_NO_DEVICE => Error::NoCompatibleDevice,
             VELLO_HIP_E_INVALID => Error::Invalid(msg),
             VELLO_HIP_E_CAPACITY => Error::Capacity(bump),
+            VELLO_HIP_E_INTERNAL => Error::Internal(msg),
             _ => Error::Hip(msg),
         }
     }

@@ -419,6 +419,11 @@ def check_front_fusion(engine, case, in_flight=(1, 2)):
 
     name, packed, layout, w, h, bg, per_frame = case
     try:
+        # The launch counts asserted below depend on which of flatten's kernel sets the engine picks (the one-launch front needs the
+        # cooperative set) and the engine picks it from the scene's size and the list counts of its last finished frame: pinned
+        # here, so that the counts do not depend on what the engine rendered before.  (Stage profiling --
+        # vello_hip_set_profiling -- also decides fusion: a stage that is timed on its own is launched on its own.)
+        engine.set_debug_flags(flatten_coop=True)
         for n in in_flight:
             engine.set_frames_in_flight(n)
             for aa in (AaConfig.Area, AaConfig.Msaa16):

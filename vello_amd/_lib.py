@@ -174,11 +174,16 @@ def kernel_sources_hash():
     import hashlib
     import os
 
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.join(here, "csrc")
     h = hashlib.sha1()
-    files = [os.path.join(root, "Makefile")] + sorted(os.path.join(root, "engine", f) for f in os.listdir(os.path.join(root, "engine")))
+    # an explicit list: the Makefile, every source the kernel objects depend on -- engine/*.hip, *.h, *.inc and the
+    # public header with the layout / config / flag types the kernels use -- and nothing else (no editor backups, no stray files)
+    engine = os.path.join(root, "engine")
+    files = [os.path.join(root, "Makefile"), os.path.join(os.path.dirname(here), "include", "vello_hip.h")]
+    files += sorted(os.path.join(engine, f) for f in os.listdir(engine) if f.endswith((".hip", ".h", ".inc")))
     for f in files:
-        if os.path.isfile(f) and not os.path.basename(f).startswith("_"):
+        with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+            h.update(fh.read())
     return h.hexdigest()[:12]

@@ -237,7 +237,17 @@ uint32_t tile_bits_words(uint32_t tiles) { return (tiles + 63u) / 64u * 8u + 2u;
 int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     const vello_hip_capacities &d = c->caps;
     int r;
-    if (!l.stream) HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    if (!l.stream) {
+        // EXPERIMENT (scripts/stream_order_probe.py): VELLO_HIP_LANE_PRIORITY=high|low creates the lanes' streams with that priority
+        // -- the runtime keeps a pool of hardware queues per priority, so the lanes' queues no longer depend on what else created
+        // streams before them
+        const char *pr = std::getenv("VELLO_HIP_LANE_PRIORITY");
+        int least = 0, greatest = 0;
+        if (pr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            HIP_TRY(c, hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, pr[0] == 'h' ? greatest : least));
+        else
+            HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    }
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile)))) return r;
@@ -494,6 +504,27 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     return 0;
 }
 
+// k_front's grid-barrier counter (Lane::front_sync) only ever grows, and the host keeps its value: a launch's barriers wait for
+// sync_base + k * (its workgroups).  The two must never drift apart: if a launch is rejected the device never adds, if a
+// barrier's spin bound trips the workgroups stop waiting -- either way the counter goes back to zero on the lane's stream, behind
+// whatever was enqueued, and the host's copy with it.
+static void reset_front_sync(Lane &l, hipStream_t st) {
+    if (l.front_sync.ptr) (void)hipMemsetAsync(l.front_sync.ptr, 0, 256, st);
+    l.front_sync_value = 0u;
+}
+// After a k_front launch: the host's copy of the counter advances only once the launch was accepted.
+static int front_accepted(vello_hip_ctx *c, Lane &l, hipStream_t st, uint32_t add) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        reset_front_sync(l, st);
+        c->last_error = std::string("k_front launch: ") + hipGetErrorString(e);
+        return VELLO_HIP_E_HIP;
+    }
+    l.front_sync_value += add;
+    c->fused_launches++;
+    return 0;
+}
+
 int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int last) {
     hipStream_t st = l.stream;
     // coarse decides which tiles are cut into slices from the number of slice blocks fine is going to launch: a FINE that
@@ -528,6 +559,8 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     }
     for (int s = first; s <= last; s++) {
         bool prof = ((c->prof_mask >> s) & 1u) != 0u;
+        uint32_t front_add = 0u;  // what a k_front launch of this stage adds to the lane's barrier counter (0: one workgroup)
+        bool front_launched = false;
         Lane::EvPair ev{s, nullptr, nullptr, {nullptr, nullptr}};
         if (prof) {
             ev.a = get_event(c);
@@ -541,8 +574,8 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
             l.flatten_ran = false;
             if (fuse_all) {
-                c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT | FRONT_HEAVY | FRONT_BINNING | FRONT_TILE_ALLOC, true,
-                                                   l.front_sync_value);
+                front_add = launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT | FRONT_HEAVY | FRONT_BINNING | FRONT_TILE_ALLOC, true, l.front_sync_value);
+                front_launched = true;
                 break;
             }
             if (fuse_a) break;  // (with FLATTEN's first launch)
@@ -553,8 +586,11 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             l.flatten_ran = true;
             if (fuse_all) break;
             // (a range that goes on to DRAW_SCAN: that stage's workgroups ride in flatten's first launch)
-            if (fuse_a)
-                c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT, last >= VELLO_HIP_STAGE_DRAW_SCAN, l.front_sync_value);
+            if (fuse_a) {
+                // (k_front's barrier counter advances on the host only once the launch was accepted: ADVICE r5)
+                const uint32_t add = launch_front(f, st, FRONT_ZERO | FRONT_PATHTAG | FRONT_LIGHT, last >= VELLO_HIP_STAGE_DRAW_SCAN, l.front_sync_value);
+                if (int r = front_accepted(c, l, st, add)) return r;
+            }
             launch_flatten(f, st, prof ? ev.mid : nullptr, last >= VELLO_HIP_STAGE_DRAW_SCAN, fuse_a);
             break;
         case VELLO_HIP_STAGE_DRAW_SCAN:
@@ -564,8 +600,10 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         case VELLO_HIP_STAGE_BINNING:
             if (fuse_all) break;
             if (fuse_b) {
-                if (f.cfg.layout.n_draw_objects != 0u || f.cfg.layout.n_paths != 0u)
-                    c->fused_launches++, l.front_sync_value += launch_front(f, st, FRONT_BINNING | FRONT_TILE_ALLOC, false, l.front_sync_value);
+                if (f.cfg.layout.n_draw_objects != 0u || f.cfg.layout.n_paths != 0u) {
+                    front_add = launch_front(f, st, FRONT_BINNING | FRONT_TILE_ALLOC, false, l.front_sync_value);
+                    front_launched = true;
+                }
             } else {
                 launch_binning(f, st);
             }
@@ -580,7 +618,11 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         case VELLO_HIP_STAGE_FINE: launch_fine(f, st); break;
         default: return VELLO_HIP_E_INVALID;
         }
-        HIP_TRY(c, hipGetLastError());
+        if (front_launched) {
+            if (int r = front_accepted(c, l, st, front_add)) return r;
+        } else {
+            HIP_TRY(c, hipGetLastError());
+        }
         if (prof) {
             HIP_TRY(c, hipEventRecord(ev.b, st));
             l.events.push_back(ev);
@@ -684,6 +726,20 @@ int vello_hip_create(int device, uint32_t aa_mask, const vello_hip_capacities *c
     if (hipSetDevice(device) != hipSuccess) {
         g_create_error = "hipSetDevice failed";
         return VELLO_HIP_E_NO_DEVICE;
+    }
+    // The process's FIRST hardware queue is a poor place for a lane: with four frames in flight a context whose lane 0 sits on it
+    // renders 8 % fewer frames per second than one whose lanes come second to fifth (profiles/r06_queue_order.txt: 2 110 against
+    // 2 300 on the road map, rocprofv3's Queue_Id per stream).  HIP hands out hardware queues in the order streams are created,
+    // and creates the null stream's lazily -- so the null stream is made to take its queue here, before the lanes' streams exist
+    // (a caller that has used the device before gets the same order by itself).
+    {
+        void *scratch = nullptr;
+        if (hipMalloc(&scratch, 256) == hipSuccess) {
+            (void)hipMemsetAsync(scratch, 0, 256, nullptr);
+            (void)hipStreamSynchronize(nullptr);
+            (void)hipFree(scratch);
+        }
+        (void)hipGetLastError();
     }
     vello_hip_ctx *c = new vello_hip_ctx();
     c->device = device;
@@ -1069,6 +1125,14 @@ static int check_lane(vello_hip_ctx *c, Lane &l) {
     if ((b.failed & FAILED_SCENE) != 0u) {
         c->last_error = "the path tag stream needs more path data, transforms or styles than the scene buffer holds";
         return VELLO_HIP_E_INVALID;
+    }
+    if ((b.failed & FAILED_INTERNAL) != 0u) {
+        // a spin bound tripped (lookback.h, k_front's barrier): not a pool overflow -- growing pools would not help.  The lane is idle
+        // here (the caller waited for it): its barrier counter starts over.
+        reset_front_sync(l, l.stream);
+        (void)hipStreamSynchronize(l.stream);
+        c->last_error = "an engine-internal wait gave up (bump.failed bit 31): the frame is discarded";
+        return VELLO_HIP_E_INTERNAL;
     }
     char msg[160];
     std::snprintf(msg, sizeof msg, "bump.failed=0x%x (lines %u, binning %u, tile %u, seg_counts %u, segments %u, ptcl %u)", b.failed,

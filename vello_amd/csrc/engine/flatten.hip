@@ -1573,27 +1573,36 @@ struct FrontArgs {
     Tile *tiles;
 };
 
-// All workgroups of the launch have finished the stage before / may start the next one.
-__device__ __forceinline__ void front_barrier(uint32_t *sync, uint32_t target, uint32_t *failed_flag) {
+// All workgroups of the launch have finished the stage before / may start the next one.  Returns false when the wait gave up (or
+// had given up before: `tripped`).  A workgroup that gave up keeps ADDING at every later barrier -- the counter must end at
+// sync_base + (barriers of the launch) x (workgroups), or every later launch on the lane would wait for the difference -- but no
+// longer waits, and k_front skips its remaining stage bodies: their inputs are whatever the workgroups it did not wait for had
+// written by then, or the previous frame's.
+__device__ __forceinline__ bool front_barrier(uint32_t *sync, uint32_t target, bool tripped, uint32_t *sh_tripped) {
     __syncthreads();  // (the workgroup's stores are out)
 #ifndef VELLO_SIMT_EMU  // (the emulator runs workgroups one after the other: a launch there is ONE workgroup)
     if (gridDim.x != 1u) {
         if (threadIdx.x == 0u) {
             __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t spins = 0u;
-            while ((int32_t)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            while (!tripped && (int32_t)(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                 // (as the look-back's: a launch that is not resident as a whole -- it always is, FRONT_MAX_WG -- must fail, not hang)
                 if (++spins > SPIN_LIMIT) {
-                    atomicOr(failed_flag, FAILED_INTERNAL);
+                    tripped = true;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *sh_tripped = tripped ? 1u : 0u;
         }
         __syncthreads();
+        tripped = *sh_tripped != 0u;
     }
+#else
+    (void)sync; (void)target; (void)sh_tripped;
 #endif
+    return !tripped;
 }
 
 template <bool HEAVY>
@@ -1601,11 +1610,13 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
     const uint32_t tid = threadIdx.x, wg = blockIdx.x, n_wg = gridDim.x;
     uint32_t target = a.sync_base;
     uint32_t todo = a.stages;
+    __shared__ uint32_t sh_tripped;
+    bool ok = true;  // (workgroup-uniform) no barrier of this launch has given up so far
     // (a barrier behind every stage but the launch's last)
 #define FRONT_STAGE_END(bit)                                   \
     do {                                                       \
         todo &= ~(bit);                                        \
-        if (todo != 0u) front_barrier(a.sync, target += n_wg, &a.control->bump.failed); \
+        if (todo != 0u) ok = front_barrier(a.sync, target += n_wg, !ok, &sh_tripped); \
     } while (0)
     if (a.stages & FRONT_ZERO) {  // render.rs:313 clears `bump`; here: Control and both look-back states
         uint4 *z = reinterpret_cast<uint4 *>(a.control);
@@ -1613,7 +1624,7 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
         FRONT_STAGE_END(FRONT_ZERO);
     }
     if (a.stages & FRONT_PATHTAG) {
-        for (uint32_t b = wg; b < a.n_pathtag_blocks; b += n_wg) {
+        for (uint32_t b = wg; ok && b < a.n_pathtag_blocks; b += n_wg) {
             pathtag_scan_workgroup(cfg, b, a.n_pathtag_blocks, a.n_tag_words, a.n_scene_words, a.scene, a.control, a.pathtag_state, a.tag_monoids,
                                    a.path_bboxes);
             __syncthreads();  // (the next turn writes the LDS this one read)
@@ -1621,7 +1632,7 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
         FRONT_STAGE_END(FRONT_PATHTAG);
     }
     if (a.stages & FRONT_LIGHT) {
-        for (uint32_t b = wg; b < a.n_draw_blocks + a.n_light_blocks; b += n_wg) {
+        for (uint32_t b = wg; ok && b < a.n_draw_blocks + a.n_light_blocks; b += n_wg) {
             if (b < a.n_draw_blocks)
                 draw_scan_workgroup(cfg, a.scene, a.control, a.draw_state, a.path_bboxes, a.draw_monoids, a.info_bin_data, a.clip_inp);
             else
@@ -1634,6 +1645,7 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
         if (a.stages & FRONT_HEAVY) {
             // (no stroke workgroups: every stroked line is the heavy list's; the workgroups stride over the list themselves)
             __shared__ __attribute__((aligned(16))) unsigned char smem[FLATTEN_MAIN_LDS];
+            if (ok)
             heavy_workgroups<HEAVY_FIRST, true>(*reinterpret_cast<FlattenShared<FLATTEN_LDS_LINES> *>(smem),
                                                 reinterpret_cast<EulerCoopLds *>(smem + FLATTEN_ARCS_AT), wg, n_wg, cfg, a.n_tags, a.scene, a.tag_monoids,
                                                 a.path_bboxes, a.control, a.lines, a.heavy_list, 0xffffffffu, a.arc_items, a.arc_shard_cap);
@@ -1641,18 +1653,21 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
         }
     }
     if (a.stages & FRONT_BINNING) {
-        for (uint32_t b = wg; b < a.n_binning_blocks; b += n_wg) {
+        for (uint32_t b = wg; ok && b < a.n_binning_blocks; b += n_wg) {
             binning_workgroup(cfg, b, a.draw_monoids, a.path_bboxes, a.clip_bboxes, a.draw_bboxes, &a.control->bump, a.info_bin_data, a.bin_headers);
             __syncthreads();
         }
         FRONT_STAGE_END(FRONT_BINNING);
     }
     if (a.stages & FRONT_TILE_ALLOC) {
-        for (uint32_t b = wg; b < a.n_tile_alloc_blocks; b += n_wg) {
+        for (uint32_t b = wg; ok && b < a.n_tile_alloc_blocks; b += n_wg) {
             tile_alloc_workgroup(cfg, b, a.scene, a.draw_bboxes, &a.control->bump, a.paths, a.tiles);
             __syncthreads();
         }
     }
+    // (raised at the END of the launch: a flag set at the barrier behind FRONT_ZERO could be cleared again by the zero fill of a
+    // workgroup that had not got that far)
+    if (!ok && tid == 0u) atomicOr(&a.control->bump.failed, FAILED_INTERNAL);
 #undef FRONT_STAGE_END
 }
 
