@@ -923,6 +923,19 @@ def path_count_both_forms(eng, name):
         bump = eng.bump()
         assert np.array_equal(img, ref), f"{name}: frame {k} differs"
         assert bump["failed"] == 0 and all(bump[key] == ob[key] for key in ("tile", "seg_counts", "lines", "binning")), (name, k, bump, ob)
+    # round 6: with frames in flight a soup of unknown or large size takes the form with the small LDS footprint (path.hip
+    # PcInFlight: chunks of 512 lines, a table of 256 cache lines, a stash of 384) -- the first frame after an upload
+    eng.set_frames_in_flight(2)
+    try:
+        eng.upload_scene(packed, layout)
+        eng.render_resident(1024, 1024, WHITE, AaConfig.Msaa16)
+        eng.sync_frame(0)
+        img = eng.read_buffer("output", np.uint8, 1024 * 1024 * 4).reshape(1024, 1024, 4)
+        bump = eng.bump()
+        assert np.array_equal(img, ref), f"{name}: the frame of the in-flight form differs"
+        assert bump["failed"] == 0 and all(bump[key] == ob[key] for key in ("tile", "seg_counts", "lines", "binning")), (name, bump, ob)
+    finally:
+        eng.set_frames_in_flight(1)
 
 
 def test_emu_path_count_both_forms(emu_engine):
@@ -952,6 +965,12 @@ def path_count_long_lines(eng, name):
     packed, layout = s.resolve()
     for aa in (AaConfig.Area, AaConfig.Msaa16):
         compare_frame(eng, packed, layout, 1600, 1600, BLACK, aa, f"{name}_{int(aa)}", tol=1 if aa == AaConfig.Area else 0)
+    # the same arms of the form frames in flight take (PcInFlight: a stash of 384, a table of 256 entries)
+    eng.set_frames_in_flight(2)
+    try:
+        compare_frame(eng, packed, layout, 1600, 1600, BLACK, AaConfig.Msaa16, f"{name}_in_flight")
+    finally:
+        eng.set_frames_in_flight(1)
 
 
 def test_emu_path_count_long_lines(emu_engine):

@@ -237,17 +237,7 @@ uint32_t tile_bits_words(uint32_t tiles) { return (tiles + 63u) / 64u * 8u + 2u;
 int alloc_lane_pools(vello_hip_ctx *c, Lane &l) {
     const vello_hip_capacities &d = c->caps;
     int r;
-    if (!l.stream) {
-        // EXPERIMENT (scripts/stream_order_probe.py): VELLO_HIP_LANE_PRIORITY=high|low creates the lanes' streams with that priority
-        // -- the runtime keeps a pool of hardware queues per priority, so the lanes' queues no longer depend on what else created
-        // streams before them
-        const char *pr = std::getenv("VELLO_HIP_LANE_PRIORITY");
-        int least = 0, greatest = 0;
-        if (pr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-            HIP_TRY(c, hipStreamCreateWithPriority(&l.stream, hipStreamNonBlocking, pr[0] == 'h' ? greatest : least));
-        else
-            HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-    }
+    if (!l.stream) HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_LINES], (size_t)d.lines * sizeof(LineSoup)))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_INFO_BIN_DATA], (size_t)d.bin_data * 4u))) return r;
     if ((r = ensure(c, l.buf[VELLO_HIP_BUF_TILES], (size_t)d.tiles * sizeof(Tile)))) return r;

@@ -179,10 +179,40 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 #ifndef VK_PC_STASH
 #define VK_PC_STASH 768
 #endif
-constexpr uint32_t PC_TABLE_LOG2 = VK_PC_TABLE_LOG2, PC_TABLE = 1u << PC_TABLE_LOG2, PC_PROBES = 3u;
+// Round 6: the kernel's LDS footprint is a parameter.  With frames in flight k_path_count shares the CUs with the other frames'
+// kernels, and 3 x 48.7 KB left them 14 KB of a CU's LDS for as long as its workgroups waited for their flushes (266 us under
+// overlap for 103 alone, profiles/r05_pipeline_timeline.txt).  PcInFlight -- chunks of 512 lines, a table of 256 cache lines, a
+// stash of 384 crossings per wave: 24.6 KB, 88 VGPRs -- is 12 % slower alone (118 against 105 us on d2) and +3.6 % frames/s with
+// four frames in flight (a process per build, alternating: profiles/r06_ab_path_count_footprint.txt); one frame at a time keeps
+// the large form.
+#ifndef VK_PC_TABLE_LOG2_IN_FLIGHT
+#define VK_PC_TABLE_LOG2_IN_FLIGHT 8
+#endif
+#ifndef VK_PC_STASH_IN_FLIGHT
+#define VK_PC_STASH_IN_FLIGHT 384
+#endif
+#ifndef VK_PC_LPT_IN_FLIGHT
+#define VK_PC_LPT_IN_FLIGHT 2
+#endif
+#ifndef VK_PC_GRID_IN_FLIGHT
+#define VK_PC_GRID_IN_FLIGHT 1024u
+#endif
+constexpr uint32_t PC_PROBES = 3u;
 constexpr uint32_t PC_EMPTY = 0xffffffffu, PC_NONE = 0xffffffffu;
-constexpr uint32_t PC_STASH = VK_PC_STASH;  // crossings per wave and chunk that wait in LDS for their cursors
 constexpr uint32_t PC_DONE = 0x80000000u;   // stash word: bits 0-15 are the slot index already (else: the cursor's word index)
+template <uint32_t TABLE_LOG2_, uint32_t STASH_>
+struct PcParams {
+    static constexpr uint32_t TABLE_LOG2 = TABLE_LOG2_, TABLE = 1u << TABLE_LOG2_;
+    static constexpr uint32_t CNT_WORDS = TABLE * 16u;
+    static constexpr uint32_t STASH = STASH_;  // crossings per wave and chunk that wait in LDS for their cursors
+    // The packed fields below hold only for these sizes (the constants are -D-overridable for sweeps and for
+    // scripts/emu_variant_check.sh; a value beyond them would corrupt slots and backdrops silently instead of failing the build):
+    static_assert(CNT_WORDS + 64u <= 65536u, "a stash word keeps the cursor's word index (spare words included) in bits 0-15");
+    static_assert(TABLE <= 65536u, "PcShared::occupied is uint16_t");
+    static_assert(4u * STASH < 32768u, "a cnt word: crossings in bits 0-15, the SIGNED sum of backdrop bumps above -- both bounded by the chunk's stashed crossings (4 waves x STASH)");
+};
+using PcAlone = PcParams<VK_PC_TABLE_LOG2, VK_PC_STASH>;
+using PcInFlight = PcParams<VK_PC_TABLE_LOG2_IN_FLIGHT, VK_PC_STASH_IN_FLIGHT>;
 
 // `c` for some lane of the wave, as a scalar branch condition: the seldom-taken arms below are a handful of instructions, which
 // the compiler would run with an empty exec mask rather than branch over.  (The emulator runs lanes as fibers: the lane's own c.)
@@ -192,26 +222,21 @@ constexpr uint32_t PC_DONE = 0x80000000u;   // stash word: bits 0-15 are the slo
 #define PC_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
 #endif
 
-constexpr uint32_t PC_CNT_WORDS = PC_TABLE * 16u;
+template <class P>
 struct PcShared {
     // (the 64 words behind keys[] and cnt[]: a place of its own for every lane whose LDS operation is not wanted -- the walk
     // loop selects ADDRESSES instead of branching around the operations: a branch costs five scalar instructions, a select one)
-    uint32_t keys[PC_TABLE + 64u];     // tile index >> 4 of the entry, PC_EMPTY; the spare words hold PC_NOBODY
+    uint32_t keys[P::TABLE + 64u];     // tile index >> 4 of the entry, PC_EMPTY; the spare words hold PC_NOBODY
     // counting, a word per tile: its crossings | << 16 the sum of the backdrop bumps of the tile to its RIGHT (where a crossing
     // with a top edge puts its bump, path_count.wgsl:181-186: one add does both); after the flush: the tile's slot cursor
-    uint32_t cnt[PC_CNT_WORDS + 64u];
-    uint16_t occupied[PC_TABLE];
+    uint32_t cnt[P::CNT_WORDS + 64u];
+    uint16_t occupied[P::TABLE];
     uint32_t n_occ;
-    uint32_t stash[4][PC_STASH]; // cursor word index or PC_DONE | slot index; | lane of the line << 16
+    uint32_t stash[4][P::STASH]; // cursor word index or PC_DONE | slot index; | lane of the line << 16
     uint32_t wave_total[4];
     uint32_t base;
 };
 constexpr uint32_t PC_NOBODY = 0xfffffffeu;
-// The packed fields above hold only for these sizes (the constants are -D-overridable for sweeps and for
-// scripts/emu_variant_check.sh; a value beyond them would corrupt slots and backdrops silently instead of failing the build):
-static_assert(PC_CNT_WORDS + 64u <= 65536u, "a stash word keeps the cursor's word index (spare words included) in bits 0-15");
-static_assert(PC_TABLE <= 65536u, "PcShared::occupied is uint16_t");
-static_assert(4u * PC_STASH < 32768u, "a cnt word: crossings in bits 0-15, the SIGNED sum of backdrop bumps above -- both bounded by the chunk's stashed crossings (4 waves x PC_STASH)");
 static_assert(PC_PROBES >= 1u, "an entry is looked for in at least one place");
 
 struct PcWalk {
@@ -222,15 +247,17 @@ struct PcWalk {
     uint32_t flags;              // 1: is_down, 2: negative slope, 4: y0 == s0.y
 };
 
-__device__ __forceinline__ uint32_t pc_hash(uint32_t line) { return (line * 0x9E3779B1u) >> (32u - PC_TABLE_LOG2); }
+template <class P>
+__device__ __forceinline__ uint32_t pc_hash(uint32_t line) { return (line * 0x9E3779B1u) >> (32u - P::TABLE_LOG2); }
 // the places a cache line of tiles may take when its first one (pc_hash) is somebody else's; PC_NONE if they all are (the table
 // only grows within a chunk: whoever asks for the same line later gets the same answer)
-__device__ __forceinline__ uint32_t pc_slot_more(PcShared &sh, uint32_t line) {
-    uint32_t h = pc_hash(line);
+template <class P>
+__device__ __forceinline__ uint32_t pc_slot_more(PcShared<P> &sh, uint32_t line) {
+    uint32_t h = pc_hash<P>(line);
     const uint32_t step = (line >> 2) | 1u;
 #pragma unroll 1
     for (uint32_t p = 1; p < PC_PROBES; p++) {
-        h = (h + step) & (PC_TABLE - 1u);
+        h = (h + step) & (P::TABLE - 1u);
         const uint32_t o = atomicCAS(&sh.keys[h], PC_EMPTY, line);
         if (o == PC_EMPTY || o == line) return h;
     }
@@ -252,7 +279,8 @@ __device__ __forceinline__ uint32_t pc_slot_more(PcShared &sh, uint32_t line) {
 #define VK_PC_COOP_FROM 8u
 #endif
 constexpr uint32_t PC_COOP_FROM = VK_PC_COOP_FROM;
-__device__ __forceinline__ void pc_count_lines(PcShared &sh, const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, uint32_t lane, uint32_t wave,
+template <class P>
+__device__ __forceinline__ void pc_count_lines(PcShared<P> &sh, const PcWalk &w, uint32_t imin, uint32_t item0, uint32_t n_stash, uint32_t lane, uint32_t wave,
                                                const Config &cfg, Tile *tile) {
     // crossing i of the line with this walk, owned by lane `owner`, item `item` of the wave
     auto crossing = [&](float a, float b, float x0, float y0, uint32_t base, uint32_t bbox02, uint32_t flags, uint32_t i, float last_z, float z,
@@ -273,13 +301,13 @@ __device__ __forceinline__ void pc_count_lines(PcShared &sh, const PcWalk &w, ui
         const bool bump = top_edge && x1 < bbox2 && bkey < cfg.tiles_size;
         // the usual crossing: in the pool, its cache line in the first place the table gives it, its bump (if any) on the tile to
         // its right -- a compare-and-swap, an add and the stash, no branch
-        const uint32_t line = key >> 4, h = pc_hash(line);
-        const uint32_t o = atomicCAS(&sh.keys[counted ? h : PC_TABLE + lane], PC_EMPTY, line);
+        const uint32_t line = key >> 4, h = pc_hash<P>(line);
+        const uint32_t o = atomicCAS(&sh.keys[counted ? h : P::TABLE + lane], PC_EMPTY, line);
         const bool hit = o == PC_EMPTY || o == line;  // (a lane outside the pool reads PC_NOBODY)
         const bool bump_right = bump && bkey == key + 1u;
         const uint32_t at = h * 16u + (key & 15u);
         const uint32_t one = 1u + (bump_right ? (uint32_t)delta << 16 : 0u);
-        atomicAdd(&sh.cnt[hit ? at : PC_CNT_WORDS + lane], one);
+        atomicAdd(&sh.cnt[hit ? at : P::CNT_WORDS + lane], one);
         uint32_t word = hit ? at : PC_DONE;  // (a crossing outside the pool gets slot 0, as a robust access would give it)
         // everything else, seldom: another place in the table, or none and straight to memory; a bump that is not on the right
         const bool rest = (counted && !hit) || (bump && !(hit && bump_right));
@@ -287,7 +315,7 @@ __device__ __forceinline__ void pc_count_lines(PcShared &sh, const PcWalk &w, ui
             if (rest) {
                 bool bumped = hit && bump_right;
                 if (counted && !hit) {
-                    const uint32_t slot = pc_slot_more(sh, line);
+                    const uint32_t slot = pc_slot_more<P>(sh, line);
                     if (slot != PC_NONE) {
                         word = slot * 16u + (key & 15u);
                         atomicAdd(&sh.cnt[word], one);
@@ -376,10 +404,11 @@ __device__ __forceinline__ void pc_walk_line_direct(const PcWalk &w, uint32_t im
     }
 }
 
-template <uint32_t LPT>
+template <uint32_t LPT, class P>
 __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, const LineSoup *__restrict__ lines,
                                                         const Path *__restrict__ paths, Tile *tile, SegmentCount *__restrict__ seg_counts) {
-    __shared__ PcShared sh;
+    __shared__ PcShared<P> sh;
+    constexpr uint32_t PC_TABLE = P::TABLE, PC_CNT_WORDS = P::CNT_WORDS, PC_STASH = P::STASH;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     if (bump->failed != 0u) return;  // path_count_setup.wgsl:18-19
     const uint32_t n_lines = minu(bump->lines, cfg.lines_size);
@@ -454,7 +483,7 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
         uint32_t done = 0u;  // items of this wave before line group j (wave-uniform)
 #pragma unroll
         for (uint32_t j = 0; j < LPT; j++) {
-            pc_count_lines(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile);
+            pc_count_lines<P>(sh, w[j], w[j].ioff + p[j], done + p[j], n_stash[j], lane, wave, cfg, tile);
             done += T[j];
         }
         if (tid == 0u) sh.base = reserved;
@@ -753,10 +782,13 @@ static uint32_t clamp_grid(uint64_t work_items, uint32_t per_block, uint32_t max
 void launch_path_count(const Frame &f, hipStream_t s) {
     if (f.path_count_small) {
         const uint32_t grid = clamp_grid(f.cfg.lines_size, 256u, VK_PC_GRID);
-        hipLaunchKernelGGL(k_path_count<1u>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
-    } else {
+        hipLaunchKernelGGL((k_path_count<1u, PcAlone>), dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    } else if (f.flatten_side_by_side) {  // (one frame in flight)
         const uint32_t grid = clamp_grid(f.cfg.lines_size, PATH_COUNT_CHUNK, VK_PC_GRID);
-        hipLaunchKernelGGL(k_path_count<PATH_COUNT_LINES_PER_THREAD>, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+        hipLaunchKernelGGL((k_path_count<PATH_COUNT_LINES_PER_THREAD, PcAlone>), dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
+    } else {  // frames in flight: the small footprint (PcInFlight, above)
+        const uint32_t grid = clamp_grid(f.cfg.lines_size, 256u * VK_PC_LPT_IN_FLIGHT, VK_PC_GRID_IN_FLIGHT);
+        hipLaunchKernelGGL((k_path_count<VK_PC_LPT_IN_FLIGHT, PcInFlight>), dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.lines, f.paths, f.tiles, f.seg_counts);
     }
 }
 
