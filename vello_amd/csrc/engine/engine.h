@@ -53,6 +53,16 @@ constexpr uint32_t FINE_HEAVY_WORDS = 384;
 #define VK_SLICE_MIN_FILLS 96
 #endif
 constexpr uint32_t FINE_SLICE_FILLS = VK_SLICE_FILLS, FINE_SLICE_MIN_FILLS = VK_SLICE_MIN_FILLS;
+// With frames in flight the tail of k_fine's launch is filled by the other frames' kernels, and what slicing costs -- the coverage
+// through memory, a second pass over the list -- is no longer paid back: the threshold is higher there (round 6,
+// profiles/r06_ab_slices_in_flight.txt).
+#ifndef VK_SLICE_MIN_FILLS_IN_FLIGHT
+#define VK_SLICE_MIN_FILLS_IN_FLIGHT 192
+#endif
+#ifndef VK_SLICE_FILLS_IN_FLIGHT
+#define VK_SLICE_FILLS_IN_FLIGHT VK_SLICE_FILLS
+#endif
+constexpr uint32_t FINE_SLICE_FILLS_IN_FLIGHT = VK_SLICE_FILLS_IN_FLIGHT, FINE_SLICE_MIN_FILLS_IN_FLIGHT = VK_SLICE_MIN_FILLS_IN_FLIGHT;
 constexpr uint32_t FINE_SLICE_FILLS_FORCED = 4, FINE_SLICE_MIN_FILLS_FORCED = 5;  // VELLO_HIP_DEBUG_FINE_SLICES
 struct SliceItem {
     uint32_t tile_ix;     // ~0: a hole left by a tile whose slices did not fit the capacity
@@ -206,6 +216,7 @@ void launch_clip(const Frame &f, hipStream_t s);             // clip.hip
 void launch_clip_sequential(const Frame &f, hipStream_t s);  // draw.hip
 void launch_binning(const Frame &f, hipStream_t s);
 void launch_tile_alloc(const Frame &f, hipStream_t s);
+void launch_binning_tile_alloc(const Frame &f, hipStream_t s);
 void launch_path_count(const Frame &f, hipStream_t s);
 void launch_backdrop(const Frame &f, hipStream_t s);
 void launch_coarse(const Frame &f, hipStream_t s, hipEvent_t *mid = nullptr);

@@ -440,8 +440,9 @@ int prepare_frame(vello_hip_ctx *c, Lane &l, const vello_hip_render_params *p, v
     l.slices_on = p->aa != 0u;
     if (p->aa != 0u) {
         const bool forced = (c->debug_flags & VELLO_HIP_DEBUG_FINE_SLICES) != 0u;
-        f.slice_fills = forced ? FINE_SLICE_FILLS_FORCED : FINE_SLICE_FILLS;
-        f.slice_min_fills = forced ? FINE_SLICE_MIN_FILLS_FORCED : FINE_SLICE_MIN_FILLS;
+        const bool alone = c->n_active == 1u;
+        f.slice_fills = forced ? FINE_SLICE_FILLS_FORCED : (alone ? FINE_SLICE_FILLS : FINE_SLICE_FILLS_IN_FLIGHT);
+        f.slice_min_fills = forced ? FINE_SLICE_MIN_FILLS_FORCED : (alone ? FINE_SLICE_MIN_FILLS : FINE_SLICE_MIN_FILLS_IN_FLIGHT);
     }
     f.heavy_list = (uint32_t *)l.heavy_list.ptr;
     f.arc_items = (uint32_t *)l.arc_items.ptr;
@@ -536,6 +537,10 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
     // + draw scan], B: [binning | tile_alloc]; a scene of a few dozen segments: everything up to tile_alloc.  Not for a stage that
     // is being timed on its own.
     bool fuse_a = false, fuse_b = false, fuse_all = false;
+    // Any scene: binning and tile_alloc as one launch (binning.hip k_binning_tile_alloc) when the range holds both and neither is
+    // timed on its own
+    const bool pair_b = (c->debug_flags & VELLO_HIP_DEBUG_NO_FUSION) == 0u && first <= VELLO_HIP_STAGE_BINNING && last >= VELLO_HIP_STAGE_TILE_ALLOC &&
+                        (c->prof_mask & ((1u << VELLO_HIP_STAGE_BINNING) | (1u << VELLO_HIP_STAGE_TILE_ALLOC))) == 0u;
     if ((c->debug_flags & VELLO_HIP_DEBUG_NO_FUSION) == 0u && f.n_tag_words * 4u <= FRONT_MAX_TAGS &&
         f.cfg.layout.n_draw_objects <= FRONT_MAX_DRAW_OBJECTS && f.cfg.layout.n_paths <= FRONT_MAX_DRAW_OBJECTS) {
         const uint32_t pm = c->prof_mask;
@@ -594,12 +599,14 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
                     front_add = launch_front(f, st, FRONT_BINNING | FRONT_TILE_ALLOC, false, l.front_sync_value);
                     front_launched = true;
                 }
+            } else if (pair_b) {
+                launch_binning_tile_alloc(f, st);
             } else {
                 launch_binning(f, st);
             }
             break;
         case VELLO_HIP_STAGE_TILE_ALLOC:
-            if (!fuse_all && !fuse_b) launch_tile_alloc(f, st);
+            if (!fuse_all && !fuse_b && !pair_b) launch_tile_alloc(f, st);
             break;
         case VELLO_HIP_STAGE_PATH_COUNT: launch_path_count(f, st); break;
         case VELLO_HIP_STAGE_BACKDROP: launch_backdrop(f, st); break;
@@ -854,6 +861,13 @@ int vello_hip_set_frames_in_flight(vello_hip_ctx *c, uint32_t n) {
             if ((r = alloc_lane_pools(c, c->lanes[i]))) return r;
             if (c->shared.resident && (r = alloc_lane_scene(c, c->lanes[i], c->shared))) return r;
         }
+    }
+    if ((c->n_active == 1u) != (n == 1u)) {
+        // fine's slicing threshold differs between one frame at a time and frames in flight (engine.h FINE_SLICE_MIN_FILLS*): the
+        // slice items a frame of the scene was seen to ask for say nothing about the other mode -- unknown again (the default
+        // capacity, and the next finished frame is read back)
+        c->shared.slice_demand = -1;
+        for (auto &l : c->lanes) l.own.slice_demand = -1;
     }
     c->n_active = n;  // shrinking keeps the extra lanes' buffers; only the rotation changes
     c->next_lane = 0;
