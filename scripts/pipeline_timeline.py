@@ -76,6 +76,23 @@ def main():
     for n in sorted(dur, key=lambda k: -sum(dur[k])):
         print(f"{n:28s} {len(dur[n]):8d} {sum(dur[n]) / len(dur[n]):8.1f} {sum(dur[n]) / max(n_frames, 1):9.1f} {beside[n] / max(own[n], 1):17.2f}")
     print(f"sum of kernel time per frame: {sum(sum(v) for v in dur.values()) / max(n_frames, 1):.0f} us")
+    # the gaps inside a queue: from the end of a kernel to the start of the next one of the same queue (round 6)
+    byq = defaultdict(list)
+    for s0, e0, n, q in win:
+        byq[q].append((s0, e0, n))
+    gaps = defaultdict(list)
+    for q, lst in byq.items():
+        lst.sort()
+        for (s0, e0, n0), (s1, e1, n1) in zip(lst[:-1], lst[1:]):
+            gaps[(n0, n1)].append((s1 - e0) / 1e3)
+    print(f"{'gap behind':28s} {'before':28s} {'n':>4s} {'mean us':>8s} {'median':>8s} {'us/frame':>9s}")
+    tot_gap = 0.0
+    for (n0, n1), v in sorted(gaps.items(), key=lambda kv: -sum(kv[1])):
+        v2 = sorted(v)
+        tot_gap += sum(v)
+        if len(v) >= 4:
+            print(f"{n0:28s} {n1:28s} {len(v):4d} {sum(v) / len(v):8.1f} {v2[len(v2) // 2]:8.1f} {sum(v) / max(n_frames, 1):9.1f}")
+    print(f"sum of the gaps per frame: {tot_gap / max(n_frames, 1):.0f} us")
 
 
 if __name__ == "__main__":

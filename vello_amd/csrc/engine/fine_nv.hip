@@ -1692,16 +1692,8 @@ __device__ __attribute__((noinline)) void blend_pass(BlendPassOut &out, uint32_t
 // BRUSHES = false is the specialisation for scenes whose draw tags are only COLOR / BEGIN_CLIP / END_CLIP (decided
 // on the host when the scene is uploaded): coarse can then never emit a gradient, image or blur command, and the
 // solid-colour interpreter does not pay their registers.
-// WAVES: the waves per SIMD the register allocation is made for.  4 = 128 VGPRs: four waves a SIMD are the whole register file,
-// and while k_fine fills the chip nothing of another frame runs beside it.  With frames in flight the solid-colour MSAA kernels are
-// built for 5 (96 VGPRs, 17 spilled; the LDS still admits 17 waves per CU): k_fine alone is 4 % slower (151 for 145 us on d2) and
-// the frames/s with four in flight +1.9 % (d2), +1.1 % (mmark-50k) -- the other frames' kernels run in the registers it leaves free
-// (profiles/r06_ab_fine_vgpr_cap.txt).  One frame at a time keeps 4.
-#ifndef VK_FINE_WAVES_IN_FLIGHT
-#define VK_FINE_WAVES_IN_FLIGHT 5
-#endif
-template <int AA, bool BRUSHES, int WAVES = 4>
-__global__ void __launch_bounds__(64, BRUSHES ? 3 : WAVES) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
+template <int AA, bool BRUSHES>
+__global__ void __launch_bounds__(64, BRUSHES ? 3 : 4) __attribute__((amdgpu_num_vgpr(BRUSHES ? 168 : 112))) k_fine(Config cfg, const Segment *__restrict__ segments, const uint32_t *__restrict__ ptcl,
                                              const uint32_t *__restrict__ info, uint32_t *blend_spill, uint8_t *__restrict__ output,
                                              uint32_t out_stride, const uint32_t *__restrict__ ramps, uint32_t n_ramps,
                                              const uint32_t *__restrict__ mask_lut, const uint32_t *__restrict__ atlas_texels,
@@ -2097,15 +2089,10 @@ static void launch_fine_aa(const Frame &f, hipStream_t s, const uint32_t *mask_l
     const uint32_t slice_blocks = AA != 0 && f.slice_min_fills != 0u ? f.slice_cap : 0u;
     dim3 grid(f.cfg.width_in_tiles * f.cfg.height_in_tiles + slice_blocks);
     uint32_t stride = (uint32_t)f.out_stride;
-    constexpr int WAVES_IN_FLIGHT = AA != 0 ? VK_FINE_WAVES_IN_FLIGHT : 4;  // (area AA: one form)
     if (f.brushes)
         hipLaunchKernelGGL((k_fine<AA, true>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
                            stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order, f.slice_items,
                            f.slice_counters, f.cov, slice_blocks, f.slice_fills);
-    else if (WAVES_IN_FLIGHT != 4 && !f.flatten_side_by_side)  // (frames in flight)
-            hipLaunchKernelGGL((k_fine<AA, false, WAVES_IN_FLIGHT>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
-                               stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order, f.slice_items,
-                               f.slice_counters, f.cov, slice_blocks, f.slice_fills);
     else
         hipLaunchKernelGGL((k_fine<AA, false>), grid, dim3(64), 0, s, f.cfg, f.segments, f.ptcl, f.info_bin_data, f.blend_spill, f.output,
                            stride, f.ramps, f.n_ramps, mask_lut, f.atlas, f.atlas_w, f.atlas_h, f.control->work_count, f.tile_order, f.slice_items,
