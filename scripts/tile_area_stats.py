@@ -38,3 +38,22 @@ print(f"  tiles with a crossing or a backdrop bump after path_count: {int(touche
 print(f"  (path, tile-row) pairs: {rows}, with a touched tile: {rows_touched} ({100 * rows_touched / max(rows, 1):.1f} %) -- mean rectangle "
       f"{w[w > 0].mean():.1f} x {h[h > 0].mean():.1f} tiles")
 print(f"  16-tile cache lines of the pool: {lines}, with a touched tile: {lines_touched} ({100 * lines_touched / max(lines, 1):.1f} %)")
+
+# Round 6: what a row flag "this row holds a backdrop bump" -- set by k_path_count's flush, read by k_backdrop --
+# would let the prefix pass skip, and what a sparse clean-up of the pool (instead of tile_alloc's dense zero fill) would still write
+bump_rows = 0
+for p in range(n_paths):
+    if w[p] == 0 or h[p] == 0:
+        continue
+    bd = tiles[base[p]:base[p] + w[p] * h[p], 0].reshape(h[p], w[p])
+    bump_rows += int((bd != 0).any(axis=1).sum())
+print(f"  (path, tile-row) pairs with a non-zero backdrop bump after path_count (the rows k_backdrop has work in): {bump_rows} ({100 * bump_rows / max(rows, 1):.1f} %)")
+o.run("backdrop", "backdrop")
+tiles2 = o.buffer("tiles", np.int32)[:b["tile"] * 2].reshape(-1, 2)
+nz = (tiles2[:, 0] != 0) | (tiles2[:, 1] != 0)
+pad2 = np.zeros(lines * 16, dtype=bool)
+pad2[:b["tile"]] = nz
+l64 = int(pad2.reshape(-1, 16)[: lines // 1].any(axis=1).sum())
+l128 = int(pad2[: (lines // 2) * 32].reshape(-1, 32).any(axis=1).sum())
+print(f"  after backdrop: non-zero tiles {int(nz.sum())} ({100 * nz.mean():.1f} %); 128-byte lines (16 tiles) holding one: {l64} ({100 * l64 / lines:.1f} %); "
+      f"256-byte pieces: {l128} ({100 * l128 / max(lines // 2, 1):.1f} %) -- what a sparse clean-up would still have to write")

@@ -242,7 +242,10 @@ static_assert(MS_BATCH_FILLS == sizeof(PixelLds::zero_at) / sizeof(PixelLds::zer
 static_assert(sizeof(PixelLds) <= sizeof(SegSetupLds), "PixelLds lives in SegSetupLds's storage");
 static_assert(sizeof(Segment) * 64u > offsetof(PixelLds, zero_at) && sizeof(Segment) * 64u <= offsetof(PixelLds, zero_at) + 4u * sizeof(PixelLds::zero_at[0]),
               "FineShared::seg ends inside rows 0-3 of PixelLds::zero_at: see the invariant at FineShared (seg is never used while a batch is staged)");
-constexpr uint32_t MS_ITEM_CAP = 512u;      // item records per batch (2 KB of LDS)
+#ifndef VK_FINE_ITEM_CAP
+#define VK_FINE_ITEM_CAP 512u
+#endif
+constexpr uint32_t MS_ITEM_CAP = VK_FINE_ITEM_CAP;      // item records per batch (2 KB of LDS)
 constexpr uint32_t REC_PIX_VALID = 1u << 24, REC_IS_DOWN = 1u << 25, REC_IS_BUMP = 1u << 26, REC_DELTA_OK = 1u << 27;
 
 struct alignas(16) FineBatch {
@@ -1508,7 +1511,9 @@ __device__ __forceinline__ void rare_command_body(RareState &st, uint32_t (*blen
     st.clip_depth = clip_depth;
     st.cmd_ix = cmd_ix;
 }
-template <bool BRUSHES>
+// (WAVES: a copy per form of the kernel -- an out-of-line function is compiled for the tightest register budget among its callers,
+// and the five-wave form's 96 VGPRs made the four-wave form's compositing pass spill: k_fine alone 145 -> 184 us when they shared it)
+template <bool BRUSHES, int WAVES>
 __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (*blend_stack)[4], uint32_t tag, uint32_t ptcl_size,
                                                        uint32_t blend_size,
                                                        const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info,
@@ -1538,7 +1543,7 @@ __device__ __attribute__((noinline)) void rare_command(RareState &st, uint32_t (
 struct BlendPassOut {
     vec4 rgba[4];
 };
-template <int AA, bool BRUSHES>
+template <int AA, bool BRUSHES, int WAVES>
 __device__ __attribute__((noinline)) void blend_pass(BlendPassOut &out, uint32_t tile_ix, uint32_t base_color_u, uint32_t ptcl_size, uint32_t blend_size,
                                                      const uint32_t *__restrict__ ptcl, const uint32_t *__restrict__ info, uint32_t *blend_spill,
                                                      const uint32_t *cov_tile, uint32_t *lds_chunk, uint32_t fill_room, uint32_t lane, float xy_x, float xy_y,
@@ -1674,7 +1679,7 @@ __device__ __attribute__((noinline)) void blend_pass(BlendPassOut &out, uint32_t
             }
             st.clip_depth = clip_depth;
             st.cmd_ix = cmd_ix;
-            rare_command<BRUSHES>(st, blend_stack, tag, ptcl_size, blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+            rare_command<BRUSHES, WAVES>(st, blend_stack, tag, ptcl_size, blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
                                   atlas_texels, atlas_w, atlas_h);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2017,7 +2022,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : WAVES) k_fine(Config cfg, co
                 rare_command_body<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps,
                                            n_ramps, atlas_texels, atlas_w, atlas_h);
             else
-                rare_command<BRUSHES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
+                rare_command<BRUSHES, WAVES>(st, blend_stack, tag, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, blend_offset, lane, xy_x, xy_y, ramps, n_ramps,
                                       atlas_texels, atlas_w, atlas_h);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -2059,7 +2064,7 @@ __global__ void __launch_bounds__(64, BRUSHES ? 3 : WAVES) k_fine(Config cfg, co
     // The tile's last slice has arrived: composite (out of line: the second interpreter must not cost the first its registers)
     {
         BlendPassOut bo;
-        blend_pass<AA, BRUSHES>(bo, tile_ix, cfg.base_color, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, cov + cov_base, sh_samples, fill_room, lane, xy_x, xy_y,
+        blend_pass<AA, BRUSHES, WAVES>(bo, tile_ix, cfg.base_color, cfg.ptcl_size, cfg.blend_size, ptcl, info, blend_spill, cov + cov_base, sh_samples, fill_room, lane, xy_x, xy_y,
                                 ramps, n_ramps, atlas_texels, atlas_w, atlas_h);
 #pragma unroll
         for (int i = 0; i < 4; i++) rgba[i] = bo.rgba[i];
