@@ -431,6 +431,16 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     else:
         iso_ms = stage_iso_ms
     ovl_ms = dom_ms / max(dom_n, 1)
+    # Round 6: several kernels have a form for ONE frame in flight and a form for several (k_fine: 4 waves per SIMD and long tiles
+    # sliced / 5 waves and unsliced; k_path_count: 48.7 / 24.6 KB of LDS) -- the in-flight forms are built to share the chip and are
+    # slower when they have it to themselves.  `frac` is the dominant kernel with the chip to itself in the form built for that
+    # (one frame in flight: what rocprofv3 shows for `bench.py --in-flight 1 --timed-only`, profiles/r0N_kernel_stats_serial_d2.csv);
+    # the in-flight form's isolated and overlapped durations are reported beside it.
+    form_iso_ms, form_stage_iso_ms = iso_ms, stage_iso_ms  # (the timed region's configuration, launched one at a time)
+    if lat_ms and dominant in lat_ms and lat_ms[dominant][1]:
+        stage_iso_ms = lat_ms[dominant][0] / max(lat_ms[dominant][1], 1)
+        iso_ms = (lat_k[dominant_kernel][0] / max(lat_k[dominant_kernel][1], 1)) if dominant in engine.KERNELS else stage_iso_ms
+    form_frac_ms = form_stage_iso_ms if dominant in engine.KERNELS else form_iso_ms
     #  algorithmic bytes exist per STAGE: when the dominant kernel is one of a stage's several, `achieved` / `frac`
     # are the stage's bytes over the stage's time (all its kernels), not over the one kernel's
     frac_ms = stage_iso_ms if dominant in engine.KERNELS else iso_ms
@@ -438,7 +448,7 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
     res = {
         "engine": engine, "frame": frame, "steps": steps, "elapsed": elapsed, "own_fps": own_fps, "bump": bump, "dominant": dominant, "dominant_kernel": dominant_kernel,
         "fine_slices": {"slice_work_items": slice_items, "coverage_scratch_bytes": cov_words * 4,
-                        "rule": "MSAA: a tile of >= 96 FILLs is cut into slices of 32 fills (coverage by one wave per slice, composited by the last to finish)"},
+                        "rule": "MSAA: a tile of >= 96 FILLs (one frame in flight; >= 192 with frames in flight: the timed region slices nothing on d2) is cut into slices of 32 fills (coverage by one wave per slice, composited by the last to finish)"},
         "exchange_ms": exchange_ms, "pcie_fps": pcie_fps, "pcie_pipelined_fps": pcie_pipelined_fps,
         "describe": wl.describe(engine),
         "frame_ms": {"median": pct(intervals, 0.5), "p10": pct(intervals, 0.1), "p90": pct(intervals, 0.9), "mean": (sum(intervals) / len(intervals)) if intervals else None,
@@ -460,7 +470,15 @@ def run_workload(wl, args, rank, local_rank, world, timed_headline):
             "frac": round(sb[dominant] / (frac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if frac_ms > 0 else None,
             "algorithmic_bytes_per_launch": int(sb[dominant]),
             "avg_launch_ms": round(iso_ms, 5),
-            "avg_launch_ms_how": "HIP events around the kernel, one frame at a time in the timed region's configuration: median of five batches' mean launch times",
+            "avg_launch_ms_how": ("HIP events around the kernel on the engine's stream, one frame at a time with ONE frame in flight configured (the form built for "
+                                  "having the chip to itself; rocprofv3 of `bench.py --in-flight 1 --timed-only` shows the same kernel): median of five batches' mean "
+                                  "launch times" if lat_ms else "HIP events around the kernel in the timed region"),
+            "in_flight_form": {
+                "what": "the form of the dominant kernel the timed region launches (frames in flight: k_fine for five waves per SIMD, long tiles not sliced), "
+                        "launched one frame at a time, and under the overlap of the timed region",
+                "avg_launch_ms_alone": round(form_iso_ms, 5),
+                "frac_alone": round(sb[dominant] / (form_frac_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if form_frac_ms > 0 else None,
+            },
             "avg_launch_ms_overlapped": round(ovl_ms, 5),
             "achieved_overlapped": round(sb[dominant] / (ovl_ms * 1e-3) / 1e9, 2) if ovl_ms > 0 else None,
             "frac_overlapped": round(sb[dominant] / (ovl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ovl_ms > 0 else None,

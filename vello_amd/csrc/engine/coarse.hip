@@ -40,10 +40,14 @@ namespace vk {
 namespace {
 
 constexpr uint32_t SUB_W = 8;         // a workgroup owns an 8x8-tile quadrant of a bin
-constexpr uint32_t NW = 8;            // waves per workgroup; wave w emits objects [64w, 64w + 64) of a batch
+#ifndef VK_COARSE_NW
+#define VK_COARSE_NW 8  // (sweep constant: 4 = half the batch, half the queue -- 46 KB of LDS instead of 86)
+#endif
+constexpr uint32_t NW = VK_COARSE_NW; // waves per workgroup; wave w emits objects [64w, 64w + 64) of a batch
 constexpr uint32_t WG = 64 * NW;
 constexpr uint32_t NB = 64 * NW;      // draw objects per batch
-constexpr uint32_t QCAP = 1024;       // queue slots: NB - 1 left over + WG new ones; power of two
+constexpr uint32_t QCAP = 2 * NB;     // queue slots: NB - 1 left over + WG new ones; power of two
+static_assert((QCAP & (QCAP - 1u)) == 0u && QCAP >= NB - 1u + WG, "the queue is a ring of a power of two that holds a batch's leftovers and a round's arrivals");
 constexpr uint32_t PART_CHUNK = 256;  // bin headers (partitions of 256 draw objects) merged at a time
 constexpr uint32_t NONE = 0xffffffffu;
 constexpr uint32_t EMIT_GROUP = 8;    // wave steps (64 pairs each) whose Tile loads are in flight together
