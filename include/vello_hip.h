@@ -229,7 +229,10 @@ int vello_hip_estimate_capacities(const uint8_t *scene, size_t scene_len, const 
  * VELLO_HIP_DEBUG_NO_FUSION launches every stage of a small scene as a kernel of its own (normally the workgroups of consecutive
  * stages up to tile_alloc share launches when the scene is small enough for launch boundaries to matter): same buffers. */
 enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP_DEBUG_SEQ_CLIP = 4, VELLO_HIP_DEBUG_FINE_SLICES = 8,
-       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64 };
+       VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64,
+       /* measurement seam: bits 24-27 = 1 + the last stage vello_hip_render_resident launches (0: all of them) -- what the stages
+        * up to k cost with frames in flight (scripts/experiments/r6_stage_marginal.py); the frames are incomplete */
+       VELLO_HIP_DEBUG_LAST_STAGE_SHIFT = 24 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -1060,7 +1060,9 @@ int vello_hip_render_resident(vello_hip_ctx *c, const vello_hip_render_params *p
     Frame f;
     r = prepare_frame(c, l, params, out_device, out_stride, f, false);
     if (r) return r;
-    return run_stage_range(c, l, f, 0, VELLO_HIP_STAGE_FINE);
+    int last = VELLO_HIP_STAGE_FINE;
+    if (const uint32_t ls = (c->debug_flags >> VELLO_HIP_DEBUG_LAST_STAGE_SHIFT) & 15u) last = (int)ls - 1 < last ? (int)ls - 1 : last;  // (measurement seam)
+    return run_stage_range(c, l, f, 0, last);
 }
 
 int vello_hip_run_stages(vello_hip_ctx *c, const vello_hip_render_params *params, int first, int last) {

@@ -197,6 +197,10 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 #ifndef VK_PC_GRID_IN_FLIGHT
 #define VK_PC_GRID_IN_FLIGHT 1024u
 #endif
+#ifndef VK_PC_FLUSH_GROUP
+#define VK_PC_FLUSH_GROUP 4
+#endif
+constexpr uint32_t PC_FLUSH_GROUP = VK_PC_FLUSH_GROUP;  // turns of the flush loop whose returning adds are in flight together
 constexpr uint32_t PC_PROBES = 3u;
 constexpr uint32_t PC_EMPTY = 0xffffffffu, PC_NONE = 0xffffffffu;
 constexpr uint32_t PC_DONE = 0x80000000u;   // stash word: bits 0-15 are the slot index already (else: the cursor's word index)
@@ -496,14 +500,33 @@ __global__ void __launch_bounds__(256) k_path_count(Config cfg, Bump *bump, cons
             if (sh.keys[k] != PC_EMPTY) sh.occupied[atomicAdd(&sh.n_occ, 1u)] = (uint16_t)k;
         __syncthreads();
         const uint32_t n_occ = sh.n_occ;
-        for (uint32_t k = tid; k < n_occ * 16u; k += 256u) {
-            const uint32_t e = sh.occupied[k >> 4], t = k & 15u;
-            const uint32_t word = sh.cnt[e * 16u + t];
-            const uint32_t n = word & 0xffffu;
-            const int32_t d = (int32_t)word >> 16;
-            const uint32_t ix = sh.keys[e] * 16u + t;
-            if (n != 0u) sh.cnt[e * 16u + t] = atomicAdd(&tile[ix].segment_count_or_ix, n);
-            if (d != 0) atomicAdd(&tile[ix + 1u].backdrop, d);  // (inside the pool: checked when the bump was added)
+        // PC_FLUSH_GROUP turns of the loop at a time: their returning adds are all requested before the first answer is waited
+        // for.  (Round 6: written a turn at a time the loop was add, s_waitcnt vmcnt(0), ds_write -- a chunk's 200 occupied entries
+        // are 12.5 turns of 256 lanes, 12.5 memory round trips in a row: 7 of a chunk's 20 us, profiles/r04_pc_timeline_agg_v5.txt.)
+        for (uint32_t k0 = tid; k0 < n_occ * 16u; k0 += 256u * PC_FLUSH_GROUP) {
+            uint32_t at[PC_FLUSH_GROUP], ix[PC_FLUSH_GROUP], word[PC_FLUSH_GROUP], old[PC_FLUSH_GROUP];
+#pragma unroll
+            for (uint32_t g = 0; g < PC_FLUSH_GROUP; g++) {
+                const uint32_t k = k0 + g * 256u;
+                const bool in = k < n_occ * 16u;
+                const uint32_t e = in ? sh.occupied[k >> 4] : 0u, t = k & 15u;
+                at[g] = e * 16u + t;
+                word[g] = in ? sh.cnt[at[g]] : 0u;
+                ix[g] = sh.keys[e] * 16u + t;
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < PC_FLUSH_GROUP; g++) {
+                old[g] = 0u;
+                if ((word[g] & 0xffffu) != 0u) old[g] = atomicAdd(&tile[ix[g]].segment_count_or_ix, word[g] & 0xffffu);
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < PC_FLUSH_GROUP; g++) {
+                const int32_t d = (int32_t)word[g] >> 16;
+                if (d != 0) atomicAdd(&tile[ix[g] + 1u].backdrop, d);  // (inside the pool: checked when the bump was added)
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < PC_FLUSH_GROUP; g++)
+                if ((word[g] & 0xffffu) != 0u) sh.cnt[at[g]] = old[g];
         }
         __syncthreads();
 #ifdef VELLO_PC_TIMELINE
