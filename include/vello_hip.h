@@ -232,7 +232,10 @@ enum { VELLO_HIP_DEBUG_NO_CULL = 1, VELLO_HIP_DEBUG_STROKE_KERNEL = 2, VELLO_HIP
        VELLO_HIP_DEBUG_FLATTEN_COOP = 16, VELLO_HIP_DEBUG_FLATTEN_ALONE = 32, VELLO_HIP_DEBUG_NO_FUSION = 64,
        /* measurement seam: bits 24-27 = 1 + the last stage vello_hip_render_resident launches (0: all of them) -- what the stages
         * up to k cost with frames in flight (scripts/experiments/r6_stage_marginal.py); the frames are incomplete */
-       VELLO_HIP_DEBUG_LAST_STAGE_SHIFT = 24 };
+       VELLO_HIP_DEBUG_LAST_STAGE_SHIFT = 24,
+       /* experiment: bit (8 + stage) makes that stage run for one frame at a time when frames are in flight (its launches wait for the
+        * same stage of the frame enqueued before) -- scripts/experiments/r6_exclusive_stages.py */
+       VELLO_HIP_DEBUG_EXCLUSIVE_SHIFT = 8 };
 int vello_hip_set_debug_flags(vello_hip_ctx *ctx, uint32_t flags);
 
 /* Number of frames the context keeps in flight (default 1, max 8).  wgpu queues recordings without waiting

@@ -81,6 +81,22 @@ def main():
     fmax = np.zeros(fn.size, dtype=np.int64)
     np.maximum.at(fmax, uk // 256, mult)
     print("fills by the largest number of records on one pixel: " + " ".join(f"{i}:{100 * (fmax == i).mean():.1f}%" for i in range(0, 6)) + f" >=6:{100 * (fmax >= 6).mean():.1f}%")
+    # greedy pairs of consecutive fills of a tile's list: both <= 32 records, no pixel of one touched by the other -- the pairs that
+    # could share ONE pass over the pixel-indexed sample counters (a half-wave of record lanes each)
+    ft = np.array(fills_tile)
+    nrec = np.bincount(rfid[ok], minlength=fn.size)
+    pix_sets = np.split(uk % 256, np.cumsum(np.bincount(uk // 256, minlength=fn.size))[:-1])
+    paired = 0; candidates = 0; collide = 0
+    i = 0
+    while i + 1 < fn.size:
+        if ft[i] == ft[i + 1] and 0 < nrec[i] <= 32 and 0 < nrec[i + 1] <= 32:
+            candidates += 1
+            if np.intersect1d(pix_sets[i], pix_sets[i + 1], assume_unique=True).size == 0:
+                paired += 2; i += 2; continue
+            collide += 1
+        i += 1
+    print(f"greedy pairs of consecutive fills (both <= 32 records): {100 * paired / fn.size:.1f} % of the fills end up in a pair with disjoint pixels; "
+          f"{collide} of {candidates} candidate pairs share a pixel")
     npx = np.bincount(uk // 256, minlength=fn.size)
     print(f"touched pixels per fill: mean {npx.mean():.1f}, <= 16 / 32 / 64: {100 * (npx <= 16).mean():.1f} / {100 * (npx <= 32).mean():.1f} / {100 * (npx <= 64).mean():.1f} %")
 

@@ -57,12 +57,16 @@ def main():
     rows = [r for r in rows if "vgpr_count" in r]
     names = demangle([r["name"] for r in rows])
     stamp = ""
-    try:
-        stamp = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-        if subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "vello_amd/csrc", "include"]).returncode != 0:
-            stamp += "-dirty"
-    except Exception:
-        pass
+    # (the GPU box holds a snapshot without .git: scripts/grun.sh leaves the commit in .commit_stamp)
+    if os.path.isdir(os.path.join(ROOT, ".git")):
+        try:
+            stamp = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            if subprocess.run(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "vello_amd/csrc", "include"], capture_output=True).returncode != 0:
+                stamp += "-dirty"
+        except Exception:
+            pass
+    elif os.path.exists(os.path.join(ROOT, ".commit_stamp")):
+        stamp = open(os.path.join(ROOT, ".commit_stamp")).read().strip()
     print(f"# {os.path.relpath(lib, ROOT)} built from {stamp}: every kernel's resources from the code objects' metadata (scripts/kernel_resources.py)")
     print(f"# waves/SIMD = min(8, floor(512 / VGPRs rounded up to 8)); LDS workgroups/CU = floor(160 KB / LDS)")
     print(f"{'kernel':48s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'v-spill':>7s} {'s-spill':>7s} {'scratch B':>9s} {'LDS B':>7s} {'waves/SIMD':>10s} {'LDS wg/CU':>9s}")

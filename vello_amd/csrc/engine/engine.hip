@@ -114,6 +114,8 @@ struct vello_hip_ctx {
     // and every frame enqueued after it waits for `atlas_ready`.
     hipStream_t upload_stream = nullptr;
     hipEvent_t atlas_ready = nullptr, lane_mark = nullptr;
+    // experiment (round 6, VELLO_HIP_DEBUG_EXCLUSIVE_SHIFT): per stage, an event behind the stage's launches of the frame enqueued last
+    hipEvent_t stage_turn[VELLO_HIP_STAGE_COUNT] = {};
     uint64_t atlas_epoch = 0;  // uploads enqueued so far
     std::vector<Staging> staging;
     uint32_t debug_flags = 0;  // VELLO_HIP_DEBUG_*
@@ -564,6 +566,13 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
             if (s == VELLO_HIP_STAGE_FLATTEN) ev.mid[1] = get_event(c);
             HIP_TRY(c, hipEventRecord(ev.a, st));
         }
+        // experiment: a stage named in the debug flags runs for ONE frame at a time -- its launches wait for the same stage of the
+        // frame enqueued before (on another lane) to be done
+        const bool exclusive = c->n_active > 1u && ((c->debug_flags >> (VELLO_HIP_DEBUG_EXCLUSIVE_SHIFT + s)) & 1u) != 0u;
+        if (exclusive) {
+            if (!c->stage_turn[s]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_turn[s], hipEventDisableTiming));
+            else HIP_TRY(c, hipStreamWaitEvent(st, c->stage_turn[s], 0));
+        }
         switch (s) {
         case VELLO_HIP_STAGE_PATHTAG_SCAN:
             // render.rs:313 clears `bump`; the same memset resets both look-back states and tickets
@@ -620,6 +629,7 @@ int run_stage_range(vello_hip_ctx *c, Lane &l, const Frame &f_in, int first, int
         } else {
             HIP_TRY(c, hipGetLastError());
         }
+        if (exclusive) HIP_TRY(c, hipEventRecord(c->stage_turn[s], st));
         if (prof) {
             HIP_TRY(c, hipEventRecord(ev.b, st));
             l.events.push_back(ev);
@@ -837,6 +847,8 @@ void vello_hip_destroy(vello_hip_ctx *c) {
         }
         (void)hipEventDestroy(c->atlas_ready);
         (void)hipEventDestroy(c->lane_mark);
+        for (auto &e : c->stage_turn)
+            if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c->upload_stream);
     }
     if (c->frame_done) (void)hipEventDestroy(c->frame_done);
