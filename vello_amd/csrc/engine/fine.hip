@@ -151,6 +151,14 @@ struct alignas(16) PixelLds {
     float area[256];
     uint32_t zero_at[12][16];
 };
+#ifdef VELLO_SIMT_EMU
+#define FINE_WAVE_ANY(c) (__ballot(c) != 0ull)
+#else
+#define FINE_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0ull)
+#endif
+#ifndef VK_FINE_REGS
+#define VK_FINE_REGS 0  // 1: a simple fill's touched pixels from their records in registers where no pixel holds three (prototype)
+#endif
 struct FineShared {
     // INVARIANT: `seg` is written only by fill_path_area / fill_path_ms, and those run only while NO batch is staged
     // (k_fine's loop: batch_pos == batch_n, and ms_build_batch returned 0 for the fill).  px.zero_at is written once per batch and
@@ -981,6 +989,97 @@ __device__ __forceinline__ void ms_fill_simple(FineShared &sh, FineBatch &bt, ui
     constexpr uint32_t SWPP = MSAA16 ? 4u : 2u;
     // (`rec`: the fill's record of this lane, zero beyond its range -- fetched a fill ahead by the caller's run loop, round 6)
     wave_lds_sync();
+#if VK_FINE_REGS
+    // ---- Prototype (round 6): the touched pixels' coverage from their RECORDS, in registers ----
+    // A record adds +-(bit - bump) to each sample counter of its pixel: sigma * M per sample with M = mask (no bump) or ~mask
+    // (bump) and sigma = -1 iff downward XOR bump.  A pixel with one or two records therefore holds counters 0x80 + C with
+    // C in {-2 .. 2} known from the two records alone, and its coverage -- the samples whose counter differs from expected_zero --
+    // is 16 - popcount(C == expected_zero - 0x80), a handful of bit operations on the 16-bit planes: no counter is touched.  The
+    // lanes of a pixel find each other through LDS (a byte per pixel: who holds a record of it; a word per holder: who else).
+    // A fill in which some pixel holds THREE or more records (round joins, 46 % of the road map's fills) takes the counters as
+    // before -- decided per wave.
+    {
+        constexpr uint32_t FULL = MSAA16 ? 0xffffu : 0xffu;
+        constexpr uint32_t NS = MSAA16 ? 16u : 8u;
+        const bool has = rec != 0u;
+        const uint32_t pix = has ? rec & 0xffu : lane * 4u;
+        const bool down = (rec & REC_IS_DOWN) != 0u;
+        {   // the winding word of the pixel to the right, as below
+            const uint32_t delta_pix = pix + 1u;
+            uint32_t d = (down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
+            if (!(rec & REC_DELTA_OK)) d = 0u;
+            atomicAdd(&sh.winding[(delta_pix >> 2) & 63u], d);
+        }
+        // (no LDS of its own -- 256 bytes more would cost the kernel its seventeenth wave per CU: `sh.count`, idle while a batch is
+        // staged, is the table of a byte per pixel, the lane that holds a record of it; `bt.seg_slot`, ms_build_batch's scratch, the
+        // word per holder: the lane with the pixel's second record, ~0 for none)
+        uint8_t *holder = reinterpret_cast<uint8_t *>(sh.count);
+        uint32_t *second = bt.seg_slot;
+        second[lane] = 0xffffffffu;
+        if (has) holder[pix] = (uint8_t)lane;
+        wave_lds_sync();
+        const uint32_t o = holder[pix];
+        const bool loser = has && o != lane;
+        if (loser) second[o] = lane;
+        wave_lds_sync();
+        const uint32_t chk = second[o & 63u];
+        const bool crowded = FINE_WAVE_ANY(loser && chk != lane);  // some pixel holds three records or more
+        if (!crowded) {
+            // x winding prefix and the 0 / 1 coverage of the untouched pixels: as below
+            const uint32_t lx = lane & 3u, ly = lane >> 2;
+            uint32_t packed_w = sh.winding[lane];
+            sh.winding[lane] = 0x80808080u;
+            packed_w += (packed_w - 0x808080u) << 8;
+            packed_w += (packed_w - 0x8080u) << 16;
+            const uint32_t prefix_x = bcast_byte3(packed_w) - 0x80808080u;
+            packed_w += row_shr0<1>(lx <= 2u ? prefix_x : 0u);
+            packed_w += row_shr0<2>(lx <= 1u ? prefix_x : 0u);
+            packed_w += row_shr0<3>(lx == 0u ? prefix_x : 0u);
+            const bool zero_possible = (uint32_t)backdrop + 128u < 256u;
+            const uint32_t differs = packed_w ^ sh.px.zero_at[slot][ly];
+            uint32_t nz = (((differs & 0x7f7f7f7fu) + 0x7f7f7f7fu) | differs) & 0x80808080u;
+            if (!zero_possible) nz = 0x80808080u;
+            const uint32_t ones = nz >> 7;
+#pragma unroll
+            for (uint32_t i = 0; i < PIXELS_PER_THREAD; i++) area[i] = (float)((ones >> (i * 8u)) & 0xffu);
+            sh.px.pw[lane] = packed_w;
+            *reinterpret_cast<float4 *>(&sh.px.area[lane * 4u]) = make_float4(area[0], area[1], area[2], area[3]);
+            // the pixel's other record (its holder's lane number was left with this lane, if there is one)
+            const uint32_t partner = second[lane];
+            uint32_t rec2 = wave_shfl(rec, partner & 63u);
+            if (partner == 0xffffffffu) rec2 = 0u;
+            wave_lds_sync();
+            pf.mark(FP_FILL_PREFIX);
+            const uint32_t xb = sh.px.pw[pix >> 2] >> ((pix & 3u) << 3);
+            const uint32_t eb = (xb - sh.px.zero_at[slot][pix >> 4] + 0x80u + (uint32_t)backdrop) & 0xffu;
+            const uint32_t e = eb - (uint32_t)backdrop;
+            const uint32_t b1 = (uint32_t)((int32_t)(rec << 5) >> 31), b2 = (uint32_t)((int32_t)(rec2 << 5) >> 31);   // REC_IS_BUMP: bit 26
+            const uint32_t m1 = ((rec >> 8) ^ b1) & FULL, m2 = ((rec2 >> 8) ^ b2) & FULL;
+            const bool neg1 = (((rec >> 25) ^ (rec >> 26)) & 1u) != 0u, neg2 = (((rec2 >> 25) ^ (rec2 >> 26)) & 1u) != 0u;
+            const bool same = neg1 == neg2;
+            const int32_t dz = (int32_t)e - 0x80;          // the counter value that means "winding number zero", relative to clear
+            const int32_t t = neg1 ? -dz : dz;             // ... in units of the first record's sign
+            const uint32_t x = m1 ^ m2, y = m1 & m2, u = m1 | m2;
+            uint32_t eq = 0u;                              // the samples whose counter equals expected_zero
+            if (t == 0) eq = same ? ~u : ~x;
+            if (t == 1) eq = same ? x : x & m1;
+            if (t == 2) eq = same ? y : 0u;
+            if (t == -1) eq = same ? 0u : x & m2;
+            const float cov = (float)(NS - (uint32_t)__popc(eq & FULL)) * (1.0f / (float)NS);
+            // (e >= 256: coverage 1, as the pixel's lane has it)
+            if (has && !loser && e < 256u) sh.px.area[pix] = cov;
+            wave_lds_sync();
+            pf.mark(FP_FILL_SPARSE);
+            const float4 a = *reinterpret_cast<const float4 *>(&sh.px.area[lane * 4u]);
+            area[0] = a.x; area[1] = a.y; area[2] = a.z; area[3] = a.w;
+            pf.mark(FP_FILL_RESTORE);
+            return;
+        }
+    }
+    constexpr bool DELTA_DONE = true;
+#else
+    constexpr bool DELTA_DONE = false;
+#endif
     // ---- the records into the counters (ms_apply, non-zero rule, without its tests) ----
     // (a lane without a record works on a pixel of its own, 4 x lane: thirty idle lanes adding their zeros to ONE word are thirty
     // LDS atomics in a row -- k_fine 150 -> 226 us on the road map when they all took pixel 0, profiles/r05_ab_fine_simple.txt)
@@ -990,7 +1089,7 @@ __device__ __forceinline__ void ms_fill_simple(FineShared &sh, FineBatch &bt, ui
         const uint32_t delta_pix = pix_ix + 1u;
         uint32_t d = (is_down ? 1u : 0xffffffffu) << ((delta_pix & 3u) << 3);
         if (!(rec & REC_DELTA_OK)) d = 0u;
-        atomicAdd(&sh.winding[(delta_pix >> 2) & 63u], d);  // (& 63: pixel 255 of a record without a delta)
+        if (!DELTA_DONE) atomicAdd(&sh.winding[(delta_pix >> 2) & 63u], d);  // (& 63: pixel 255 of a record without a delta)
         const uint32_t bump = (rec & REC_IS_BUMP) != 0u ? 0x1010101u : 0u;
         uint32_t *word = &sh_samples[(pix_ix & 3u) * SWPP * 64u + (pix_ix >> 2)];
 #pragma unroll
