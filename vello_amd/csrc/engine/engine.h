@@ -119,7 +119,7 @@ constexpr uint32_t FLATTEN_ARC_SHARDS = 64;
 #define VK_STROKES_GRID_SIDE_BY_SIDE 4096u
 #endif
 #ifndef VK_STROKES_GRID_OWN_LAUNCH
-#define VK_STROKES_GRID_OWN_LAUNCH 512u  // (scripts/emu_variant_check.sh sets both to 2: several rounds per workgroup on the emulator's small scenes)
+#define VK_STROKES_GRID_OWN_LAUNCH 384u  // (scripts/emu_variant_check.sh sets both to 2: several rounds per workgroup on the emulator's small scenes)
 #endif
 inline uint32_t flatten_strokes_grid(uint32_t n_seg_max, bool side_by_side) {
     const uint32_t cap = side_by_side ? VK_STROKES_GRID_SIDE_BY_SIDE : VK_STROKES_GRID_OWN_LAUNCH;

@@ -1759,7 +1759,11 @@ void launch_flatten(const Frame &f, hipStream_t s, hipEvent_t *mid, bool with_dr
     // is padded to 4096 tags)
     const uint32_t n_seg_max = flatten_n_seg_max(f);
     uint32_t grid_heavy = (n_seg_max + 3u) / 4u;
-    if (grid_heavy > 2048u) grid_heavy = 2048u;
+#ifndef VK_FH_GRID_IN_FLIGHT
+#define VK_FH_GRID_IN_FLIGHT 2048u  // (sweep constant: the heavy workgroups' cap with frames in flight)
+#endif
+    const uint32_t heavy_cap = f.flatten_side_by_side ? 2048u : VK_FH_GRID_IN_FLIGHT;
+    if (grid_heavy > heavy_cap) grid_heavy = heavy_cap;
     if (grid_heavy < 4u) grid_heavy = 4u;
     // (stroke workgroups leave at once when the scene has too few stroked lines for workgroups of their own; they are not
     // launched at all once a finished frame of the scene has shown that)

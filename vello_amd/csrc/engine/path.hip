@@ -195,7 +195,7 @@ __device__ __forceinline__ LineWalk setup_line_walk(const LineSoup &line, GetPat
 #define VK_PC_LPT_IN_FLIGHT 2
 #endif
 #ifndef VK_PC_GRID_IN_FLIGHT
-#define VK_PC_GRID_IN_FLIGHT 1024u
+#define VK_PC_GRID_IN_FLIGHT 768u
 #endif
 #ifndef VK_PC_FLUSH_GROUP
 #define VK_PC_FLUSH_GROUP 4
@@ -819,12 +819,19 @@ void launch_backdrop(const Frame &f, hipStream_t s) {
     if (f.cfg.layout.n_paths == 0) return;
     // a workgroup per four paths (its waves share their row blocks), workgroups striding over the groups
     uint32_t n_wg = (f.cfg.layout.n_paths + 3u) / 4u;
-    if (n_wg > 8192u) n_wg = 8192u;
+#ifndef VK_BD_GRID_IN_FLIGHT
+#define VK_BD_GRID_IN_FLIGHT 8192u  // (sweep constant: the grid's cap with frames in flight)
+#endif
+    const uint32_t cap = f.flatten_side_by_side ? 8192u : VK_BD_GRID_IN_FLIGHT;
+    if (n_wg > cap) n_wg = cap;
     hipLaunchKernelGGL(k_backdrop, dim3(n_wg), dim3(256), 0, s, f.cfg, f.bump(), f.paths, f.tiles);
 }
 
 void launch_path_tiling(const Frame &f, hipStream_t s) {
-    uint32_t grid = clamp_grid(f.cfg.seg_counts_size, 256u, 2048u);
+#ifndef VK_PT_GRID_IN_FLIGHT
+#define VK_PT_GRID_IN_FLIGHT 2048u  // (sweep constant: the grid's cap with frames in flight)
+#endif
+    uint32_t grid = clamp_grid(f.cfg.seg_counts_size, 256u, f.flatten_side_by_side ? 2048u : VK_PT_GRID_IN_FLIGHT);
     hipLaunchKernelGGL(k_path_tiling, dim3(grid), dim3(256), 0, s, f.cfg, f.bump(), f.seg_counts, f.lines, f.paths, f.tiles,
                        f.segments, f.ptcl);
 }
