@@ -1336,18 +1336,20 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
             const bool last_round = base + n_blocks * 256u >= n_lines_q;
             const bool do_flush = last_round || sh.count + FLATTEN_STROKE_ROUND_LINES > CAP;
             const uint32_t n_lds = do_flush ? minu(sh.count, sh.lds_end) : 0u;
+            // (the paths' boxes between the reservations' request and their answer: the box atomics need neither -- round 6)
+            uint32_t got = 0u;
             if (tid < 2u) {
                 uint32_t *const counter = tid == 0u ? &control->arc_count[shard] : &bump->lines;
                 const uint32_t n = tid == 0u ? n_arcs : n_lds;
-                const uint32_t got = n ? atomicAdd(counter, n) : 0u;
-                if (tid == 0u) arcs.base = got;
-                else sh.base = got;
+                got = n ? atomicAdd(counter, n) : 0u;
             }
+            wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
+            if (tid == 0u) arcs.base = got;
+            if (tid == 1u) sh.base = got;
             __syncthreads();
             // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
             if (tid < n_arcs && arcs.base + tid < arc_shard_cap) reinterpret_cast<ArcItem *>(arc_items)[shard * arc_shard_cap + arcs.base + tid] = arcs.item[tid];
             if (do_flush) copy_staged_lines(sh, lines, cfg.lines_size, sh.base, n_lds, tid);
-            wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
             __syncthreads();
             if (tid == 0u) {
                 arcs.count = 0u;
