@@ -988,6 +988,9 @@ __device__ uint32_t flatten_tag_coop(Emitter &em, EulerCoopLds &cl, bool has_tag
 // min/max commute with the monotone floor/ceil, so the resulting integer bbox is identical.
 __device__ __forceinline__ void wave_bbox_update(PathBbox *path_bboxes, uint32_t n_paths, uint32_t key, float x0, float y0, float x1,
                                                  float y1, int lane) {
+    // (a wave without a single extent -- the light kernel's waves of stroked tags, which it only queues -- has nothing to merge and
+    // nothing to send: thirty shuffles saved)
+    if (!FL_WAVE_ANY(key < n_paths && (x1 > x0 || y1 > y0))) return;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t ok_key = __shfl_up(key, d);
