@@ -629,7 +629,14 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
             const uint32_t last_tile = cfg.tiles_size - 1u;
             auto request = [&](uint32_t base) {
 #pragma unroll
+#ifdef VK_BD_REQUEST_BEYOND_BLOCK  // (round 4's form: the requests run on into the next path's tiles)
                 for (uint32_t k = 0; k < G; k++) next[k] = tiles[minu(first + base + k * 64u + lane, last_tile)].backdrop;
+#else
+                // (round 6: nothing is requested beyond the block's last tile -- the lanes past it load that tile again.  Round 4 kept the
+                // requests running into the next path's tiles for 3 us one frame at a time; now the clamped form is 1.2 us faster alone
+                // and +0.4 % with four frames in flight, profiles/r06_ab_backdrop_clamp.txt: 110 MB fetched for 80 MB of tiles before)
+                for (uint32_t k = 0; k < G; k++) next[k] = tiles[minu(minu(first + base + k * 64u + lane, first + n - 1u), last_tile)].backdrop;
+#endif
             };
             // one step: 64 tiles from tile i0 of the block on, their backdrops in `loaded`
             auto step = [&](uint32_t i0, int32_t loaded) {
@@ -658,8 +665,7 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
                 int32_t cur[G];
 #pragma unroll
                 for (uint32_t k = 0; k < G; k++) cur[k] = next[k];
-                // (beyond the block: clamped loads nobody reads -- but not useless: what lies behind a path's tiles are the next path's,
-                // and a small block without this request was 3 us slower over the road map, profiles/r04_ab_s17_backdrop.txt)
+                // (beyond the block: loads of the block's last tile that nobody reads, see `request`)
                 request(base + 64u * G);
 #pragma unroll
                 for (uint32_t k = 0; k < G; k++) {
