@@ -318,6 +318,20 @@ __device__ __forceinline__ TagMonoid reduce_tag_f(uint32_t tag_word) {
 }
 
 // flatten.wgsl:684-701
+// (the two loads of compute_tag_monoid apart from its arithmetic: the stroke workgroups request a round's tag words and monoids while the
+// round before it is still being flattened)
+__device__ __forceinline__ PathTagData tag_monoid_of(uint32_t tag_word, const TagMonoid &pre, uint32_t ix) {
+    uint32_t shift = (ix & 3u) * 8u;
+    TagMonoid tm = reduce_tag_f(tag_word & ((1u << shift) - 1u));
+    PathTagData r;
+    r.tag_byte = (tag_word >> shift) & 0xffu;
+    r.monoid.trans_ix = pre.trans_ix + tm.trans_ix - 1u;
+    r.monoid.pathseg_ix = pre.pathseg_ix + tm.pathseg_ix;
+    r.monoid.pathseg_offset = pre.pathseg_offset + tm.pathseg_offset;
+    r.monoid.style_ix = pre.style_ix + tm.style_ix - STYLE_SIZE_IN_WORDS;
+    r.monoid.path_ix = pre.path_ix + tm.path_ix;
+    return r;
+}
 __device__ PathTagData compute_tag_monoid(const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids, uint32_t ix) {
     uint32_t tag_word = scene[cfg.layout.path_tag_base + (ix >> 2)];
     uint32_t shift = (ix & 3u) * 8u;
@@ -1188,10 +1202,11 @@ __device__ __forceinline__ bool stroke_arc_one_line(Emitter &em, uint32_t path_i
 
 // One stroked LINETO (flatten_tag's stroke branch with flatten_euler reduced to its straight-segment shortcut).  Returns
 // false when the segment is not straight (the heavy kernel takes it).  Arcs that need the exact path are pushed to `q`.
+// tag_word / pre: the tag word ix >> 2 and its monoid, loaded by the caller (a round ahead).
 __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg, const uint32_t *scene, const TagMonoid *tag_monoids,
-                                     uint32_t ix, uint32_t &path_ix_out) {
+                                     uint32_t ix, uint32_t tag_word, const TagMonoid &pre, uint32_t &path_ix_out) {
     using namespace inl;  // (tangents, joins and caps without arcs: no transcendentals either way)
-    PathTagData tag = compute_tag_monoid(cfg, scene, tag_monoids, ix);
+    PathTagData tag = tag_monoid_of(tag_word, pre, ix);
     const uint32_t path_ix = tag.monoid.path_ix;
     path_ix_out = path_ix;
     em.bx0 = 1e31f; em.by0 = 1e31f; em.bx1 = -1e31f; em.by1 = -1e31f;
@@ -1206,8 +1221,8 @@ __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg
                                 length(v2(transform.m0 - transform.m3, transform.m1 + transform.m2)));
     // (false for a degenerate segment too: its chord is shorter than the test's lower bound)
     if (!cubic_is_straight(pts.p0, pts.p1, pts.p2, pts.p3, scale, offset)) return false;
-    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822
-    PathTagData ntag = compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
+    // read_neighboring_segment(ix + 1), flatten.wgsl:810-822 (three times out of four in the word at hand)
+    PathTagData ntag = ((ix + 1u) >> 2) == (ix >> 2) ? tag_monoid_of(tag_word, pre, ix + 1u) : compute_tag_monoid(cfg, scene, tag_monoids, ix + 1u);
     CubicPoints npts = read_path_segment(pd, ntag, true);
     bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
     bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
@@ -1289,6 +1304,15 @@ constexpr size_t FLATTEN_MAIN_LDS = FLATTEN_ARCS_AT + (sizeof(ArcQueue) > 4u * s
 static_assert(FLATTEN_MAIN_LDS <= 80u * 1024u && sizeof(FlattenShared<FLATTEN_LDS_LINES>) + 4u * sizeof(EulerCoopLds) <= 80u * 1024u, "two heavy workgroups per CU");
 
 
+#ifdef VELLO_STROKE_TIMELINE
+// measurement build (scripts/stroke_timeline.py): wall-clock stamps (100 MHz) of a stroke workgroup's rounds, thread 0's view
+constexpr uint32_t STL_ROUNDS = 16384u;
+__device__ uint32_t g_stroke_tl[STL_ROUNDS][8];
+__device__ uint32_t g_stroke_tl_n;
+#define STL_STAMP(k) do { if (tid == 0u) stl[k] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define STL_STAMP(k) do { } while (0)
+#endif
 template <uint32_t CAP>
 __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueue &arcs, uint32_t block, uint32_t n_blocks, const Config &cfg,
                                  uint32_t n_tags, const uint32_t *__restrict__ scene, const TagMonoid *__restrict__ tag_monoids,
@@ -1306,8 +1330,26 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
     __syncthreads();
     Bump *bump = &control->bump;
     const uint32_t lane = tid & 63u;
+    // A round is a chain of dependent loads -- list entry, tag word + monoid, points / style / transform, the neighbour's -- and with
+    // frames in flight a workgroup walks 7 of them on a road map (profiles/r06_stroke_timeline_d2.txt: the line is 4.4 of a round's
+    // 7.1 us): the list entries are requested TWO rounds ahead, the tag words and monoids ONE, from clamped addresses (a load under a
+    // branch would wait for everything in flight: DESIGN.md 3.1), so a round starts with its data's addresses in registers.
+    const uint32_t stride = n_blocks * 256u, last = n_lines_q - 1u;
+    const uint32_t *const list = heavy_list + 2u * (size_t)n_tags;
+    uint32_t tag_ix_cur = list[minu(block * 256u + tid, last)];
+    uint32_t tag_ix_next = list[minu(block * 256u + tid + stride, last)];
+    uint32_t word_cur = scene[cfg.layout.path_tag_base + (tag_ix_cur >> 2)];
+    TagMonoid pre_cur = tag_monoids[tag_ix_cur >> 2];
 #pragma unroll 1
-    for (uint32_t base = block * 256u; base < n_lines_q; base += n_blocks * 256u) {
+    for (uint32_t base = block * 256u; base < n_lines_q; base += stride) {
+        // (what the rounds after this one will want; beyond the list: its last entry again)
+        const uint32_t tag_ix_after = list[minu(base + tid + 2u * stride, last)];
+        const uint32_t word_next = scene[cfg.layout.path_tag_base + (tag_ix_next >> 2)];
+        const TagMonoid pre_next = tag_monoids[tag_ix_next >> 2];
+#ifdef VELLO_STROKE_TIMELINE
+        uint32_t stl[8] = {};
+#endif
+        STL_STAMP(0);
         Emitter em;
         em.lines = lines;
         em.lines_size = cfg.lines_size;
@@ -1317,10 +1359,9 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
         float x0 = 1e31f, y0 = 1e31f, x1 = -1e31f, y1 = -1e31f;
         const uint32_t e = base + tid;
         bool hand_on = false;
-        uint32_t tag_ix = 0u;
+        const uint32_t tag_ix = tag_ix_cur;
         if (e < n_lines_q) {
-            tag_ix = heavy_list[2u * n_tags + e];
-            hand_on = !flatten_stroked_line(em, arcs, cfg, scene, tag_monoids, tag_ix, key);
+            hand_on = !flatten_stroked_line(em, arcs, cfg, scene, tag_monoids, tag_ix, word_cur, pre_cur, key);
             if (hand_on) key = 0xffffffffu;
             else if (em.bx1 > em.bx0 || em.by1 > em.by0) {
                 x0 = em.bx0; y0 = em.by0; x1 = em.bx1; y1 = em.by1;
@@ -1328,11 +1369,13 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
         }
         // (rare: one atomic each is fine.  A list of its own: the heavy workgroups of this launch read the lengths of the
         // other three while this one grows)
+        STL_STAMP(1);
         if (hand_on) heavy_list[3u * n_tags + atomicAdd(&control->heavy_count[3], 1u)] = tag_ix;
         // The round's arcs go to the frame's list and -- when another round would no longer fit the staging area, or there is none --
         // the staged lines to the soup: the two reservations as ONE instruction of two lanes (they were two round trips in a row;
         // the soup's counter is one address for every workgroup of the launch: keep staging while another round still fits).
         __syncthreads();  // (sh.count, arcs.count: every emit of the round is behind this)
+        STL_STAMP(2);
         {
             const uint32_t n_arcs = arcs.count;
             const uint32_t shard = block % FLATTEN_ARC_SHARDS;
@@ -1349,11 +1392,29 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
             wave_bbox_update(path_bboxes, cfg.layout.n_paths, key, x0, y0, x1, y1, (int)lane);
             if (tid == 0u) arcs.base = got;
             if (tid == 1u) sh.base = got;
+#ifdef VELLO_STROKE_TIMELINE
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            STL_STAMP(3);
             __syncthreads();
+            STL_STAMP(4);
             // (a shard holds <= 256 arcs per round of each of its workgroups: arc_shard_cap is sized for that)
             if (tid < n_arcs && arcs.base + tid < arc_shard_cap) reinterpret_cast<ArcItem *>(arc_items)[shard * arc_shard_cap + arcs.base + tid] = arcs.item[tid];
             if (do_flush) copy_staged_lines(sh, lines, cfg.lines_size, sh.base, n_lds, tid);
+#ifdef VELLO_STROKE_TIMELINE
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            STL_STAMP(5);
             __syncthreads();
+            STL_STAMP(6);
+#ifdef VELLO_STROKE_TIMELINE
+            if (tid == 0u) {
+                const uint32_t slot = atomicAdd(&g_stroke_tl_n, 1u);
+                stl[7] = n_lds | (n_arcs << 16);
+                if (slot < STL_ROUNDS)
+                    for (uint32_t k = 0; k < 8u; k++) g_stroke_tl[slot][k] = stl[k];
+            }
+#endif
             if (tid == 0u) {
                 arcs.count = 0u;
                 if (do_flush) {
@@ -1363,6 +1424,10 @@ __device__ __forceinline__ void stroke_workgroup(FlattenShared<CAP> &sh, ArcQueu
             }
             __syncthreads();  // (the next round appends to both)
         }
+        tag_ix_cur = tag_ix_next;
+        tag_ix_next = tag_ix_after;
+        word_cur = word_next;
+        pre_cur = pre_next;
     }
 }
 
@@ -1676,6 +1741,19 @@ __global__ void __launch_bounds__(256) k_front(Config cfg, FrontArgs a) {
 #undef FRONT_STAGE_END
 }
 
+#ifdef VELLO_STROKE_TIMELINE
+}  // namespace vk
+// measurement build only: the stamps of the stroke workgroups' rounds since the last call, read and cleared (scripts/stroke_timeline.py)
+extern "C" int vello_stroke_timeline_read(uint32_t *out, uint32_t *n_out) {
+    uint32_t zero = 0u;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(n_out, HIP_SYMBOL(vk::g_stroke_tl_n), 4);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(vk::g_stroke_tl), sizeof(uint32_t) * 8u * vk::STL_ROUNDS);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(vk::g_stroke_tl_n), &zero, 4);
+    return (int)e;
+}
+namespace vk {
+#endif
 #ifdef VELLO_FLATTEN_PROF
 }  // namespace vk
 // measurement build only: the counters of g_flatten_prof, read and cleared (scripts/flatten_prof.py binds it with ctypes)
