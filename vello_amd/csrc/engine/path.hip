@@ -651,11 +651,29 @@ __global__ void __launch_bounds__(256) k_backdrop(Config cfg, const Bump *__rest
                 if (__ballot(v != 0) == 0ull && carry == 0) return;
                 const uint32_t col = i % width;
                 const int32_t own = v;
+                // the rows' inclusive sums: a lane may add the lane d to its left iff its column is >= d.  (Round 6: inside the 16-lane
+                // rows of the DPP by row shifts, then the totals of DPP rows 0 / 2 into rows 1 / 3 and of lane 31 into rows 2 and 3 where
+                // the tile row began before them -- ten vector operations and no trip through the LDS crossbar; the six ds_bpermute
+                // rounds, each with its wait, were most of the kernel's 9.6 M vector instructions: 60 % of the steps get here.)
+#ifdef VELLO_SIMT_EMU
 #pragma unroll
                 for (uint32_t d = 1; d < 64u; d <<= 1) {
                     const int32_t up = __shfl_up(v, (int)d);
                     if (lane >= d && col >= d) v += up;
                 }
+#else
+                {
+                    uint32_t u = (uint32_t)v;
+                    uint32_t t;
+                    t = VK_DPP0(u, 0x111, 0xf); u += col >= 1u ? t : 0u;
+                    t = VK_DPP0(u, 0x112, 0xf); u += col >= 2u ? t : 0u;
+                    t = VK_DPP0(u, 0x114, 0xf); u += col >= 4u ? t : 0u;
+                    t = VK_DPP0(u, 0x118, 0xf); u += col >= 8u ? t : 0u;
+                    t = VK_DPP0(u, 0x142, 0xa); u += col > (lane & 15u) ? t : 0u;   // (rows 1, 3: lane 15 / 47; rows 0, 2 get 0)
+                    t = VK_DPP0(u, 0x143, 0xc); u += col + 31u >= lane ? t : 0u;   // (rows 2, 3: lane 31; rows 0, 1 get 0)
+                    v = (int32_t)u;
+                }
+#endif
                 if (col > lane) v += carry;  // the row began before this step's first lane
                 carry = __shfl(v, 63);
                 if (valid && v != own) tiles[tile_ix].backdrop = v;
