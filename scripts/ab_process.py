@@ -22,6 +22,7 @@ import vello_amd._lib as L  # noqa: E402
 from vello_amd.renderer import STAGES  # noqa: E402
 
 WHITE = 0xFFFFFFFF
+NIF = int(os.environ.get("VELLO_AB_NIF", "4"))  # frames in flight (the ring of targets is as deep)
 
 
 def workload(key):
@@ -47,17 +48,17 @@ def main():
         eng = vello_amd.Engine(capacities=wl.caps) if wl.caps else vello_amd.Engine()
         eng.upload_scene(wl.packed, wl.layout)
         w, h, aa = wl.width, wl.height, wl.aa
-        ring = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+        ring = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for _ in range(NIF)]
         torch.cuda.synchronize()
-        eng.set_frames_in_flight(4)
+        eng.set_frames_in_flight(NIF)
         for i in range(20):
-            eng.render_resident(w, h, WHITE, aa, out=ring[i % 4])
+            eng.render_resident(w, h, WHITE, aa, out=ring[i % NIF])
         assert eng.sync() == 0, eng.bump()
         fps = []
         for _ in range(3):
             t = time.perf_counter()
             for i in range(200):
-                eng.render_resident(w, h, WHITE, aa, out=ring[i % 4])
+                eng.render_resident(w, h, WHITE, aa, out=ring[i % NIF])
             assert eng.sync() == 0
             fps.append(200 / (time.perf_counter() - t))
         eng.set_frames_in_flight(1)
