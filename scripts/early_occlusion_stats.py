@@ -107,5 +107,64 @@ def main():
           f"stay with k_coarse as today")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def lines_under_covers():
+    """What occlusion known before FLATTEN could leave out: the lines of d2's soup ALL of whose tiles (the tiles of the line's
+    bounding box: what a test per line could afford) lie under a later fill's opaque full cover.  occ[] as k_occ_build would make it: per
+    fill, the tiles of its rectangle without segments and with a backdrop that is not clear."""
+    seed, n_paths = 0x5EED0001, 30000
+    packed, layout = workloads.paris_like_scene_d2(seed).resolve()
+    w = h = 1600
+    o = Oracle(capacity_scale=8)
+    o.set_threads(8)
+    o.set_scene(packed, layout, w, h, 0xFFFFFFFF, 2)
+    o.render()
+    bump = o.bump()
+    tiles = o.buffer("tiles", np.int32).reshape(-1, 2)[: bump["tile"]]
+    paths = o.buffer("paths", np.uint32).reshape(-1, 8)[:n_paths]
+    lines_u = o.buffer("lines", np.uint32).reshape(-1, 6)[: bump["lines"]]
+    lines_f = o.buffer("lines", np.float32).reshape(-1, 6)[: bump["lines"]]
+    is_stroke = np.random.Generator(np.random.PCG64(seed)).random(n_paths) < 0.70
+    n_tx, n_ty = (w + 15) // 16, (h + 15) // 16
+    occ = np.zeros((n_ty, n_tx), np.int64)
+    for i in np.nonzero(~is_stroke)[0]:   # (every colour of the scene is opaque; the fills are non-zero)
+        x0, y0, x1, y1, first = (int(v) for v in paths[i, :5])
+        if x1 <= x0 or y1 <= y0:
+            continue
+        t = tiles[first: first + (x1 - x0) * (y1 - y0)].reshape(y1 - y0, x1 - x0, 2)
+        cover = (t[:, :, 1] == 0) & (t[:, :, 0] != 0)
+        sub = occ[y0:y1, x0:x1]
+        sub[cover] = np.maximum(sub[cover], i + 1)
+    print(f"tiles with an opaque full cover: {int((occ > 0).sum())} of {n_tx * n_ty}")
+    p = lines_u[:, 0].astype(np.int64)
+    ok = p < n_paths
+    xs0 = np.floor(np.minimum(lines_f[:, 2], lines_f[:, 4]) / 16).astype(np.int64)
+    xs1 = np.floor(np.maximum(lines_f[:, 2], lines_f[:, 4]) / 16).astype(np.int64)
+    ys0 = np.floor(np.minimum(lines_f[:, 3], lines_f[:, 5]) / 16).astype(np.int64)
+    ys1 = np.floor(np.maximum(lines_f[:, 3], lines_f[:, 5]) / 16).astype(np.int64)
+    inside = ok & (xs0 >= 0) & (ys0 >= 0) & (xs1 < n_tx) & (ys1 < n_ty)
+    # min of occ over the line's box of tiles, by a running minimum over the (few) tiles of the box
+    dead = np.zeros(lines_u.shape[0], bool)
+    idx = np.nonzero(inside)[0]
+    span = (xs1[idx] - xs0[idx] + 1) * (ys1[idx] - ys0[idx] + 1)
+    small = idx[span <= 16]
+    m = np.full(small.size, np.iinfo(np.int64).max)
+    for dy in range(4):
+        for dx in range(16):
+            xx, yy = xs0[small] + dx, ys0[small] + dy
+            use = (xx <= xs1[small]) & (yy <= ys1[small])
+            v = occ[np.minimum(yy, n_ty - 1), np.minimum(xx, n_tx - 1)]
+            m = np.where(use, np.minimum(m, v), m)
+    dead[small] = m > p[small] + 1
+    off = ok & ~inside & ((xs1 < 0) | (ys1 < 0) | (xs0 >= n_tx) | (ys0 >= n_ty))
+    n = lines_u.shape[0]
+    st = ok & is_stroke[np.minimum(p, n_paths - 1)]
+    print(f"lines {n}: of strokes {int(st.sum())}; every tile of the line's box under a later cover: {int(dead.sum())} = {100 * dead.sum() / n:.1f} % "
+          f"(strokes' {int((dead & st).sum())} = {100 * (dead & st).sum() / max(st.sum(), 1):.1f} % of theirs); wholly off the target {int(off.sum())}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "lines":
+    lines_under_covers()
