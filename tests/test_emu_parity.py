@@ -579,6 +579,35 @@ def test_emu_fuzz_extreme_values(emu_engine):
         emu_engine.set_auto_grow(False)
 
 
+def stroke_kernel_untame_inputs(eng, name, seeds=(4552, 8707, 11797)):
+    """The fuzz seeds whose paths of NaN lines got another box from the FORCED stroke kernel than from the oracle (a NaN makes min / max
+    depend on the order of their operands, and the kernel writes a tag's lines in another order than flatten.wgsl's one invocation): since
+    round 6 the kernel hands inputs that are not finite, or large enough to overflow, to the heavy code.  Every stage against the oracle,
+    with the kernel forced, one frame at a time and with frames in flight (the kernel as a launch of its own)."""
+    import vello_amd
+    from oracle.oracle import Oracle
+    from workloads.fuzz import fuzz_scene
+
+    eng.set_auto_grow(True)
+    try:
+        for seed in seeds:
+            r = vello_amd.Resolver().resolve(fuzz_scene(seed, n_ops=14, extreme=True))
+            aa = [AaConfig.Area, AaConfig.Msaa8, AaConfig.Msaa16][seed % 3]
+            for nif in (1, 2):
+                eng.set_frames_in_flight(nif)
+                eng.update_debug_flags(stroke_kernel=True)
+                compare_frame(eng, r.packed, r.layout, 128, 128, BLACK, aa, f"{name}_{seed}_{nif}", tol=1 if aa == AaConfig.Area else 0,
+                              resolved=r, order_sensitive=True, min_agree=None, back_half=False, oracle=Oracle(capacity_scale=4, auto_grow=True))
+    finally:
+        eng.update_debug_flags(stroke_kernel=False)
+        eng.set_frames_in_flight(1)
+        eng.set_auto_grow(False)
+
+
+def test_emu_stroke_kernel_untame_inputs(emu_engine):
+    stroke_kernel_untame_inputs(emu_engine, "emu_stroke_untame")
+
+
 @pytest.mark.parametrize("atlas", [None, (32, 128)])
 def test_emu_persistent_resolver_over_many_frames(emu_engine, atlas):
     # ONE Resolver across 100 frames of recurring fuzz scenes (60 distinct ones): ramp ids reused and evicted in the ramp cache

@@ -723,6 +723,13 @@ def test_gpu_path_count_both_forms(gpu_engine):
 
 
 @pytest.mark.gpu
+def test_gpu_stroke_kernel_untame_inputs(gpu_engine):
+    from tests.test_emu_parity import stroke_kernel_untame_inputs
+
+    stroke_kernel_untame_inputs(gpu_engine, "gpu_stroke_untame", seeds=(4552, 8707, 11797, 11851))
+
+
+@pytest.mark.gpu
 def test_gpu_path_count_long_lines(gpu_engine):
     from tests.test_emu_parity import path_count_long_lines
 

@@ -1227,6 +1227,20 @@ __device__ bool flatten_stroked_line(Emitter &em, ArcQueue &q, const Config &cfg
     bool n_is_closed = (ntag.tag_byte & PATH_TAG_SEG_TYPE) == PATH_TAG_LINETO;
     bool n_is_marker = (ntag.tag_byte & PATH_TAG_SUBPATH_END) != 0u;
     bool do_join = !n_is_marker || n_is_closed;
+    // Inputs that are not finite, or so large that the offsets or the transform overflow, go to the heavy code like a line that is not
+    // straight (round 6): a NaN makes min / max depend on the order of their operands, and this thread writes a tag's lines -- and the
+    // lane that takes its arc the rest -- in another order than flatten.wgsl's one invocation does, so the path's box came out differently
+    // (fuzz seeds 4552, 8707, 11797, 11851 with the kernel forced: DESIGN.md 4).  The largest magnitude by the bit patterns: NaN and
+    // infinity compare above every number.
+    {
+        auto mag = [](float f) { return __float_as_uint(f) & 0x7fffffffu; };
+        uint32_t m = maxu(maxu(mag(pts.p0.x), mag(pts.p0.y)), maxu(mag(pts.p3.x), mag(pts.p3.y)));
+        m = maxu(m, maxu(maxu(mag(npts.p0.x), mag(npts.p0.y)), maxu(mag(npts.p3.x), mag(npts.p3.y))));
+        m = maxu(m, maxu(maxu(mag(npts.p1.x), mag(npts.p1.y)), maxu(mag(npts.p2.x), mag(npts.p2.y))));
+        m = maxu(m, maxu(maxu(mag(transform.m0), mag(transform.m1)), maxu(mag(transform.m2), mag(transform.m3))));
+        m = maxu(m, maxu(maxu(mag(transform.t0), mag(transform.t1)), mag(offset)));
+        if (m > __float_as_uint(1.0e15f)) return false;
+    }
     vec2 n_tangent = npts.p3 - npts.p0;
     if (!n_is_marker) n_tangent = cubic_start_tangent(npts.p0, npts.p1, npts.p2, npts.p3);
     vec2 tan_start = cubic_start_tangent(pts.p0, pts.p1, pts.p2, pts.p3);
